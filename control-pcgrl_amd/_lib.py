@@ -1,0 +1,87 @@
+"""ctypes binding of csrc/libpcgrl_amd.so (the C ABI of include/pcgrl_amd.h).  No fallback: a missing or
+stale library is an error."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpcgrl_amd.so")
+SOURCES = ["pcgrl_engine.hip", "pcgrl_kernels2d.h", "pcgrl_sokoban.h", "pcgrl_common.h"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "pcgrl_amd.h")
+
+PCGRL_MAX_STATS = 8
+ERRORS = {1: "EINVAL", 2: "EUNSUPPORTED", 3: "EHIP", 4: "EACTION"}
+
+
+class PcgrlConfig(C.Structure):
+    _fields_ = [
+        ("problem", C.c_int32), ("representation", C.c_int32), ("ndim", C.c_int32),
+        ("dims", C.c_int32 * 3), ("obs_window", C.c_int32 * 3),
+        ("max_iterations", C.c_int32), ("max_changes", C.c_int32), ("n_stats", C.c_int32),
+        ("has_trg", C.c_int32 * PCGRL_MAX_STATS), ("weights", C.c_double * PCGRL_MAX_STATS),
+        ("trg_lo", C.c_double * PCGRL_MAX_STATS), ("trg_hi", C.c_double * PCGRL_MAX_STATS),
+        ("solver_power", C.c_int32),
+    ]
+
+
+SYMBOLS = {
+    # name: (restype, argtypes)
+    "pcgrl_create": (C.c_int, [C.POINTER(PcgrlConfig), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pcgrl_destroy": (None, [C.c_void_p]),
+    "pcgrl_seed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pcgrl_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
+    "pcgrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_obs_bytes": (C.c_int64, [C.c_void_p]),
+    "pcgrl_obs_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 4), C.POINTER(C.c_int32)]),
+    "pcgrl_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    "pcgrl_get_last_episode": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    "pcgrl_stats_for_grids": (C.c_int, [C.POINTER(PcgrlConfig), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p]),
+    "pcgrl_poll_error": (C.c_int, [C.c_void_p]),
+    "pcgrl_last_error": (C.c_char_p, []),
+    "pcgrl_version": (C.c_char_p, []),
+}
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Rebuilds when a source is newer."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-o", LIB_PATH, os.path.join(CSRC, "pcgrl_engine.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or control_pcgrl_amd._lib.build()).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().pcgrl_last_error().decode()
+        exc = ValueError if rc in (1, 4) else (NotImplementedError if rc == 2 else RuntimeError)
+        raise exc(f"{what}: PCGRL_{ERRORS.get(rc, rc)}: {msg}")

@@ -1,0 +1,75 @@
+// pcgrl_common.h -- state layout shared by the host API (pcgrl_engine.hip) and the gfx950 kernels.
+//
+// HBM layout (all arrays owned by the engine, contiguous over envs):
+//   planes  M[N][NB][H]   tile grid as NB = ceil(log2(n_tiles)) bit-planes; word (e,k,r) holds bit k of the
+//                         tile ids of row r (bit x = column x).  One wavefront lane owns one row, so a
+//                         16x16 binary map is 16 consecutive 32-bit words and a group of 16 lanes loads
+//                         its env with one coalesced 64-byte access per plane.
+//   st      EnvState[N]   128-byte record of per-env scalars (one cache line).
+//   rng     RngState[N]   two PCG64 streams (representation, problem), numpy-compatible.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/pcgrl_amd.h"
+
+namespace pcgrl {
+
+struct alignas(16) EnvState {
+  int32_t pos[3];
+  int32_t n_step;
+  int32_t iteration;
+  int32_t changes;
+  int32_t ep_len;
+  int32_t last_ep_len;
+  double last_loss;
+  double ep_return;
+  double last_ep_return;
+  int64_t n_episodes;
+  int32_t stats[PCGRL_MAX_STATS];
+  int32_t final_stats[PCGRL_MAX_STATS];
+};
+static_assert(sizeof(EnvState) == 128, "EnvState must be one 128-byte line");
+
+struct alignas(16) RngState {
+  uint64_t rep[4];   // state_hi, state_lo, inc_hi, inc_lo
+  uint64_t prob[4];
+};
+
+// LCG skip-ahead by k draws:  state' = A*state + G*inc  (mod 2^128), G = 1 + a + ... + a^(k-1)
+struct alignas(16) JumpEntry {
+  uint64_t a_hi, a_lo, g_hi, g_lo;
+};
+
+struct Params {
+  pcgrl_config cfg;
+  int32_t n_envs;
+  int32_t n_tiles;
+  int32_t n_bits;
+  int32_t n_cells;
+  int32_t obs_chunks;  // 16-byte chunks per observation row
+  void *planes;
+  EnvState *st;
+  RngState *rng;
+  const JumpEntry *jump;  // [H+1]: skip by row*W draws; entry H = H*W draws
+  int32_t *err;           // device error word
+  // per-call I/O
+  const int32_t *actions;
+  uint8_t *obs;
+  float *reward;
+  uint8_t *done;
+  int32_t *stats_out;
+  int32_t auto_reset;
+  const uint8_t *mask;
+  const uint8_t *init_grids;
+  const int32_t *init_pos;
+  // get_state outputs
+  uint8_t *out_grids;
+  int32_t *out_pos;
+  int32_t *out_counters;
+  double *out_last_loss;
+  double *out_ep_return;
+  int32_t *out_ep_len;
+  int64_t *out_n_episodes;
+};
+
+}  // namespace pcgrl

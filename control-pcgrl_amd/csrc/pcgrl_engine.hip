@@ -1,0 +1,412 @@
+// pcgrl_engine.hip -- host side of libpcgrl_amd.so: the C ABI declared in include/pcgrl_amd.h.
+//
+// Owns the per-env state in HBM, seeds the numpy-compatible RNG streams, validates configs and launches the
+// gfx950 kernels of pcgrl_kernels2d.h / pcgrl_kernels3d.h on the caller's HIP stream.  No torch types, no
+// hidden synchronisation in reset/step/observe.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pcgrl_common.h"
+#include "pcgrl_kernels2d.h"
+#include "pcgrl_sokoban.h"
+
+using namespace pcgrl;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t _e = (x);                                                                            \
+    if (_e != hipSuccess) return fail(PCGRL_EHIP, std::string(#x) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct pcgrl_engine {
+  Params p;
+  int device = 0;
+  int lpe = 16;
+  size_t lds_bytes = 0;
+  int64_t obs_bytes = 0;
+  int obs_ndim = 0;
+  int32_t obs_shape[4] = {0, 0, 0, 0};
+  std::vector<void *> allocs;
+};
+
+// ---------------------------------------------------------------------------------------------- RNG seeding (host)
+// numpy.random.SeedSequence(seed).generate_state(4, uint64) -> PCG64 state/inc (numpy/random/bit_generator.pyx,
+// _pcg64.pyx, src/pcg64/pcg64.h); reached in the reference through gymnasium.utils.seeding.np_random
+// (envs/reps/representation.py:50-53, envs/probs/problem.py:79-81).
+static void seedseq_words(uint64_t seed, uint64_t out[4]) {
+  const uint32_t INIT_A = 0x43b0d7e5u, MULT_A = 0x931e8875u, INIT_B = 0x8b51f9ddu, MULT_B = 0x58f38dedu;
+  const uint32_t MIX_L = 0xca01f9ddu, MIX_R = 0x4973f715u;
+  uint32_t ent[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0, 0};
+  int n_ent = ent[1] ? 2 : 1;
+  uint32_t pool[4], hc = INIT_A;
+  auto hashmix = [&](uint32_t v) {
+    v ^= hc;
+    hc *= MULT_A;
+    v *= hc;
+    v ^= v >> 16;
+    return v;
+  };
+  for (int i = 0; i < 4; i++) pool[i] = hashmix(i < n_ent ? ent[i] : 0u);
+  for (int s = 0; s < 4; s++)
+    for (int d = 0; d < 4; d++)
+      if (s != d) {
+        uint32_t r = MIX_L * pool[d] - MIX_R * hashmix(pool[s]);
+        r ^= r >> 16;
+        pool[d] = r;
+      }
+  uint32_t w[8], hb = INIT_B;
+  for (int i = 0; i < 8; i++) {
+    uint32_t v = pool[i & 3] ^ hb;
+    hb *= MULT_B;
+    v *= hb;
+    v ^= v >> 16;
+    w[i] = v;
+  }
+  for (int i = 0; i < 4; i++) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+
+static void pcg64_seed_state(uint64_t seed, uint64_t st[4]) {
+  uint64_t w[4];
+  seedseq_words(seed, w);
+  const U128 mult{PCG_MULT_HI, PCG_MULT_LO};
+  U128 initstate{w[0], w[1]}, initseq{w[2], w[3]};
+  U128 inc{(initseq.hi << 1) | (initseq.lo >> 63), (initseq.lo << 1) | 1ull};
+  U128 s{0, 0};
+  s = add128(mul128(s, mult), inc);
+  s = add128(s, initstate);
+  s = add128(mul128(s, mult), inc);
+  st[0] = s.hi;
+  st[1] = s.lo;
+  st[2] = inc.hi;
+  st[3] = inc.lo;
+}
+
+// ---------------------------------------------------------------------------------------------- config
+static int n_tiles_of(int prob) {
+  switch (prob) {
+    case PCGRL_PROB_BINARY: return 2;
+    case PCGRL_PROB_ZELDA: return 8;
+    case PCGRL_PROB_SOKOBAN: return 5;
+    case PCGRL_PROB_MC3DMAZE: return 2;
+  }
+  return 0;
+}
+static int n_stats_of(int prob) {
+  switch (prob) {
+    case PCGRL_PROB_BINARY: return 2;
+    case PCGRL_PROB_ZELDA: return 7;
+    case PCGRL_PROB_SOKOBAN: return 7;
+    case PCGRL_PROB_MC3DMAZE: return 3;
+  }
+  return 0;
+}
+
+static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &obs_chunks, int32_t shape[4], int &ndim) {
+  if (c.problem < 0 || c.problem > PCGRL_PROB_MC3DMAZE) return fail(PCGRL_EINVAL, "unknown problem");
+  if (c.representation < 0 || c.representation > PCGRL_REP_WIDE) return fail(PCGRL_EINVAL, "unknown representation");
+  if (c.n_stats != n_stats_of(c.problem)) return fail(PCGRL_EINVAL, "n_stats does not match the problem");
+  const int nt = n_tiles_of(c.problem);
+  if (c.problem == PCGRL_PROB_MC3DMAZE) return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze kernels are not built yet");
+  if (c.ndim != 2) return fail(PCGRL_EINVAL, "2-D problem needs ndim == 2");
+  const int H = c.dims[0], W = c.dims[1];
+  if (H < 1 || W < 1 || H > 64 || W > 32) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 32");
+  lpe = H <= 8 ? 8 : (H <= 16 ? 16 : (H <= 32 ? 32 : 64));
+  if (c.representation == PCGRL_REP_WIDE) {
+    if (c.obs_window[0] != H || c.obs_window[1] != W)
+      return fail(PCGRL_EINVAL, "wide representation needs obs_window == map_shape (reference wrappers.py:140-150 reshape)");
+    if (H != W) return fail(PCGRL_EUNSUPPORTED, "wide representation: the reference's transposed write needs a square map");
+    if ((W * nt) % 16) return fail(PCGRL_EUNSUPPORTED, "wide observation rows must be a multiple of 16 bytes");
+    obs_chunks = W * nt / 16;
+    obs_bytes = (int64_t)H * W * nt;
+    shape[0] = H;
+    shape[1] = W;
+    shape[2] = nt;
+    ndim = 3;
+  } else {
+    const int OH = c.obs_window[0], OW = c.obs_window[1], C = nt + 1;
+    if (OH < 1 || OW < 1) return fail(PCGRL_EINVAL, "obs_window must be positive");
+    if ((OW * C) % 16) return fail(PCGRL_EUNSUPPORTED, "obs_window[1] * (n_tiles+1) must be a multiple of 16 bytes");
+    obs_chunks = OW * C / 16;
+    obs_bytes = (int64_t)OH * OW * C;
+    shape[0] = OH;
+    shape[1] = OW;
+    shape[2] = C;
+    ndim = 3;
+  }
+  return PCGRL_OK;
+}
+
+static std::vector<JumpEntry> make_jump_table(int H, int W) {
+  // A_k = a^k, G_k = 1 + a + ... + a^(k-1)  (mod 2^128); entry r = skip r*W draws, entry H = H*W draws
+  std::vector<JumpEntry> t(H + 1);
+  U128 A{0, 1}, G{0, 0};
+  const U128 a{PCG_MULT_HI, PCG_MULT_LO};
+  int k = 0;
+  for (int r = 0; r <= H; r++) {
+    while (k < r * W) {
+      G = add128(mul128(G, a), U128{0, 1});
+      A = mul128(A, a);
+      k++;
+    }
+    t[r] = JumpEntry{A.hi, A.lo, G.hi, G.lo};
+  }
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------- dispatch
+enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS };
+
+template <int PROB, int LPE>
+static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_t s) {
+  const int epw = 64 / LPE;
+  dim3 grid((p.n_envs + epw - 1) / epw), block(64);
+  switch (id) {
+    case K_STEP: hipLaunchKernelGGL((step_kernel<PROB, LPE>), grid, block, lds, s, p); break;
+    case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE>), grid, block, lds, s, p); break;
+    case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<PROB, LPE>), grid, block, lds, s, p); break;
+    case K_GET_STATE: hipLaunchKernelGGL((get_state_kernel<PROB, LPE>), grid, block, 0, s, p); break;
+    case K_LAST_EPISODE:
+      hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
+      break;
+    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE>), grid, block, 0, s, p); break;
+  }
+  return hipGetLastError();
+}
+
+template <int PROB>
+static hipError_t launch_p(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s) {
+  switch (lpe) {
+    case 8: return launch_pl<PROB, 8>(id, p, lds, s);
+    case 16: return launch_pl<PROB, 16>(id, p, lds, s);
+    case 32: return launch_pl<PROB, 32>(id, p, lds, s);
+    default: return launch_pl<PROB, 64>(id, p, lds, s);
+  }
+}
+
+static hipError_t launch(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s) {
+  switch (p.cfg.problem) {
+    case PCGRL_PROB_BINARY: return launch_p<PCGRL_PROB_BINARY>(id, lpe, p, lds, s);
+    case PCGRL_PROB_ZELDA: return launch_p<PCGRL_PROB_ZELDA>(id, lpe, p, lds, s);
+    default: return launch_p<PCGRL_PROB_SOKOBAN>(id, lpe, p, lds, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char *pcgrl_last_error(void) { return g_err.c_str(); }
+const char *pcgrl_version(void) { return "pcgrl_amd 0.1 (gfx950)"; }
+
+int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_handle *out) {
+  if (!cfg || !out || n_envs < 1) return fail(PCGRL_EINVAL, "pcgrl_create: bad arguments");
+  int lpe = 16, obs_chunks = 0, ndim = 0;
+  int64_t obs_bytes = 0;
+  int32_t shape[4] = {0, 0, 0, 0};
+  int rc = validate(*cfg, lpe, obs_bytes, obs_chunks, shape, ndim);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(device));
+  pcgrl_engine *e = new pcgrl_engine();
+  e->device = device;
+  e->lpe = lpe;
+  e->obs_bytes = obs_bytes;
+  e->obs_ndim = ndim;
+  memcpy(e->obs_shape, shape, sizeof(shape));
+  Params &p = e->p;
+  memset(&p, 0, sizeof(p));
+  p.cfg = *cfg;
+  p.n_envs = n_envs;
+  p.n_tiles = n_tiles_of(cfg->problem);
+  p.n_bits = p.n_tiles <= 2 ? 1 : 3;
+  p.n_cells = cfg->dims[0] * cfg->dims[1];
+  p.obs_chunks = obs_chunks;
+  e->lds_bytes = (size_t)obs_chunks * 64 * 16;
+  const int H = cfg->dims[0], W = cfg->dims[1];
+  auto dalloc = [&](void **ptr, size_t bytes) -> hipError_t {
+    hipError_t err = hipMalloc(ptr, bytes);
+    if (err == hipSuccess) {
+      e->allocs.push_back(*ptr);
+      err = hipMemset(*ptr, 0, bytes);
+    }
+    return err;
+  };
+#define CREATE_CHK(x)                                                                                \
+  do {                                                                                               \
+    hipError_t _e = (x);                                                                             \
+    if (_e != hipSuccess) {                                                                          \
+      pcgrl_destroy(e);                                                                              \
+      return fail(PCGRL_EHIP, std::string(#x) + ": " + hipGetErrorString(_e));                       \
+    }                                                                                                \
+  } while (0)
+  CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * p.n_bits * H * sizeof(uint32_t)));
+  CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
+  CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
+  CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 4));
+  std::vector<JumpEntry> jt = make_jump_table(H, W);
+  JumpEntry *djt = nullptr;
+  CREATE_CHK(dalloc((void **)&djt, jt.size() * sizeof(JumpEntry)));
+  CREATE_CHK(hipMemcpy(djt, jt.data(), jt.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
+  p.jump = djt;
+  if (cfg->problem == PCGRL_PROB_SOKOBAN) CREATE_CHK(sokoban_alloc(p, e->allocs));
+#undef CREATE_CHK
+  *out = e;
+  // default seeding: env i gets seed i (callers normally call pcgrl_seed)
+  std::vector<uint64_t> seeds(n_envs);
+  for (int i = 0; i < n_envs; i++) seeds[i] = (uint64_t)i;
+  return pcgrl_seed(e, seeds.data());
+}
+
+void pcgrl_destroy(pcgrl_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (void *a : h->allocs) (void)hipFree(a);
+  delete h;
+}
+
+int pcgrl_seed(pcgrl_handle h, const uint64_t *seeds) {
+  if (!h || !seeds) return fail(PCGRL_EINVAL, "pcgrl_seed: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<RngState> r(h->p.n_envs);
+  for (int i = 0; i < h->p.n_envs; i++) {
+    pcg64_seed_state(seeds[i], r[i].rep);
+    memcpy(r[i].prob, r[i].rep, sizeof(r[i].rep));  // envs/pcgrl_env.py:142-146: same seed for both streams
+  }
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(h->p.rng, r.data(), r.size() * sizeof(RngState), hipMemcpyHostToDevice));
+  return PCGRL_OK;
+}
+
+int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_grids, const int32_t *d_init_pos, void *stream) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_reset: null handle");
+  Params p = h->p;
+  p.mask = d_mask;
+  p.init_grids = d_init_grids;
+  p.init_pos = d_init_pos;
+  HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
+  if (p.cfg.problem == PCGRL_PROB_SOKOBAN) HIPCHK(sokoban_launch(p, h->lpe, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done,
+               int32_t *d_stats, void *stream) {
+  if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step: bad arguments");
+  Params p = h->p;
+  p.actions = d_actions;
+  p.auto_reset = auto_reset;
+  p.obs = d_obs;
+  p.reward = d_reward;
+  p.done = d_done;
+  p.stats_out = d_stats;
+  HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
+  if (p.cfg.problem == PCGRL_PROB_SOKOBAN) HIPCHK(sokoban_launch(p, h->lpe, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream) {
+  if (!h || !d_obs) return fail(PCGRL_EINVAL, "pcgrl_observe: bad arguments");
+  Params p = h->p;
+  p.obs = d_obs;
+  HIPCHK(launch(K_OBSERVE, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int64_t pcgrl_obs_bytes(pcgrl_handle h) { return h ? h->obs_bytes : -1; }
+
+int pcgrl_obs_shape(pcgrl_handle h, int32_t shape_out[4], int32_t *ndim_out) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_obs_shape: null handle");
+  memcpy(shape_out, h->obs_shape, sizeof(h->obs_shape));
+  *ndim_out = h->obs_ndim;
+  return PCGRL_OK;
+}
+
+int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d_counters, int32_t *d_stats, double *d_last_loss,
+                    double *d_ep_return, void *stream) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_get_state: null handle");
+  Params p = h->p;
+  p.out_grids = d_grids;
+  p.out_pos = d_pos;
+  p.out_counters = d_counters;
+  p.stats_out = d_stats;
+  p.out_last_loss = d_last_loss;
+  p.out_ep_return = d_ep_return;
+  HIPCHK(launch(K_GET_STATE, h->lpe, p, 0, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_len, int32_t *d_final_stats, int64_t *d_n_episodes,
+                           void *stream) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_get_last_episode: null handle");
+  Params p = h->p;
+  p.out_ep_return = d_ep_return;
+  p.out_ep_len = d_ep_len;
+  p.stats_out = d_final_stats;
+  p.out_n_episodes = d_n_episodes;
+  HIPCHK(launch(K_LAST_EPISODE, h->lpe, p, 0, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_grids, int32_t *d_stats, int32_t device, void *stream) {
+  if (!cfg || n < 1 || !d_grids || !d_stats) return fail(PCGRL_EINVAL, "pcgrl_stats_for_grids: bad arguments");
+  int lpe = 16, obs_chunks = 0, ndim = 0;
+  int64_t obs_bytes = 0;
+  int32_t shape[4];
+  pcgrl_config c = *cfg;
+  c.representation = PCGRL_REP_NARROW;
+  c.obs_window[0] = 2 * c.dims[0];
+  c.obs_window[1] = 32;  // unused here; any legal value
+  int rc = validate(c, lpe, obs_bytes, obs_chunks, shape, ndim);
+  if (rc) return rc;
+  if (c.problem == PCGRL_PROB_SOKOBAN) {
+    // the solver needs engine-owned scratch: go through a transient engine
+    pcgrl_handle h = nullptr;
+    rc = pcgrl_create(&c, n, device, &h);
+    if (rc) return rc;
+    Params p = h->p;
+    p.init_grids = d_grids;
+    p.stats_out = d_stats;
+    hipError_t e1 = launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream);
+    hipError_t e2 = e1 == hipSuccess ? sokoban_launch(p, lpe, (hipStream_t)stream) : e1;
+    hipError_t e3 = hipStreamSynchronize((hipStream_t)stream);
+    pcgrl_destroy(h);
+    if (e2 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e2));
+    if (e3 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e3));
+    return PCGRL_OK;
+  }
+  HIPCHK(hipSetDevice(device));
+  Params p;
+  memset(&p, 0, sizeof(p));
+  p.cfg = c;
+  p.n_envs = n;
+  p.n_tiles = n_tiles_of(c.problem);
+  p.n_bits = p.n_tiles <= 2 ? 1 : 3;
+  p.n_cells = c.dims[0] * c.dims[1];
+  p.init_grids = d_grids;
+  p.stats_out = d_stats;
+  HIPCHK(launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_poll_error(pcgrl_handle h) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_poll_error: null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(flags, h->p.err, sizeof(flags), hipMemcpyDeviceToHost));
+  if (flags[0]) {
+    HIPCHK(hipMemset(h->p.err, 0, sizeof(flags)));
+    if (flags[0] & 1) return fail(PCGRL_EACTION, "an action was outside the action space (the reference raises IndexError)");
+    if (flags[0] & 2) return fail(PCGRL_EUNSUPPORTED, "sokoban solver: level exceeds the device solver's limits");
+    return fail(PCGRL_EINVAL, "device error flag set");
+  }
+  return PCGRL_OK;
+}
+
+}  // extern "C"

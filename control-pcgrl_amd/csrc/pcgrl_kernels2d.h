@@ -1,0 +1,821 @@
+// pcgrl_kernels2d.h -- gfx950 kernels for the 2-D problems (binary, zelda, sokoban).
+//
+// Execution model: a wavefront (64 lanes) is split into groups of LPE lanes, one group per env, one lane per
+// map ROW.  A row of W<=32 tiles is held as bit masks in VGPRs (one 32-bit word per bit-plane), so
+//   * horizontal neighbours are 1-bit shifts inside the lane,
+//   * vertical neighbours are one DPP row_shr:1 / row_shl:1 lane shift (a DPP row is 16 lanes = one 16x16 env),
+//   * "is any frontier left" is a 64-bit wave ballot, sliced per group,
+//   * "first cell in row-major order" is ctz(ballot) then ctz(row word).
+// Flood fill / BFS therefore run on whole rows per instruction and never touch memory.  LDS is used only to
+// assemble the byte-granular one-hot observation rows before they are written with 16-byte stores.
+// No MFMA: this is integer/bit work, bounded by HBM writes of the observation tensor.
+//
+// Reference semantics restated here (paths relative to the reference's control_pcgrl/):
+//   envs/pcgrl_env.py:158-188, :267-342   reset / step orchestration
+//   envs/reps/{narrow,turtle,wide}_rep.py update()
+//   envs/helper.py:173-276                flood fill, BFS ("dijkstra"), longest path
+//   envs/probs/binary/binary_prob.py:152-158, zelda/zelda_ctrl_prob.py:90-168, sokoban/sokoban_prob.py:160-180
+//   control_wrappers.py:216-244, :318-345 reward = delta of weighted target distance
+//   wrappers.py:407-437, :232-257, :140-150  cropped one-hot observation
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pcgrl_common.h"
+
+namespace pcgrl {
+
+// ------------------------------------------------------------------------------------------------ PCG64
+struct U128 {
+  uint64_t hi, lo;
+};
+__host__ __device__ inline U128 mul128(U128 a, U128 b) {
+  U128 r;
+  r.lo = a.lo * b.lo;
+#ifdef __HIP_DEVICE_COMPILE__
+  r.hi = __umul64hi(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi;
+#else
+  r.hi = (uint64_t)(((unsigned __int128)a.lo * b.lo) >> 64) + a.hi * b.lo + a.lo * b.hi;
+#endif
+  return r;
+}
+__host__ __device__ inline U128 add128(U128 a, U128 b) {
+  U128 r;
+  r.lo = a.lo + b.lo;
+  r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+  return r;
+}
+#define PCG_MULT_HI 0x2360ED051FC65DA4ULL
+#define PCG_MULT_LO 0x4385DF649FCCF645ULL
+
+struct Pcg {
+  U128 s, inc;
+  __device__ inline void load(const uint64_t *p) {
+    s.hi = p[0];
+    s.lo = p[1];
+    inc.hi = p[2];
+    inc.lo = p[3];
+  }
+  __device__ inline void store(uint64_t *p) const {
+    p[0] = s.hi;
+    p[1] = s.lo;
+  }
+  __device__ inline uint64_t next() {
+    s = add128(mul128(s, U128{PCG_MULT_HI, PCG_MULT_LO}), inc);
+    uint64_t x = s.hi ^ s.lo;
+    unsigned rot = (unsigned)(s.hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+  }
+  __device__ inline double next_double() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  __device__ inline void jump(const JumpEntry &j) {
+    s = add128(mul128(U128{j.a_hi, j.a_lo}, s), mul128(U128{j.g_hi, j.g_lo}, inc));
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ lane groups
+template <int LPE>
+struct Grp {
+  static_assert(LPE == 8 || LPE == 16 || LPE == 32 || LPE == 64, "lanes per env");
+  int lane, row, gbase;
+  __device__ inline void init() {
+    lane = (int)__lane_id();
+    row = lane & (LPE - 1);
+    gbase = lane - row;
+  }
+  // value held by lane-1 / lane+1 of the same group (0 at the group edge)
+  __device__ inline uint32_t from_above(uint32_t v) const {
+    uint32_t r;
+    if constexpr (LPE <= 16) {
+      r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, true);
+      if constexpr (LPE < 16) r = row == 0 ? 0u : r;
+    } else {
+      r = (uint32_t)__shfl_up((int)v, 1, 64);
+      r = row == 0 ? 0u : r;
+    }
+    return r;
+  }
+  __device__ inline uint32_t from_below(uint32_t v) const {
+    uint32_t r;
+    if constexpr (LPE <= 16) {
+      r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xF, 0xF, true);
+      if constexpr (LPE < 16) r = row == LPE - 1 ? 0u : r;
+    } else {
+      r = (uint32_t)__shfl_down((int)v, 1, 64);
+      r = row == LPE - 1 ? 0u : r;
+    }
+    return r;
+  }
+  // this group's slice of a wave ballot
+  __device__ inline uint64_t gballot(bool p) const {
+    uint64_t b = __ballot(p);
+    if constexpr (LPE == 64) return b;
+    return (b >> gbase) & ((1ull << LPE) - 1ull);
+  }
+  __device__ inline bool gany(bool p) const { return gballot(p) != 0; }
+  // sum over the group's lanes (result in every lane)
+  __device__ inline uint32_t gsum(uint32_t v) const {
+#pragma unroll
+    for (int o = 1; o < LPE; o <<= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+  }
+  // broadcast from the group's lane `src_row`
+  __device__ inline uint32_t gbcast(uint32_t v, int src_row) const { return (uint32_t)__shfl((int)v, gbase + src_row, 64); }
+};
+
+// 4-neighbour dilation of a row-mask set (without the set itself; callers AND with the passable mask,
+// which also removes the bit shifted past column W-1)
+template <int LPE>
+__device__ inline uint32_t expand(const Grp<LPE> &g, uint32_t f) {
+  return (f << 1) | (f >> 1) | g.from_above(f) | g.from_below(f);
+}
+
+// first set cell in row-major order: one bit in one lane of the group (0 everywhere if the set is empty)
+template <int LPE>
+__device__ inline uint32_t first_rowmajor(const Grp<LPE> &g, uint32_t x) {
+  uint64_t gb = g.gballot(x != 0);
+  int fl = gb ? __builtin_ctzll(gb) : -1;
+  return g.row == fl ? (x & (0u - x)) : 0u;
+}
+
+// all cells of the horizontal runs of `a` that contain a bit of s (s subset of a): carry-propagation fill
+__device__ inline uint32_t hfill(uint32_t s, uint32_t a) {
+  uint32_t up = (a & ~(a + s)) | s;
+  uint32_t ar = __brev(a), sr = __brev(s);
+  uint32_t dn = __brev((ar & ~(ar + sr)) | sr);
+  return up | dn;
+}
+
+// helper.py:200-210 calc_num_regions: number of 4-connected components of `avail`.
+// Components are peeled off in row-major order of their first cell; each fill alternates an O(1) horizontal
+// run fill with a one-row vertical step until it stops growing.
+template <int LPE>
+__device__ inline int count_regions(const Grp<LPE> &g, uint32_t avail) {
+  uint32_t remaining = avail;
+  int n = 0;
+  while (true) {
+    uint64_t gb = g.gballot(remaining != 0);
+    if (__ballot(gb != 0) == 0) break;
+    int fl = gb ? __builtin_ctzll(gb) : -1;
+    uint32_t f = g.row == fl ? (remaining & (0u - remaining)) : 0u;
+    f = hfill(f, remaining);
+    while (true) {
+      uint32_t v = (g.from_above(f) | g.from_below(f)) & remaining & ~f;
+      if (__ballot(v != 0) == 0) break;
+      f = hfill(f | v, remaining);
+    }
+    remaining &= ~f;
+    n += gb != 0;
+  }
+  return n;
+}
+
+// helper.py:255-276 calc_longest_path + :200-210 calc_num_regions over the same passable set.
+// Per component (row-major order of first cell): level-synchronous BFS from the first cell; the last
+// non-empty frontier holds the farthest cells and np.argmax picks its first cell in row-major order.
+// The second BFS runs from all "far" cells at once (components are disjoint): the number of levels until
+// every frontier is empty is max over components of the eccentricity = the reference's final_value.
+template <int LPE>
+__device__ inline void regions_and_longest_path(const Grp<LPE> &g, uint32_t pass, int &regions, int &path_len) {
+  uint32_t remaining = pass, fars = 0;
+  int reg = 0;
+  // isolated cells are components of their own with path length 0: count them in one shot
+  {
+    uint32_t iso = pass & ~expand(g, pass);
+    reg += (int)g.gsum((uint32_t)__popc(iso));
+    remaining &= ~iso;
+  }
+  while (true) {
+    uint64_t gb = g.gballot(remaining != 0);
+    if (__ballot(gb != 0) == 0) break;
+    int fl = gb ? __builtin_ctzll(gb) : -1;
+    uint32_t seed = g.row == fl ? (remaining & (0u - remaining)) : 0u;
+    uint32_t front = seed, vis = seed, last = seed;
+    int lastlev = 0, lev = 0;
+    while (true) {
+      uint32_t nb = expand(g, front) & remaining & ~vis;
+      if (__ballot(nb != 0) == 0) break;
+      lev++;
+      vis |= nb;
+      front = nb;
+      if (nb) {
+        last = nb;
+        lastlev = lev;
+      }
+    }
+    // deepest level reached in this group, then the first cell of that level
+    int maxlev = lastlev;
+#pragma unroll
+    for (int o = 1; o < LPE; o <<= 1) maxlev = max(maxlev, __shfl_xor(maxlev, o, 64));
+    uint32_t cand = (lastlev == maxlev) ? last : 0u;
+    fars |= first_rowmajor(g, cand);
+    remaining &= ~vis;
+    reg += gb != 0;
+  }
+  uint32_t front = fars, vis = fars;
+  int len = 0;
+  while (true) {
+    uint32_t nb = expand(g, front) & pass & ~vis;
+    uint64_t gn = g.gballot(nb != 0);
+    if (__ballot(gn != 0) == 0) break;
+    vis |= nb;
+    front = nb;
+    len += gn != 0;
+  }
+  regions = reg;
+  path_len = len;
+}
+
+// helper.py:225-240 run_dijkstra from a single source, reduced to "distance to the first target cell":
+// level k >= 1 at which the frontier first meets targetA / targetB, or -1 if the frontier dies first.
+template <int LPE>
+__device__ inline void bfs_first_hit(const Grp<LPE> &g, uint32_t src, uint32_t avail, uint32_t targetA, uint32_t targetB,
+                                     int &dA, int &dB) {
+  uint32_t front = src & avail, vis = front;
+  bool needA = g.gany(targetA != 0), needB = g.gany(targetB != 0);
+  dA = -1;
+  dB = -1;
+  int lev = 0;
+  while (true) {
+    uint32_t nb = expand(g, front) & avail & ~vis;
+    bool alive = g.gany(nb != 0) && (needA || needB);
+    if (__ballot(alive) == 0) break;
+    lev++;
+    nb = alive ? nb : 0u;
+    vis |= nb;
+    front = nb;
+    bool hitA = g.gany((nb & targetA) != 0), hitB = g.gany((nb & targetB) != 0);
+    if (needA && hitA) {
+      dA = lev;
+      needA = false;
+    }
+    if (needB && hitB) {
+      dB = lev;
+      needB = false;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ per-problem stats
+template <int PROB>
+struct ProbTraits;
+template <>
+struct ProbTraits<PCGRL_PROB_BINARY> {
+  static constexpr int NT = 2, NB = 1, NS = 2;
+};
+template <>
+struct ProbTraits<PCGRL_PROB_ZELDA> {
+  static constexpr int NT = 8, NB = 3, NS = 7;
+};
+template <>
+struct ProbTraits<PCGRL_PROB_SOKOBAN> {
+  static constexpr int NT = 5, NB = 3, NS = 7;
+};
+
+struct SokobanWork;  // device-side solver scratch (pcgrl_sokoban.h)
+template <int LPE>
+__device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
+                              uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
+
+template <int PROB, int LPE>
+__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, const uint32_t *b,
+                                     uint32_t colmask, int32_t *st) {
+  if constexpr (PROB == PCGRL_PROB_BINARY) {
+    // binary_prob.py:152-158: regions and path-length over "empty" (tile 0)
+    uint32_t pass = active ? (~b[0] & colmask) : 0u;
+    int reg, len;
+    regions_and_longest_path(g, pass, reg, len);
+    st[0] = reg;
+    st[1] = len;
+  } else if constexpr (PROB == PCGRL_PROB_ZELDA) {
+    // zelda_ctrl_prob.py:90-168.  ids: 0 empty 1 solid 2 player 3 key 4 door 5 bat 6 scorpion 7 spider
+    uint32_t cm = active ? colmask : 0u;
+    uint32_t solid = b[0] & ~b[1] & ~b[2] & cm, door = ~b[0] & ~b[1] & b[2] & cm;
+    uint32_t player = ~b[0] & b[1] & ~b[2] & cm, key = b[0] & b[1] & ~b[2] & cm, enemy = b[2] & (b[0] | b[1]) & cm;
+    uint32_t walk = cm & ~(solid | door), walkd = cm & ~solid;
+    uint32_t c01 = g.gsum((uint32_t)__popc(player) | ((uint32_t)__popc(key) << 16));
+    uint32_t c23 = g.gsum((uint32_t)__popc(door) | ((uint32_t)__popc(enemy) << 16));
+    int n_player = c01 & 0xFFFF, n_key = c01 >> 16, n_door = c23 & 0xFFFF, n_enemy = c23 >> 16;
+    st[0] = n_player;
+    st[1] = n_key;
+    st[2] = n_door;
+    st[3] = n_enemy;
+    st[4] = count_regions(g, walk);
+    int nearest = 0, plen = 0;
+    bool one_player = n_player == 1;
+    bool want_enemy = one_player && n_enemy > 0;
+    bool want_path = one_player && n_key == 1 && n_door == 1;
+    if (__ballot(want_enemy || want_path) != 0) {
+      int dE, dK, dD, dummy;
+      bfs_first_hit(g, (want_enemy || want_path) ? player : 0u, walk, want_enemy ? enemy : 0u, want_path ? key : 0u, dE, dK);
+      if (want_enemy) nearest = dE > 0 ? dE : 0;
+      if (__ballot(want_path) != 0) {
+        bfs_first_hit(g, want_path ? key : 0u, walkd, want_path ? door : 0u, 0u, dD, dummy);
+        if (want_path) plen = dK + dD;  // each term is -1 when unreachable
+      }
+    }
+    st[5] = nearest;
+    st[6] = plen;
+  } else {
+    // sokoban_prob.py:160-180 + sokoban_ctrl_prob.py:58-65.  ids: 0 empty 1 solid 2 player 3 crate 4 target
+    uint32_t cm = active ? colmask : 0u;
+    uint32_t solid = b[0] & ~b[1] & ~b[2] & cm, player = ~b[0] & b[1] & ~b[2] & cm;
+    uint32_t crate = b[0] & b[1] & ~b[2] & cm, target = ~b[0] & ~b[1] & b[2] & cm;
+    uint32_t c01 = g.gsum((uint32_t)__popc(player) | ((uint32_t)__popc(crate) << 16));
+    int n_player = c01 & 0xFFFF, n_crate = c01 >> 16, n_target = (int)g.gsum((uint32_t)__popc(target));
+    int regions = count_regions(g, cm & ~solid);
+    int dist_win = p.cfg.dims[0] * p.cfg.dims[1] * (p.cfg.dims[0] + p.cfg.dims[1]);
+    int sol_len = 0;
+    bool need = active && n_player == 1 && n_crate == n_target && n_crate > 0 && regions == 1;
+    if (__ballot(need) != 0) sokoban_solve(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
+    st[0] = n_player;
+    st[1] = n_crate;
+    st[2] = n_target;
+    st[3] = regions;
+    st[4] = dist_win;
+    st[5] = sol_len;
+    st[6] = n_crate > n_target ? n_crate - n_target : n_target - n_crate;
+  }
+}
+
+// control_wrappers.py:318-345
+template <int NS>
+__device__ inline double get_loss(const pcgrl_config &c, const int32_t *st) {
+  double loss = 0.0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    double v = (double)st[k];
+    double d = v < c.trg_lo[k] ? c.trg_lo[k] - v : (v > c.trg_hi[k] ? v - c.trg_hi[k] : 0.0);
+    loss += c.has_trg[k] ? (-d) * c.weights[k] : 0.0;
+  }
+  return loss;
+}
+
+// ------------------------------------------------------------------------------------------------ tile <-> planes
+template <int NB>
+__device__ inline int tile_at(const uint32_t *b, int x) {
+  int t = 0;
+#pragma unroll
+  for (int k = 0; k < NB; k++) t |= (int)((b[k] >> x) & 1u) << k;
+  return t;
+}
+template <int NB>
+__device__ inline void set_tile(uint32_t *b, int x, int t) {
+#pragma unroll
+  for (int k = 0; k < NB; k++) b[k] = (b[k] & ~(1u << x)) | ((uint32_t)((t >> k) & 1) << x);
+}
+
+// ------------------------------------------------------------------------------------------------ reset (RNG)
+// envs/pcgrl_env.py:158-188 + reps/representation.py:65-76 + helper.py:491-494, :527-536.
+// Every lane of the group replays the env's problem-RNG draws; the map draws of the representation RNG are
+// split by row with an LCG skip-ahead so the 16 lanes generate their rows concurrently.
+template <int PROB, int LPE>
+__device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, uint32_t *b, int *pos) {
+  constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  if (!active) return;
+  Pcg rp, rr;
+  rp.load(p.rng[env].prob);
+  rr.load(p.rng[env].rep);
+  double cdf[NT], total = 0.0;
+#pragma unroll
+  for (int t = 0; t < NT; t++) cdf[t] = rp.next_double();
+#pragma unroll
+  for (int t = 0; t < NT; t++) total += cdf[t];
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    acc += cdf[t] / total;
+    cdf[t] = acc;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) cdf[t] /= acc;
+  if (PROB == PCGRL_PROB_BINARY) (void)rp.next();  // binary_prob.py:139-143 draws one more double
+  pos[0] = pos[1] = 0;
+  if (p.cfg.representation == PCGRL_REP_TURTLE) {  // turtle_rep.py:31-44, before the map
+    pos[0] = (int)(rr.next_double() * (double)H);
+    pos[1] = (int)(rr.next_double() * (double)W);
+  }
+  Pcg end = rr;
+  end.jump(p.jump[H]);
+  if (g.row < H) {
+    rr.jump(p.jump[g.row]);
+#pragma unroll
+    for (int k = 0; k < NB; k++) b[k] = 0;
+    for (int x = 0; x < W; x++) {
+      double u = rr.next_double();
+      int idx = 0;
+#pragma unroll
+      for (int t = 0; t < NT; t++) idx += cdf[t] <= u ? 1 : 0;  // searchsorted(cdf, u, side='right')
+#pragma unroll
+      for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((idx >> k) & 1) << x;
+    }
+  }
+  if (g.row == 0) {
+    end.store(p.rng[env].rep);
+    rp.store(p.rng[env].prob);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ observation
+// One lane assembles one observation row (OW*C bytes) in LDS, interleaved per 16-byte chunk across the
+// wave ((chunk*64 + lane)*16) so that both the 16-byte fills/read-backs and the byte scatters spread over banks.
+__device__ inline uint32_t lds_addr(int lane, int off) { return (uint32_t)((((off >> 4) << 6) + lane) << 4) + (uint32_t)(off & 15); }
+
+// 16-byte chunk q of the all-out-of-bounds row pattern (byte k is 1 iff k % C == 0)
+template <int C>
+__device__ inline uint4 oob_chunk(int q) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int k = q * 16 + i * 4 + j;
+      v |= (uint32_t)((k % C) == 0) << (8 * j);
+    }
+    w[i] = v;
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+
+template <int C>
+__device__ inline uint4 oob_chunk_rt(int q) {
+  switch (q % C) {
+    case 0: return oob_chunk<C>(0);
+    case 1: return oob_chunk<C>(1);
+    case 2: return oob_chunk<C>(2);
+    case 3: return oob_chunk<C>(3);
+    case 4: return oob_chunk<C>(4);
+    case 5: return oob_chunk<C>(5);
+    case 6: return oob_chunk<C>(6);
+    case 7: return oob_chunk<C>(7);
+    default: return oob_chunk<C>(8);
+  }
+}
+
+template <int PROB, int LPE>
+__device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, bool active, const uint32_t *b, const int *pos,
+                                  uint8_t *lds) {
+  constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  if (p.obs == nullptr) return;
+  if (p.cfg.representation == PCGRL_REP_WIDE) {
+    // wrappers.py:502-526: plain one-hot of the map, (H, W, NT), no out-of-bounds channel
+    const int row_bytes = W * NT, chunks = row_bytes >> 4;
+    for (int q = 0; q < chunks; q++) *(uint4 *)(lds + lds_addr(g.lane, q * 16)) = make_uint4(0, 0, 0, 0);
+    if (active && g.row < H)
+      for (int x = 0; x < W; x++) lds[lds_addr(g.lane, x * NT + tile_at<NB>(b, x))] = 1;
+    if (active && g.row < H) {
+      uint8_t *dst = p.obs + ((size_t)env * H + g.row) * row_bytes;
+      for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = *(uint4 *)(lds + lds_addr(g.lane, q * 16));
+    }
+    return;
+  }
+  // wrappers.py:407-437 Cropped (map+1, zero pad, window of obs_window around pos) -> :232-257 one-hot with
+  // C = NT+1 channels, channel 0 = out of bounds -> :140-150 channel-last image.
+  constexpr int C = NT + 1;
+  const int OH = p.cfg.obs_window[0], OW = p.cfg.obs_window[1];
+  const int chunks = p.obs_chunks;  // OW*C/16
+  const int row_bytes = OW * C;
+  uint8_t *base = p.obs + (size_t)env * OH * row_bytes;
+  // obs row i shows map row i + pos_r - OH/2 ; visible map rows [r0, r1)
+  const int top = pos[0] - OH / 2;  // map row shown by obs row 0
+  const int r0 = max(0, top), r1 = min(H, top + OH);
+  const int nvis = max(0, r1 - r0), a = r0 - top;  // obs rows [a, a+nvis) are map rows
+  if (active) {
+    // (1) rows that are entirely out of bounds: constant pattern, spread over the group's lanes
+    const int n_oob = OH - nvis;
+    for (int k = g.row; k < n_oob; k += LPE) {
+      int i = k < a ? k : k + nvis;
+      uint8_t *dst = base + (size_t)i * row_bytes;
+      for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = oob_chunk_rt<C>(q);
+    }
+  }
+  // (2) this lane's own map row
+  const bool vis = active && g.row >= r0 && g.row < r1;
+  for (int q = 0; q < chunks; q++) *(uint4 *)(lds + lds_addr(g.lane, q * 16)) = oob_chunk_rt<C>(q);
+  if (vis) {
+    const int left = pos[1] - OW / 2;  // map column shown by obs column 0
+    for (int x = 0; x < W; x++) {
+      int j = x - left;
+      if (j >= 0 && j < OW) {
+        int o = j * C;
+        lds[lds_addr(g.lane, o)] = 0;
+        lds[lds_addr(g.lane, o + 1 + tile_at<NB>(b, x))] = 1;
+      }
+    }
+    uint8_t *dst = base + (size_t)(g.row - top) * row_bytes;
+    for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = *(uint4 *)(lds + lds_addr(g.lane, q * 16));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+template <int NB>
+__device__ inline void load_planes(const Params &p, int env, int row, bool ok, uint32_t *b) {
+  const uint32_t *pl = (const uint32_t *)p.planes;
+  const int H = p.cfg.dims[0];
+#pragma unroll
+  for (int k = 0; k < NB; k++) b[k] = ok ? pl[((size_t)env * NB + k) * H + row] : 0u;
+}
+template <int NB>
+__device__ inline void store_planes(const Params &p, int env, int row, bool ok, const uint32_t *b) {
+  uint32_t *pl = (uint32_t *)p.planes;
+  const int H = p.cfg.dims[0];
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) pl[((size_t)env * NB + k) * H + row] = b[k];
+  }
+}
+
+// reps/*.update(): returns change flag (uniform over the group); edits the owning lane's planes, updates pos/n_step
+template <int PROB, int LPE>
+__device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool active, int action, uint32_t *b, int *pos,
+                                  int &n_step, bool &bad_action) {
+  constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  int r = pos[0], c = pos[1], tile = -1;
+  switch (p.cfg.representation) {
+    case PCGRL_REP_NARROW:  // narrow_rep.py:89-102
+      bad_action = action < 0 || action >= NT;
+      tile = action;
+      break;
+    case PCGRL_REP_TURTLE:  // turtle_rep.py:87-107
+      bad_action = action < 0 || action >= NT + 4;
+      if (action >= 4) tile = action - 4;
+      break;
+    default: {  // wrappers.py:304-323 ActionMap + wide_rep.py:40-45: row = x = (a / NT) % W, col = y = a / (W*NT)
+      bad_action = action < 0 || action >= H * W * NT;
+      tile = action % NT;
+      r = (action / NT) % W;
+      c = action / (W * NT);
+      break;
+    }
+  }
+  if (bad_action || !active) tile = -1;
+  bool mine = tile >= 0 && g.row == r;
+  bool ch = false;
+  if (mine) {
+    ch = tile_at<NB>(b, c) != tile;
+    set_tile<NB>(b, c, tile);
+  }
+  bool change = g.gany(ch);
+  if (active && !bad_action) {
+    if (p.cfg.representation == PCGRL_REP_NARROW) {  // Q1: position advances with the pre-increment index
+      int idx = n_step % (H * W);
+      pos[0] = idx / W;
+      pos[1] = idx % W;
+      n_step++;
+    } else if (p.cfg.representation == PCGRL_REP_TURTLE) {
+      if (action < 4) {  // _dirs = [(-1,0),(1,0),(0,-1),(0,1)] on (row, col), clamped
+        int dr = action == 0 ? -1 : (action == 1 ? 1 : 0), dc = action == 2 ? -1 : (action == 3 ? 1 : 0);
+        pos[0] = min(max(pos[0] + dr, 0), H - 1);
+        pos[1] = min(max(pos[1] + dc, 0), W - 1);
+      }
+    } else {
+      pos[0] = r;
+      pos[1] = c;
+    }
+  }
+  return change;
+}
+
+template <int PROB, int LPE>
+__global__ __launch_bounds__(64) void step_kernel(Params p) {
+  constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  Grp<LPE> g;
+  g.init();
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  const bool active = env < p.n_envs;
+  const bool rowok = active && g.row < H;
+  const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
+  const int e = active ? env : 0;
+
+  uint32_t b[NB];
+  load_planes<NB>(p, e, g.row, rowok, b);
+  EnvState *S = &p.st[e];
+  int pos[2] = {S->pos[0], S->pos[1]};
+  int n_step = S->n_step, iteration = S->iteration, changes = S->changes, ep_len = S->ep_len;
+  double last_loss = S->last_loss, ep_return = S->ep_return;
+  int32_t st[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+  const int action = active ? p.actions[e] : 0;
+
+  // envs/pcgrl_env.py:267-342
+  bool bad = false;
+  iteration++;
+  bool change = rep_update<PROB, LPE>(g, p, active, action, b, pos, n_step, bad);
+  if (bad && g.row == 0 && active) atomicOr(p.err, 1);
+  changes += change ? 1 : 0;
+  if (__ballot(change) != 0) {
+    int32_t ns[NS];
+    compute_stats<PROB, LPE>(g, p, e, change, b, colmask, ns);
+    if (change) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) st[k] = ns[k];
+    }
+  }
+  bool done = iteration > p.cfg.max_iterations;
+  if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
+  // control_wrappers.py:216-244
+  double loss = get_loss<NS>(p.cfg, st);
+  double rew = loss - last_loss;
+  last_loss = loss;
+  ep_return += rew;
+  ep_len++;
+  if (active && g.row == 0) {
+    if (p.reward) p.reward[e] = (float)rew;
+    if (p.done) p.done[e] = done ? 1 : 0;
+    if (p.stats_out) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) p.stats_out[(size_t)e * NS + k] = st[k];
+    }
+  }
+  const bool do_reset = active && done && p.auto_reset != 0;
+  if (__ballot(do_reset) != 0) {
+    if (do_reset && g.row == 0) {
+      S->last_ep_return = ep_return;
+      S->last_ep_len = ep_len;
+      S->n_episodes += 1;
+#pragma unroll
+      for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
+    }
+    reset_from_rng<PROB, LPE>(g, p, e, do_reset, b, pos);
+    int32_t ns[NS];
+    compute_stats<PROB, LPE>(g, p, e, do_reset, b, colmask, ns);
+    if (do_reset) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) st[k] = ns[k];
+      iteration = 0;
+      changes = 0;
+      n_step = 0;
+      ep_len = 0;
+      ep_return = 0.0;
+      last_loss = get_loss<NS>(p.cfg, st);
+    }
+  }
+  // write back state
+  if (change || do_reset) store_planes<NB>(p, e, g.row, rowok, b);
+  if (active && g.row == 0) {
+    S->pos[0] = pos[0];
+    S->pos[1] = pos[1];
+    S->n_step = n_step;
+    S->iteration = iteration;
+    S->changes = changes;
+    S->ep_len = ep_len;
+    S->last_loss = last_loss;
+    S->ep_return = ep_return;
+#pragma unroll
+    for (int k = 0; k < NS; k++) S->stats[k] = st[k];
+  }
+  encode_obs<PROB, LPE>(g, p, e, active, b, pos, lds);
+}
+
+template <int PROB, int LPE>
+__global__ __launch_bounds__(64) void reset_kernel(Params p) {
+  constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  Grp<LPE> g;
+  g.init();
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  const bool inb = env < p.n_envs;
+  const int e = inb ? env : 0;
+  const bool active = inb && (p.mask == nullptr || p.mask[e] != 0);
+  const bool rowok = active && g.row < H;
+  const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
+  EnvState *S = &p.st[e];
+  uint32_t b[NB];
+  int pos[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < NB; k++) b[k] = 0;
+  if (p.init_grids) {  // inject: bytes -> planes (envs/pcgrl_ctrl_env.py:12-14 set_map)
+    if (rowok) {
+      const uint8_t *src = p.init_grids + ((size_t)e * H + g.row) * W;
+      for (int x = 0; x < W; x++) {
+        int t = src[x];
+#pragma unroll
+        for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((t >> k) & 1) << x;
+      }
+    }
+    if (p.init_pos && p.cfg.representation != PCGRL_REP_WIDE) {
+      pos[0] = p.init_pos[(size_t)e * 3 + 0];
+      pos[1] = p.init_pos[(size_t)e * 3 + 1];
+    }
+  } else {
+    reset_from_rng<PROB, LPE>(g, p, e, active, b, pos);
+  }
+  int32_t st[NS];
+  compute_stats<PROB, LPE>(g, p, e, active, b, colmask, st);
+  store_planes<NB>(p, e, g.row, rowok, b);
+  if (active && g.row == 0) {
+    S->pos[0] = pos[0];
+    S->pos[1] = pos[1];
+    S->pos[2] = 0;
+    S->n_step = 0;
+    S->iteration = 0;
+    S->changes = 0;
+    S->ep_len = 0;
+    S->ep_return = 0.0;
+    S->last_loss = get_loss<NS>(p.cfg, st);
+#pragma unroll
+    for (int k = 0; k < NS; k++) S->stats[k] = st[k];
+  }
+  (void)lds;
+}
+
+template <int PROB, int LPE>
+__global__ __launch_bounds__(64) void observe_kernel(Params p) {
+  constexpr int NB = ProbTraits<PROB>::NB, EPW = 64 / LPE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  Grp<LPE> g;
+  g.init();
+  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  const bool active = env < p.n_envs;
+  const int e = active ? env : 0;
+  const bool rowok = active && g.row < p.cfg.dims[0];
+  uint32_t b[NB];
+  load_planes<NB>(p, e, g.row, rowok, b);
+  int pos[2] = {p.st[e].pos[0], p.st[e].pos[1]};
+  encode_obs<PROB, LPE>(g, p, e, active, b, pos, lds);
+}
+
+template <int PROB, int LPE>
+__global__ __launch_bounds__(64) void get_state_kernel(Params p) {
+  constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
+  Grp<LPE> g;
+  g.init();
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  if (env >= p.n_envs) return;
+  const EnvState *S = &p.st[env];
+  if (p.out_grids && g.row < H) {
+    uint32_t b[NB];
+    load_planes<NB>(p, env, g.row, true, b);
+    uint8_t *dst = p.out_grids + ((size_t)env * H + g.row) * W;
+    for (int x = 0; x < W; x++) dst[x] = (uint8_t)tile_at<NB>(b, x);
+  }
+  if (g.row == 0) {
+    if (p.out_pos) {
+      p.out_pos[(size_t)env * 3 + 0] = S->pos[0];
+      p.out_pos[(size_t)env * 3 + 1] = S->pos[1];
+      p.out_pos[(size_t)env * 3 + 2] = 0;
+    }
+    if (p.out_counters) {
+      p.out_counters[(size_t)env * 4 + 0] = S->iteration;
+      p.out_counters[(size_t)env * 4 + 1] = S->changes;
+      p.out_counters[(size_t)env * 4 + 2] = S->n_step;
+      p.out_counters[(size_t)env * 4 + 3] = S->ep_len;
+    }
+    if (p.stats_out)
+      for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = S->stats[k];
+    if (p.out_last_loss) p.out_last_loss[env] = S->last_loss;
+    if (p.out_ep_return) p.out_ep_return[env] = S->ep_return;
+  }
+}
+
+template <int PROB, int LPE>
+__global__ __launch_bounds__(64) void last_episode_kernel(Params p) {
+  constexpr int NS = ProbTraits<PROB>::NS;
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= p.n_envs) return;
+  const EnvState *S = &p.st[env];
+  if (p.out_ep_return) p.out_ep_return[env] = S->last_ep_return;
+  if (p.out_ep_len) p.out_ep_len[env] = S->last_ep_len;
+  if (p.out_n_episodes) p.out_n_episodes[env] = S->n_episodes;
+  if (p.stats_out)
+    for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = S->final_stats[k];
+}
+
+// Problem.get_stats on caller-provided byte grids (no engine state)
+template <int PROB, int LPE>
+__global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
+  constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
+  Grp<LPE> g;
+  g.init();
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  const bool active = env < p.n_envs;
+  const int e = active ? env : 0;
+  const bool rowok = active && g.row < H;
+  const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
+  uint32_t b[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) b[k] = 0;
+  if (rowok) {
+    const uint8_t *src = p.init_grids + ((size_t)e * H + g.row) * W;
+    for (int x = 0; x < W; x++) {
+      int t = src[x];
+#pragma unroll
+      for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((t >> k) & 1) << x;
+    }
+  }
+  int32_t st[NS];
+  compute_stats<PROB, LPE>(g, p, e, active, b, colmask, st);
+  if (active && g.row == 0)
+    for (int k = 0; k < NS; k++) p.stats_out[(size_t)e * NS + k] = st[k];
+}
+
+}  // namespace pcgrl

@@ -1,0 +1,113 @@
+"""Single-environment adapter with the reference's gym call shape.
+
+`make_env(cfg)` mirrors control_pcgrl/rl/envs.py:28-81: it returns an object whose
+reset() -> (obs, info) and step(a) -> (obs, reward, done, truncated, info) tuples, observation_space /
+action_space and the attributes RLlib callbacks read (`unwrapped._rep_stats`, `metrics`, `ctrl_metrics`,
+`metric_trgs`, `cond_bounds`, `static_trgs`; control_wrappers.py:56-76, envs/pcgrl_ctrl_env.py:8-10) match the
+reference's wrapped env, while the transition itself runs on the GPU engine (a VecPcgrlEnv of size 1, or a slot
+of a shared batch).  Intended for plumbing / drop-in checks; throughput comes from make_vec_env().
+"""
+import numpy as np
+import torch
+
+from .vec_env import VecPcgrlEnv, _cfg_get, make_vec_env
+
+try:  # use the real spaces when gymnasium is installed, else shape/bounds holders with the same attributes
+    from gymnasium import spaces as _spaces
+
+    Box, Discrete = _spaces.Box, _spaces.Discrete
+except Exception:  # pragma: no cover - gymnasium is not in the build image
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+        def __repr__(self):
+            return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+    class Discrete:
+        def __init__(self, n):
+            self.n, self.shape, self.dtype = int(n), (), np.dtype(np.int64)
+
+        def sample(self):
+            return int(np.random.randint(self.n))
+
+        def __repr__(self):
+            return f"Discrete({self.n})"
+
+
+class PcgrlGymEnv:
+    """One env with the reference's API on top of the batched engine."""
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, cfg=None, vec: VecPcgrlEnv = None, device="cuda:0", seed=None):
+        self._vec = vec if vec is not None else make_vec_env(cfg, 1, device=device, auto_reset=False,
+                                                              seeds=None if seed is None else [seed])
+        assert self._vec.num_envs == 1 and not self._vec.auto_reset
+        v = self._vec
+        # wrappers.py:121-123 ToImage: Box(low=0, high=max tile value, shape=(H, W, C)) float32
+        self.observation_space = Box(low=0, high=1, shape=v.obs_shape, dtype=np.float32)
+        self.action_space = Discrete(v.num_actions)  # narrow_rep.py:65-68, turtle_rep.py:70-71, wrappers.py:297
+        self.static_trgs = dict(v.spec.static_trgs)
+        self.metric_trgs = self.static_trgs
+        self.cond_bounds = dict(v.spec.cond_bounds)
+        self.ctrl_metrics = []
+        self.metric_weights = {k: float(v.cfg.weights[i]) for i, k in enumerate(v.stat_keys)}
+        self.metrics = {k: None for k in self.static_trgs}
+        self._rep_stats = None
+        self.render_mode = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self._vec.seed([int(seed)])
+        return [seed]
+
+    def _stats_dict(self, stats_row):
+        vals = stats_row.tolist()
+        return {k: int(x) for k, x in zip(self._vec.stat_keys, vals)}
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            self.seed(seed)
+        obs, _ = self._vec.reset()
+        st = self._vec.get_state()
+        self._rep_stats = self._stats_dict(st.stats[0].cpu())
+        self.metrics = self._rep_stats
+        return obs[0].float().cpu().numpy(), {}
+
+    def step(self, action):
+        a = int(action)
+        if not 0 <= a < self.action_space.n:
+            # the reference raises IndexError from numpy indexing on an out-of-range action
+            raise IndexError(f"action {a} outside Discrete({self.action_space.n})")
+        act = torch.tensor([a], dtype=torch.int32, device=self._vec.device)
+        obs, rew, done, trunc, info = self._vec.step(act)
+        stats = info["stats"][0].cpu()
+        self._rep_stats = self._stats_dict(stats)
+        self.metrics = self._rep_stats
+        st = self._vec.get_state()
+        d = bool(done[0].item())
+        out_info = dict(self._rep_stats)
+        out_info.update(iterations=int(st.iteration[0]), changes=int(st.changes[0]),
+                        max_iterations=int(self._vec.cfg.max_iterations),
+                        max_changes=None if self._vec.cfg.max_changes < 0 else int(self._vec.cfg.max_changes))
+        return obs[0].float().cpu().numpy(), float(rew[0].item()), d, d, out_info
+
+    def get_map(self):
+        return self._vec.get_state().grids[0].cpu().numpy()
+
+    def close(self):
+        self._vec.close()
+
+
+def make_env(cfg, device="cuda:0"):
+    """Drop-in for control_pcgrl/rl/envs.py:make_env(cfg) on this path."""
+    rep = _cfg_get(cfg, "representation")
+    if rep not in ("narrow", "turtle", "wide"):
+        raise Exception("Unknown representation: {}".format(rep))  # rl/envs.py:65
+    return PcgrlGymEnv(cfg, device=device)

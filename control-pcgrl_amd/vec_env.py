@@ -1,0 +1,238 @@
+"""Batched PCGRL environment on one MI355X: N envs advanced by one HIP launch per step.
+
+Mirrors, for a batch, the reference's  make_env(cfg) -> ControlWrapper(CroppedImage|ActionMapImage
+PCGRLWrapper(PcgrlCtrlEnv))  stack (control_pcgrl/rl/envs.py:28-81): same observation layout
+(channel-last one-hot, uint8), same reward, same done rule, same per-problem stats.  All tensors live on the
+env's GPU; step() performs no host synchronisation.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+from .problems import PROBLEMS, REPRESENTATIONS, problem_spec, target_interval
+
+
+def _cfg_get(cfg, path, default=None):
+    cur = cfg
+    for part in path.split("."):
+        if cur is None:
+            return default
+        cur = cur.get(part, default) if isinstance(cur, dict) else getattr(cur, part, default)
+    return cur
+
+
+def build_config(problem, representation, map_shape, obs_window=None, weights=None, max_board_scans=3,
+                 change_percentage=None, solver_power=10000, static_trgs=None):
+    """cfg fields -> pcgrl_config (include/pcgrl_amd.h)."""
+    if representation not in REPRESENTATIONS:
+        raise ValueError(f"Unknown representation: {representation}")  # rl/envs.py:65
+    spec = problem_spec(problem, map_shape)
+    map_shape = tuple(int(s) for s in map_shape)
+    ndim = len(map_shape)
+    if obs_window is None:
+        # rl/utils.py:302-334 validate_config: default obs_window = 2 * map_shape; wide must see the whole map
+        obs_window = map_shape if representation == "wide" else tuple(2 * s for s in map_shape)
+    obs_window = tuple(int(s) for s in obs_window)
+    weights = dict(spec.default_weights if weights is None else weights)
+    trgs = dict(spec.static_trgs)
+    if static_trgs:
+        trgs.update(static_trgs)
+    c = _lib.PcgrlConfig()
+    c.problem = PROBLEMS[problem]
+    c.representation = REPRESENTATIONS[representation]
+    c.ndim = ndim
+    for d in range(3):
+        c.dims[d] = map_shape[d] if d < ndim else 1
+        c.obs_window[d] = obs_window[d] if d < ndim else 1
+    n_cells = int(np.prod(map_shape))
+    c.max_iterations = n_cells * int(max_board_scans) + 1  # envs/pcgrl_env.py:241
+    if change_percentage is None:
+        c.max_changes = -1
+    else:
+        assert 0 < change_percentage
+        c.max_changes = max(int(change_percentage * n_cells), 1)  # envs/pcgrl_env.py:235-239
+    c.n_stats = len(spec.stat_keys)
+    for i, k in enumerate(spec.stat_keys):
+        c.weights[i] = float(weights.get(k, 0.0))  # control_wrappers.py:41-45
+        if k in trgs:  # control_wrappers.py:48-82: all_metrics = static targets when not controllable
+            c.has_trg[i] = 1
+            c.trg_lo[i], c.trg_hi[i] = target_interval(trgs[k])
+    c.solver_power = int(solver_power)
+    return c, spec, obs_window
+
+
+class VecPcgrlEnv:
+    """N independent PCGRL envs on one GPU.
+
+    step(actions) -> (obs uint8 [N, *obs_shape], reward f32 [N], done bool [N], truncated bool [N], info)
+      info["stats"]  int32 [N, n_stats] in `self.stat_keys` order
+    Output tensors are owned by the env and overwritten by the next step()/reset() (clone to keep).
+    auto_reset=True (default): finished envs restart inside the same launch (RLlib's convention: the returned
+    observation is the first of the new episode); last_episode() exposes what RLlib's callbacks read at
+    episode end (rl/callbacks.py:91-117).
+    """
+
+    def __init__(self, problem, representation, map_shape, num_envs, device="cuda:0", obs_window=None, weights=None,
+                 max_board_scans=3, change_percentage=None, seeds=None, auto_reset=True, solver_power=10000,
+                 static_trgs=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("VecPcgrlEnv needs a GPU (ROCm device); there is no CPU fallback in the product path")
+        self.device = torch.device(device)
+        self.problem, self.representation = problem, representation
+        self.map_shape = tuple(int(s) for s in map_shape)
+        self.num_envs = int(num_envs)
+        self.auto_reset = bool(auto_reset)
+        self.cfg, self.spec, self.obs_window = build_config(
+            problem, representation, map_shape, obs_window, weights, max_board_scans, change_percentage, solver_power,
+            static_trgs)
+        self.stat_keys = list(self.spec.stat_keys)
+        self.n_stats = len(self.stat_keys)
+        self.n_cells = int(np.prod(self.map_shape))
+        L = _lib.lib()
+        h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(L.pcgrl_create(C.byref(self.cfg), self.num_envs, dev_index, C.byref(h)), "pcgrl_create")
+        self._h = h
+        self._L = L
+        shape = (C.c_int32 * 4)()
+        nd = C.c_int32()
+        _lib.check(L.pcgrl_obs_shape(h, C.byref(shape), C.byref(nd)), "pcgrl_obs_shape")
+        self.obs_shape = tuple(shape[i] for i in range(nd.value))
+        n_act = {"narrow": self.spec.n_tiles, "turtle": self.spec.n_tiles + 4,
+                 "wide": self.n_cells * self.spec.n_tiles}[representation]
+        self.num_actions = n_act
+        N, dev = self.num_envs, self.device
+        self._obs = torch.empty((N,) + self.obs_shape, dtype=torch.uint8, device=dev)
+        self._reward = torch.empty(N, dtype=torch.float32, device=dev)
+        self._done = torch.empty(N, dtype=torch.uint8, device=dev)
+        self._stats = torch.empty((N, self.n_stats), dtype=torch.int32, device=dev)
+        self._ptrs = (self._obs.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._stats.data_ptr())
+        if seeds is not None:
+            self.seed(seeds)
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pcgrl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def seed(self, seeds):
+        """Env i gets numpy PCG64(SeedSequence(seeds[i])) for both RNG streams (envs/pcgrl_env.py:142-146)."""
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.num_envs,)))
+        _lib.check(self._L.pcgrl_seed(self._h, s.ctypes.data), "pcgrl_seed")
+
+    # -- gym-like API ------------------------------------------------------------------------------
+    def reset(self, mask=None, init_grids=None, init_pos=None):
+        def dev(t, dtype):
+            if t is None:
+                return None
+            return torch.as_tensor(t, device=self.device).to(dtype).contiguous()
+
+        m = dev(mask, torch.uint8)
+        g = dev(init_grids, torch.uint8)
+        p = None
+        if init_pos is not None:
+            ip = torch.as_tensor(init_pos, device=self.device).to(torch.int32).reshape(self.num_envs, -1)
+            p = torch.zeros((self.num_envs, 3), dtype=torch.int32, device=self.device)
+            p[:, : ip.shape[1]] = ip
+        if g is not None:
+            assert g.numel() == self.num_envs * self.n_cells
+        _lib.check(self._L.pcgrl_reset(self._h, m.data_ptr() if m is not None else None,
+                                       g.data_ptr() if g is not None else None,
+                                       p.data_ptr() if p is not None else None, self._stream()), "pcgrl_reset")
+        _lib.check(self._L.pcgrl_observe(self._h, self._ptrs[0], self._stream()), "pcgrl_observe")
+        return self._obs, {}
+
+    def step(self, actions):
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        rc = self._L.pcgrl_step(self._h, actions.data_ptr(), 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
+                                self._ptrs[2], self._ptrs[3], self._stream())
+        if rc:
+            _lib.check(rc, "pcgrl_step")
+        done = self._done.view(torch.bool)
+        return self._obs, self._reward, done, done, {"stats": self._stats}
+
+    def step_raw(self, actions_ptr, stream):
+        """Lowest-overhead launch: device pointer of int32 actions + raw hipStream_t."""
+        return self._L.pcgrl_step(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
+                                  self._ptrs[2], self._ptrs[3], stream)
+
+    def observe(self):
+        _lib.check(self._L.pcgrl_observe(self._h, self._ptrs[0], self._stream()), "pcgrl_observe")
+        return self._obs
+
+    def check_errors(self):
+        """Synchronises; raises ValueError if a kernel saw an action outside the action space."""
+        _lib.check(self._L.pcgrl_poll_error(self._h), "pcgrl_poll_error")
+
+    # -- state access ------------------------------------------------------------------------------
+    def get_state(self):
+        N, dev = self.num_envs, self.device
+        out = SimpleNamespace(
+            grids=torch.empty((N,) + self.map_shape, dtype=torch.uint8, device=dev),
+            pos=torch.empty((N, 3), dtype=torch.int32, device=dev),
+            counters=torch.empty((N, 4), dtype=torch.int32, device=dev),
+            stats=torch.empty((N, self.n_stats), dtype=torch.int32, device=dev),
+            last_loss=torch.empty(N, dtype=torch.float64, device=dev),
+            ep_return=torch.empty(N, dtype=torch.float64, device=dev))
+        _lib.check(self._L.pcgrl_get_state(self._h, out.grids.data_ptr(), out.pos.data_ptr(), out.counters.data_ptr(),
+                                           out.stats.data_ptr(), out.last_loss.data_ptr(), out.ep_return.data_ptr(),
+                                           self._stream()), "pcgrl_get_state")
+        out.iteration, out.changes, out.n_step, out.ep_len = (out.counters[:, i] for i in range(4))
+        return out
+
+    def last_episode(self):
+        N, dev = self.num_envs, self.device
+        out = SimpleNamespace(ep_return=torch.empty(N, dtype=torch.float64, device=dev),
+                              ep_len=torch.empty(N, dtype=torch.int32, device=dev),
+                              final_stats=torch.empty((N, self.n_stats), dtype=torch.int32, device=dev),
+                              n_episodes=torch.empty(N, dtype=torch.int64, device=dev))
+        _lib.check(self._L.pcgrl_get_last_episode(self._h, out.ep_return.data_ptr(), out.ep_len.data_ptr(),
+                                                  out.final_stats.data_ptr(), out.n_episodes.data_ptr(),
+                                                  self._stream()), "pcgrl_get_last_episode")
+        return out
+
+    def stats_for_grids(self, grids):
+        """Problem.get_stats on caller maps (the evolution driver's entry, evo/evolve.py:1083-1120)."""
+        g = torch.as_tensor(grids, device=self.device).to(torch.uint8).contiguous()
+        n = g.numel() // self.n_cells
+        out = torch.empty((n, self.n_stats), dtype=torch.int32, device=self.device)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._L.pcgrl_stats_for_grids(C.byref(self.cfg), n, g.data_ptr(), out.data_ptr(), dev_index,
+                                                 self._stream()), "pcgrl_stats_for_grids")
+        return out
+
+
+def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
+    """Batched counterpart of control_pcgrl/rl/envs.py:make_env(cfg).  `cfg` is the reference's Config-like
+    object (attributes or dict keys): task.problem, task.map_shape, task.obs_window, task.weights,
+    representation, max_board_scans, change_percentage."""
+    unsupported = {
+        "controls": _cfg_get(cfg, "controls"), "act_window": _cfg_get(cfg, "act_window"),
+        "static_prob": _cfg_get(cfg, "static_prob"), "n_static_walls": _cfg_get(cfg, "n_static_walls"),
+        "n_aux_tiles": _cfg_get(cfg, "n_aux_tiles", 0) or None,
+        "show_agents": _cfg_get(cfg, "show_agents", False) or None,
+        "multiagent.n_agents": _cfg_get(cfg, "multiagent.n_agents", 0) or None,
+    }
+    bad = {k: v for k, v in unsupported.items() if v not in (None, 0, False)}
+    if bad:
+        raise NotImplementedError(f"outside the accelerated hot path (SURVEY.md section 8f 'next'): {bad}")
+    return VecPcgrlEnv(
+        problem=_cfg_get(cfg, "task.problem"), representation=_cfg_get(cfg, "representation"),
+        map_shape=tuple(_cfg_get(cfg, "task.map_shape")), num_envs=num_envs, device=device,
+        obs_window=_cfg_get(cfg, "task.obs_window"), weights=_cfg_get(cfg, "task.weights"),
+        max_board_scans=_cfg_get(cfg, "max_board_scans", 3), change_percentage=_cfg_get(cfg, "change_percentage"),
+        seeds=seeds, auto_reset=auto_reset)

@@ -1,0 +1,118 @@
+/*
+ * pcgrl_amd.h -- C ABI of the MI355X-native batched PCGRL environment engine (libpcgrl_amd.so).
+ *
+ * The reference (smearle/control-pcgrl) is pure Python and has no FFI; the boundary it exposes for this
+ * path is the gym.Env interface of one environment object.  Each entry point below names the reference
+ * interface it replaces for a *batch* of N environments resident on one GPU
+ * (paths relative to the reference's control_pcgrl/ directory):
+ *
+ *   pcgrl_create / pcgrl_destroy   rl/envs.py:28-81 make_env(cfg)  ->  envs/pcgrl_env.py:39-94 PcgrlEnv.__init__
+ *                                  + wrappers.py:443-476 / :502-526 wrapper stacks + control_wrappers.py:27-121
+ *   pcgrl_seed                     envs/pcgrl_env.py:142-146 PcgrlEnv.seed (rep + problem RNG, PCG64(SeedSequence))
+ *   pcgrl_reset                    control_wrappers.py:174-187 ControlWrapper.reset -> envs/pcgrl_env.py:158-188;
+ *                                  init_grids != NULL additionally covers envs/pcgrl_ctrl_env.py:12-14 set_map
+ *   pcgrl_step                     control_wrappers.py:216-244 ControlWrapper.step -> wrappers.py:126-132, :219-224,
+ *                                  :394-399, :304-323 -> envs/pcgrl_env.py:267-342 PcgrlEnv.step
+ *   pcgrl_observe                  wrappers.py:407-437 Cropped._transform, :232-257 OneHotEncoding._transform,
+ *                                  :140-150 ToImage._transform
+ *   pcgrl_get_state                env.unwrapped._rep._map / _rep._pos / _iteration / _changes / _rep_stats
+ *                                  (read by rl/callbacks.py:91-117)
+ *   pcgrl_get_last_episode         rl/callbacks.py:91-117 StatsCallbacks.on_episode_end (final stats, return)
+ *   pcgrl_stats_for_grids          envs/probs/problem.py:128 Problem.get_stats(map) as called directly by
+ *                                  evo/evolve.py:1083-1120
+ *
+ * Conventions
+ *   - every `d_` pointer is a DEVICE pointer on the engine's GPU; the caller owns all I/O buffers,
+ *     the engine owns persistent env state.  `seeds` in pcgrl_seed is a HOST pointer.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All calls except create /
+ *     destroy / seed / poll_error are asynchronous on that stream.
+ *   - return value 0 = success, otherwise a PCGRL_E* code; pcgrl_last_error() gives the message.
+ *   - one handle per (process, GPU); a handle is not re-entrant; several handles may coexist.
+ */
+#ifndef PCGRL_AMD_H
+#define PCGRL_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCGRL_MAX_STATS 8
+
+enum { PCGRL_PROB_BINARY = 0, PCGRL_PROB_ZELDA = 1, PCGRL_PROB_SOKOBAN = 2, PCGRL_PROB_MC3DMAZE = 3 };
+enum { PCGRL_REP_NARROW = 0, PCGRL_REP_TURTLE = 1, PCGRL_REP_WIDE = 2 };
+enum {
+  PCGRL_OK = 0,
+  PCGRL_EINVAL = 1,       /* bad argument / config */
+  PCGRL_EUNSUPPORTED = 2, /* problem x representation x shape not supported by the kernels */
+  PCGRL_EHIP = 3,         /* HIP runtime error */
+  PCGRL_EACTION = 4       /* an out-of-range action was seen on the device (pcgrl_poll_error) */
+};
+
+/* Stat order per problem (columns of every `stats` array):
+ *   binary   : regions, path-length
+ *   zelda    : player, key, door, enemies, regions, nearest-enemy, path-length
+ *   sokoban  : player, crate, target, regions, dist-win, sol-length, ratio
+ *   mc3dmaze : regions, path-length, n_jump                                                       */
+typedef struct {
+  int32_t problem;        /* PCGRL_PROB_* */
+  int32_t representation; /* PCGRL_REP_*  */
+  int32_t ndim;           /* 2 or 3 */
+  int32_t dims[3];        /* cfg.task.map_shape: 2-D {H, W, 1}; 3-D {Z, Y, X} */
+  int32_t obs_window[3];  /* cfg.task.obs_window (wide: must equal map_shape) */
+  int32_t max_iterations; /* prod(map_shape) * cfg.max_board_scans + 1     (envs/pcgrl_env.py:241) */
+  int32_t max_changes;    /* max(int(cfg.change_percentage * prod), 1) or -1 (envs/pcgrl_env.py:235-239) */
+  int32_t n_stats;
+  int32_t has_trg[PCGRL_MAX_STATS]; /* stat enters the loss (key of Problem.static_trgs) */
+  double weights[PCGRL_MAX_STATS];  /* ControlWrapper.metric_weights (control_wrappers.py:41-45) */
+  double trg_lo[PCGRL_MAX_STATS];   /* inclusive target interval; scalar target t: lo = hi = t;        */
+  double trg_hi[PCGRL_MAX_STATS];   /* tuple (a, b): [a, last of arange(a, b)] (control_wrappers.py:337) */
+  int32_t solver_power;             /* sokoban solver iterations per stage (sokoban_prob.py:40) */
+} pcgrl_config;
+
+typedef struct pcgrl_engine *pcgrl_handle;
+
+int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_handle *out);
+void pcgrl_destroy(pcgrl_handle h);
+
+/* seeds: HOST pointer to n_envs uint64.  Synchronous. */
+int pcgrl_seed(pcgrl_handle h, const uint64_t *seeds);
+
+/* d_mask NULL = every env.  d_init_grids (uint8 [N][cells]) / d_init_pos (int32 [N][3]) non-NULL: start
+ * from the given maps / agent positions instead of drawing them (no RNG consumption). */
+int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_grids, const int32_t *d_init_pos,
+                void *stream);
+
+/* One env step for all N envs.  Any output pointer may be NULL.
+ *   d_actions int32 [N]      d_obs uint8 [N][obs_bytes]   d_reward float [N]
+ *   d_done uint8 [N]         d_stats int32 [N][n_stats]
+ * auto_reset != 0: an env whose episode ended is reset inside the same launch; reward/done/stats are
+ * those of the finished step, the observation is the first one of the new episode (RLlib convention),
+ * and the finished episode's return / length / final stats are latched for pcgrl_get_last_episode. */
+int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
+               uint8_t *d_done, int32_t *d_stats, void *stream);
+
+int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream);
+int64_t pcgrl_obs_bytes(pcgrl_handle h); /* bytes per env: prod(obs_shape) */
+int pcgrl_obs_shape(pcgrl_handle h, int32_t shape_out[4], int32_t *ndim_out);
+
+/* d_counters int32 [N][4] = iteration, changes, n_step, episode_len.  Any pointer may be NULL. */
+int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d_counters, int32_t *d_stats,
+                    double *d_last_loss, double *d_ep_return, void *stream);
+int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_len, int32_t *d_final_stats,
+                           int64_t *d_n_episodes, void *stream);
+
+/* Stateless Problem.get_stats on n maps: d_grids uint8 [n][cells] -> d_stats int32 [n][n_stats]. */
+int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_grids, int32_t *d_stats,
+                          int32_t device, void *stream);
+
+/* Synchronises the device and returns PCGRL_EACTION if any kernel saw an out-of-range action since the
+ * last poll (the reference raises IndexError there), PCGRL_EHIP on a pending HIP error, else 0. */
+int pcgrl_poll_error(pcgrl_handle h);
+const char *pcgrl_last_error(void);
+const char *pcgrl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

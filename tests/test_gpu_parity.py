@@ -1,0 +1,223 @@
+"""GPU parity: the HIP engine (through the C ABI, via control_pcgrl_amd) against
+  (a) golden vectors captured from the reference (tests/golden/), and
+  (b) the CPU oracle on identical seeded inputs, at BASELINE sizes.
+Bars: bit-exact grids / positions / counters / stats / done / observations; |reward - reference| <= 1e-6
+(the engine returns float32; the values are integers, so the comparison is in fact exact).
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import pcgrl_oracle as po  # noqa: E402  (checker only)
+from conftest import GOLDEN  # noqa: E402
+
+EPISODES = [p for p in sorted(glob.glob(os.path.join(GOLDEN, "episode_*.npz"))) if "mc3d" not in p]
+REW_TOL = 1e-6
+
+
+def _vec(*a, **k):
+    from control_pcgrl_amd import VecPcgrlEnv
+    return VecPcgrlEnv(*a, **k)
+
+
+@pytest.mark.parametrize("path", EPISODES, ids=[os.path.basename(p)[8:-4] for p in EPISODES])
+def test_golden_episode_replay(path):
+    z = np.load(path)
+    problem, rep = str(z["problem"]), str(z["representation"])
+    shape = tuple(int(s) for s in z["map_shape"])
+    env = _vec(problem, rep, shape, 1, seeds=[int(z["seed"])], auto_reset=False)
+    T, ep_len = len(z["action"]), int(z["episode_len"])
+    obs_steps = {int(s): i for i, s in enumerate(z["obs_steps"])}
+
+    def check_reset(k):
+        obs, _ = env.reset()
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["reset_grid"][k]), "reset grid (RNG stream)"
+        if rep != "wide":
+            assert np.array_equal(st.pos[0, :2].cpu().numpy(), z["reset_pos"][k])
+        assert np.array_equal(st.stats[0].cpu().numpy(), z["reset_stats"][k])
+        assert np.array_equal(obs[0].cpu().numpy().ravel(), z["reset_obs"][k])
+
+    check_reset(0)
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    for t in range(T):
+        obs, rew, done, _, info = env.step(acts[t:t + 1])
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["grid"][t]), f"grid @ {t}"
+        if rep != "wide":
+            assert np.array_equal(st.pos[0, :2].cpu().numpy(), z["pos"][t]), f"pos @ {t}"
+        got = info["stats"][0].cpu().numpy()
+        assert np.array_equal(got, z["stats"][t]), f"stats @ {t}: {got} vs {z['stats'][t]}"
+        assert abs(float(rew[0]) - z["reward"][t]) <= REW_TOL, f"reward @ {t}"
+        assert bool(done[0]) == bool(z["done"][t]), f"done @ {t}"
+        assert int(st.changes[0]) == z["changes"][t] and int(st.iteration[0]) == z["iterations"][t]
+        o = obs[0].cpu().numpy()
+        assert zlib.crc32(o.tobytes()) == int(z["obs_crc"][t]), f"obs crc @ {t}"
+        if t in obs_steps:
+            assert np.array_equal(o.ravel(), z["obs_full"][obs_steps[t]])
+        if t == ep_len - 1:
+            check_reset(1)
+    env.check_errors()
+
+
+@pytest.mark.parametrize("problem,fname", [("binary", "stats_binary.npz"), ("zelda", "stats_zelda.npz"),
+                                           ("sokoban", "stats_sokoban.npz")])
+def test_golden_stats_known_answers(problem, fname):
+    z = np.load(os.path.join(GOLDEN, fname))
+    env = _vec(problem, "narrow", z["grids"].shape[1:], 1, auto_reset=False)
+    got = env.stats_for_grids(torch.as_tensor(z["grids"])).cpu().numpy()
+    bad = np.nonzero((got != z["stats"]).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} grids differ, first {bad[:5]}: got {got[bad[:3]]} want {z['stats'][bad[:3]]}"
+
+
+def _rollout_vs_oracle(problem, rep, shape, n_envs, n_steps, seed0=100, full_every=97, threads=8, **kw):
+    env = _vec(problem, rep, shape, n_envs, seeds=seed0 + np.arange(n_envs), auto_reset=True, **kw)
+    orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=seed0 + np.arange(n_envs), threads=threads, **kw)
+    obs, _ = env.reset()
+    oobs = orc.reset()
+    assert np.array_equal(obs.cpu().numpy(), oobs), "reset observation"
+    g = torch.Generator(device="cpu").manual_seed(seed0)
+    n_done = 0
+    for t in range(n_steps):
+        a = torch.randint(0, env.num_actions, (n_envs,), generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a.to(env.device))
+        want_obs = (t % full_every == 0) or t == n_steps - 1
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want_obs)
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL, f"reward @ {t}"
+        assert np.array_equal(done.cpu().numpy(), odone), f"done @ {t}"
+        n_done += int(odone.sum())
+        if want_obs:
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+            st, ost = env.get_state(), orc.get_state()
+            assert np.array_equal(st.grids.cpu().numpy().reshape(n_envs, -1), ost["grids"]), f"grids @ {t}"
+            if rep != "wide":
+                assert np.array_equal(st.pos.cpu().numpy()[:, :2], ost["pos"][:, :2])
+            assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"])
+            assert np.array_equal(st.changes.cpu().numpy(), ost["changes"])
+            assert np.allclose(st.ep_return.cpu().numpy(), ost["ep_return"], atol=REW_TOL)
+    le, ole = env.last_episode(), orc.last_episode()
+    assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"])
+    assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"])
+    assert np.array_equal(le.ep_len.cpu().numpy(), ole["ep_len"])
+    assert np.allclose(le.ep_return.cpu().numpy(), ole["ep_return"], atol=REW_TOL)
+    env.check_errors()
+    return n_done
+
+
+def test_binary_narrow_4096_envs_vs_oracle():
+    """BASELINE configs[1]: binary-narrow 16x16, 4096 envs on one MI355X, bit-exact state check vs CPU,
+    across an auto-reset boundary (episode = 770 steps)."""
+    n_done = _rollout_vs_oracle("binary", "narrow", (16, 16), 4096, 800)
+    assert n_done == 4096
+
+
+def test_zelda_turtle_4096_envs_vs_oracle():
+    """BASELINE configs[2] (shortened rollout, still crosses the auto-reset)."""
+    n_done = _rollout_vs_oracle("zelda", "turtle", (16, 16), 4096, 790, full_every=131)
+    assert n_done == 4096
+
+
+@pytest.mark.parametrize("problem,rep", [("binary", "turtle"), ("binary", "wide"), ("zelda", "narrow"),
+                                         ("zelda", "wide"), ("sokoban", "narrow"), ("sokoban", "turtle"),
+                                         ("sokoban", "wide")])
+def test_other_pairs_vs_oracle(problem, rep):
+    _rollout_vs_oracle(problem, rep, (16, 16), 203, 300, full_every=37)
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (5, 7), (12, 16), (16, 32), (32, 32), (20, 24), (64, 32), (40, 16)])
+def test_other_map_shapes_vs_oracle(shape):
+    """ragged / non-square / maximum sizes: lanes-per-env 8, 16, 32, 64; rows beyond H idle."""
+    ow = (2 * shape[0], 32 if shape[1] <= 16 else 64)
+    _rollout_vs_oracle("binary", "narrow", shape, 37, 2 * shape[0] * shape[1] * 3 + 40, full_every=53, obs_window=ow)
+    _rollout_vs_oracle("zelda", "turtle", shape, 21, 200, full_every=29, obs_window=ow)
+
+
+def test_small_obs_window_and_change_percentage():
+    _rollout_vs_oracle("binary", "narrow", (16, 16), 64, 200, obs_window=(8, 16), change_percentage=0.2, full_every=7)
+    _rollout_vs_oracle("zelda", "turtle", (16, 16), 64, 200, obs_window=(16, 16), full_every=7)
+
+
+def test_trained_like_maps_stats_vs_oracle():
+    """Long corridors (the regime a trained generator reaches): snake / spiral / random walks, path-length > 100."""
+    z = np.load(os.path.join(GOLDEN, "stats_binary.npz"))
+    rng = np.random.default_rng(5)
+    grids = [z["grids"][i] for i in range(13)]
+    for _ in range(500):
+        g = np.ones((16, 16), np.uint8)
+        y, x = rng.integers(16, size=2)
+        for _ in range(int(rng.integers(50, 600))):
+            g[y, x] = 0
+            d = rng.integers(4)
+            y = int(np.clip(y + (d == 0) - (d == 1), 0, 15)); x = int(np.clip(x + (d == 2) - (d == 3), 0, 15))
+        grids.append(g)
+    grids = np.array(grids, np.uint8)
+    want = po.stats_for_grids("binary", grids)
+    env = _vec("binary", "narrow", (16, 16), 1, auto_reset=False)
+    got = env.stats_for_grids(torch.as_tensor(grids)).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert want[:, 1].max() >= 136
+
+
+def test_inject_initial_maps_and_masked_reset():
+    n = 50
+    rng = np.random.default_rng(3)
+    grids = rng.integers(0, 8, size=(n, 16, 16), dtype=np.uint8)
+    pos = rng.integers(0, 16, size=(n, 2)).astype(np.int32)
+    env = _vec("zelda", "turtle", (16, 16), n, seeds=np.arange(n), auto_reset=False)
+    orc = po.OracleVecEnv("zelda", "turtle", (16, 16), n, seeds=np.arange(n))
+    obs, _ = env.reset(init_grids=grids, init_pos=pos)
+    oobs = orc.reset(init_grids=grids, init_pos=pos)
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    st, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(st.stats.cpu().numpy(), ost["stats"])
+    assert np.array_equal(st.last_loss.cpu().numpy(), ost["last_loss"])
+    # masked reset: only even envs restart (from their RNG streams)
+    mask = (np.arange(n) % 2 == 0).astype(np.uint8)
+    obs, _ = env.reset(mask=mask)
+    oobs = orc.reset(mask=mask)
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+
+
+def test_out_of_range_action_is_reported():
+    env = _vec("binary", "narrow", (16, 16), 8, seeds=np.arange(8), auto_reset=False)
+    env.reset()
+    before = env.get_state().grids.clone()
+    a = torch.tensor([0, 1, 2, 0, 1, -1, 0, 1], dtype=torch.int32, device=env.device)
+    env.step(a)
+    with pytest.raises(ValueError):
+        env.check_errors()
+    env.check_errors()  # flag is cleared by the poll
+    after = env.get_state().grids
+    assert torch.equal(before[2], after[2]) and torch.equal(before[5], after[5])  # bad actions edit nothing
+
+
+def test_gym_adapter_matches_golden():
+    """make_env(cfg): the reference's single-env call shape (rl/envs.py:28-81) on top of the engine."""
+    from types import SimpleNamespace as NS
+    from control_pcgrl_amd import make_env
+    z = np.load(os.path.join(GOLDEN, "episode_binary_narrow_s1.npz"))
+    cfg = NS(representation="narrow", max_board_scans=3, change_percentage=None, controls=None,
+             task=NS(problem="binary", map_shape=(16, 16), obs_window=(32, 32), weights={"path-length": 1, "regions": 1}),
+             multiagent=NS(n_agents=0))
+    env = make_env(cfg)
+    env.unwrapped.seed(int(z["seed"]))
+    obs, info = env.reset()
+    assert obs.shape == (32, 32, 3) and obs.dtype == np.float32 and info == {}
+    assert np.array_equal(obs.astype(np.uint8).ravel(), z["reset_obs"][0])
+    for t in range(60):
+        obs, r, d, tr, info = env.step(int(z["action"][t]))
+        assert r == z["reward"][t] and d == bool(z["done"][t]) and tr == d
+        assert env.unwrapped._rep_stats == {"regions": int(z["stats"][t][0]), "path-length": int(z["stats"][t][1])}
+        assert info["iterations"] == z["iterations"][t] and info["changes"] == z["changes"][t]
+    with pytest.raises(IndexError):
+        env.step(2)

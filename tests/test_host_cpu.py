@@ -1,0 +1,131 @@
+"""CPU-side checks (no GPU): C-ABI library loads and exports every declared symbol, host tables agree with the
+oracle's independent tables, config building mirrors the reference's derived constants, and the multi-process
+episodic-return reduction works over gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pcgrl_oracle as po
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from control_pcgrl_amd import _lib
+    _lib.build()
+    header = open(os.path.join(ROOT, "include", "pcgrl_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pcgrl_[a-z_]+)\s*\(", header))
+    assert declared >= {"pcgrl_create", "pcgrl_step", "pcgrl_reset", "pcgrl_destroy", "pcgrl_get_state"}
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/pcgrl_amd.h but not exported"
+    assert set(_lib.SYMBOLS) == declared
+    assert b"gfx950" in L.pcgrl_version()
+
+
+def test_code_object_targets_gfx950():
+    from control_pcgrl_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+
+
+def test_create_rejects_bad_configs_without_gpu():
+    """validation happens before any HIP call"""
+    import ctypes as C
+    from control_pcgrl_amd import _lib
+    from control_pcgrl_amd.vec_env import build_config
+    L = _lib.lib()
+    h = C.c_void_p()
+    cfg, _, _ = build_config("binary", "wide", (16, 16), obs_window=(32, 32))
+    assert L.pcgrl_create(C.byref(cfg), 4, 0, C.byref(h)) == 1  # EINVAL: wide needs obs_window == map_shape
+    assert b"obs_window" in L.pcgrl_last_error()
+    cfg, _, _ = build_config("binary", "narrow", (16, 48))
+    assert L.pcgrl_create(C.byref(cfg), 4, 0, C.byref(h)) == 2  # EUNSUPPORTED
+    with pytest.raises(ValueError):
+        build_config("binary", "cellular", (16, 16))
+    with pytest.raises(ValueError):
+        build_config("smb", "narrow", (16, 16))
+
+
+@pytest.mark.parametrize("problem,shape", [("binary", (16, 16)), ("binary", (32, 32)), ("binary", (10, 14)),
+                                           ("zelda", (16, 16)), ("zelda", (32, 32)), ("sokoban", (16, 16)),
+                                           ("minecraft_3D_maze", (7, 7, 7))])
+def test_host_tables_match_oracle_tables(problem, shape):
+    from control_pcgrl_amd.vec_env import build_config
+    for rep in ("narrow", "turtle", "wide"):
+        if problem == "minecraft_3D_maze" and rep != "narrow":
+            continue
+        c, spec, ow = build_config(problem, rep, shape)
+        o = po.make_config(problem, rep, shape)
+        for f in ("problem", "representation", "ndim", "max_iterations", "max_changes", "n_stats", "solver_power"):
+            assert getattr(c, f) == getattr(o, f), f
+        for f in ("dims", "obs_window"):
+            assert list(getattr(c, f)) == list(getattr(o, f)), f
+        for f in ("has_trg", "weights", "trg_lo", "trg_hi"):
+            assert list(getattr(c, f)) == list(getattr(o, f)), f
+        assert spec.stat_keys == po.STAT_KEYS[problem]
+
+
+def test_reference_derived_constants():
+    """values the survey probed from the reference"""
+    from control_pcgrl_amd.problems import problem_spec, target_interval
+    assert problem_spec("binary", (16, 16)).static_trgs["path-length"] == 136
+    z = problem_spec("zelda", (16, 16)).static_trgs
+    assert z["path-length"] == 271 and target_interval(z["nearest-enemy"]) == (5.0, 143.0)
+    assert target_interval(z["enemies"]) == (2.0, 4.0)
+    s = problem_spec("sokoban", (16, 16)).static_trgs
+    assert s["sol-length"] == 20 and target_interval(s["crate"]) == (2.0, 2.0) and "target" not in s
+    m = problem_spec("minecraft_3D_maze", (7, 7, 7)).static_trgs
+    assert m["path-length"] == 12700 and m["n_jump"] == 5
+    from control_pcgrl_amd.vec_env import build_config
+    c, _, _ = build_config("binary", "narrow", (16, 16), change_percentage=0.2)
+    assert c.max_iterations == 769 and c.max_changes == 51
+
+
+def test_shard_ranges_cover_everything():
+    from control_pcgrl_amd.dist import shard_env_range, shard_seeds
+    for total, ws in ((4096 * 8, 8), (10, 3), (7, 8)):
+        ranges = [shard_env_range(total, r, ws) for r in range(ws)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == total
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(ws - 1))
+    assert shard_seeds(100, 10, 1, 3) == [104, 105, 106]
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from control_pcgrl_amd.dist import EpisodeStatsReducer, shard_env_range
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+lo, hi = shard_env_range(10, rank, 2)
+red = EpisodeStatsReducer(2, "cpu")
+n = hi - lo
+done = torch.tensor([(g % 2 == 0) for g in range(lo, hi)])
+ret = torch.tensor([float(g) for g in range(lo, hi)])
+ln = torch.full((n,), 770, dtype=torch.int32)
+fs = torch.stack([torch.arange(lo, hi), torch.arange(lo, hi) * 2], 1).to(torch.int32)
+red.update(done, ret, ln, fs)
+out = red.reduce()
+assert out["episodes"] == 5.0, out
+assert abs(out["mean_return"] - (0 + 2 + 4 + 6 + 8) / 5) < 1e-12, out
+assert out["mean_length"] == 770.0
+assert out["mean_final_stats"] == [4.0, 8.0], out
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_episode_stats_reduction_gloo_world2(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o
