@@ -169,10 +169,29 @@ template <int PROB, int LPE>
 static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_t s) {
   const int epw = 64 / LPE;
   dim3 grid((p.n_envs + epw - 1) / epw), block(64);
+  // compile-time specialised observation path: 16x16 map, 32x32 window (reference default obs_window = 2*map)
+  const bool fast = p.cfg.representation != PCGRL_REP_WIDE && p.cfg.dims[0] == 16 && p.cfg.dims[1] == 16 &&
+                    p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32;
   switch (id) {
-    case K_STEP: hipLaunchKernelGGL((step_kernel<PROB, LPE>), grid, block, lds, s, p); break;
-    case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE>), grid, block, lds, s, p); break;
-    case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<PROB, LPE>), grid, block, lds, s, p); break;
+    case K_STEP:
+      if constexpr (LPE == 16) {
+        if (fast) {
+          hipLaunchKernelGGL((step_kernel<PROB, LPE, true>), grid, dim3(128), lds, s, p);
+          break;
+        }
+      }
+      hipLaunchKernelGGL((step_kernel<PROB, LPE, false>), grid, dim3(128), lds, s, p);
+      break;
+    case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE>), grid, block, 0, s, p); break;
+    case K_OBSERVE:
+      if constexpr (LPE == 16) {
+        if (fast) {
+          hipLaunchKernelGGL((observe_kernel<PROB, LPE, true>), grid, block, lds, s, p);
+          break;
+        }
+      }
+      hipLaunchKernelGGL((observe_kernel<PROB, LPE, false>), grid, block, lds, s, p);
+      break;
     case K_GET_STATE: hipLaunchKernelGGL((get_state_kernel<PROB, LPE>), grid, block, 0, s, p); break;
     case K_LAST_EPISODE:
       hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
@@ -228,7 +247,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   p.n_bits = p.n_tiles <= 2 ? 1 : 3;
   p.n_cells = cfg->dims[0] * cfg->dims[1];
   p.obs_chunks = obs_chunks;
-  e->lds_bytes = (size_t)obs_chunks * 64 * 16;
+  e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * 65;  // one padded observation row per lane + the OOB row
   const int H = cfg->dims[0], W = cfg->dims[1];
   auto dalloc = [&](void **ptr, size_t bytes) -> hipError_t {
     hipError_t err = hipMalloc(ptr, bytes);

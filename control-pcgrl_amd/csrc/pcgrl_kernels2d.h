@@ -111,11 +111,21 @@ struct Grp {
     return (b >> gbase) & ((1ull << LPE) - 1ull);
   }
   __device__ inline bool gany(bool p) const { return gballot(p) != 0; }
-  // sum over the group's lanes (result in every lane)
+  // sum over the group's lanes (result in every lane): DPP butterfly inside a 16-lane row
+  // (quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror), bpermute only across rows
   __device__ inline uint32_t gsum(uint32_t v) const {
-#pragma unroll
-    for (int o = 1; o < LPE; o <<= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    if constexpr (LPE >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+    if constexpr (LPE >= 32) v += (uint32_t)__shfl_xor((int)v, 16, 64);
+    if constexpr (LPE >= 64) v += (uint32_t)__shfl_xor((int)v, 32, 64);
     return v;
+  }
+  // this group's slice of an already computed wave ballot
+  __device__ inline uint64_t gslice(uint64_t b) const {
+    if constexpr (LPE == 64) return b;
+    return (b >> gbase) & ((1ull << LPE) - 1ull);
   }
   // broadcast from the group's lane `src_row`
   __device__ inline uint32_t gbcast(uint32_t v, int src_row) const { return (uint32_t)__shfl((int)v, gbase + src_row, 64); }
@@ -189,24 +199,15 @@ __device__ inline void regions_and_longest_path(const Grp<LPE> &g, uint32_t pass
     int fl = gb ? __builtin_ctzll(gb) : -1;
     uint32_t seed = g.row == fl ? (remaining & (0u - remaining)) : 0u;
     uint32_t front = seed, vis = seed, last = seed;
-    int lastlev = 0, lev = 0;
     while (true) {
       uint32_t nb = expand(g, front) & remaining & ~vis;
-      if (__ballot(nb != 0) == 0) break;
-      lev++;
+      uint64_t bb = __ballot(nb != 0);
+      if (bb == 0) break;
       vis |= nb;
       front = nb;
-      if (nb) {
-        last = nb;
-        lastlev = lev;
-      }
+      last = g.gslice(bb) ? nb : last;  // groups whose frontier died keep their last non-empty level
     }
-    // deepest level reached in this group, then the first cell of that level
-    int maxlev = lastlev;
-#pragma unroll
-    for (int o = 1; o < LPE; o <<= 1) maxlev = max(maxlev, __shfl_xor(maxlev, o, 64));
-    uint32_t cand = (lastlev == maxlev) ? last : 0u;
-    fars |= first_rowmajor(g, cand);
+    fars |= first_rowmajor(g, last);
     remaining &= ~vis;
     reg += gb != 0;
   }
@@ -368,7 +369,8 @@ __device__ inline void set_tile(uint32_t *b, int x, int t) {
 // Every lane of the group replays the env's problem-RNG draws; the map draws of the representation RNG are
 // split by row with an LCG skip-ahead so the 16 lanes generate their rows concurrently.
 template <int PROB, int LPE>
-__device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, uint32_t *b, int *pos) {
+__device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, uint32_t *b, int *pos,
+                                      bool commit = true) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   if (!active) return;
@@ -409,16 +411,17 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
       for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((idx >> k) & 1) << x;
     }
   }
-  if (g.row == 0) {
+  if (commit && g.row == 0) {
     end.store(p.rng[env].rep);
     rp.store(p.rng[env].prob);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ observation
-// One lane assembles one observation row (OW*C bytes) in LDS, interleaved per 16-byte chunk across the
-// wave ((chunk*64 + lane)*16) so that both the 16-byte fills/read-backs and the byte scatters spread over banks.
-__device__ inline uint32_t lds_addr(int lane, int off) { return (uint32_t)((((off >> 4) << 6) + lane) << 4) + (uint32_t)(off & 15); }
+// One lane assembles one observation row (OW*C bytes) in its own LDS row (row stride = bytes + 16, which keeps
+// 16-byte alignment and makes the 16-byte fills / read-backs bank-conflict free), scatters the one-hot bytes of
+// its map row into it, and streams it out with 16-byte stores.
+__device__ inline int lds_row_stride(int row_bytes) { return row_bytes + 16; }
 
 // 16-byte chunk q of the all-out-of-bounds row pattern (byte k is 1 iff k % C == 0)
 template <int C>
@@ -437,7 +440,6 @@ __device__ inline uint4 oob_chunk(int q) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-
 template <int C>
 __device__ inline uint4 oob_chunk_rt(int q) {
   switch (q % C) {
@@ -453,7 +455,10 @@ __device__ inline uint4 oob_chunk_rt(int q) {
   }
 }
 
-template <int PROB, int LPE>
+// FAST: map 16x16 with a 32x32 window (the reference's default obs_window = 2 * map_shape): every map row is
+// visible, every map cell lands inside the window, each lane writes exactly one map row and one all-OOB row,
+// and every loop bound is a compile-time constant.
+template <int PROB, int LPE, bool FAST>
 __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, bool active, const uint32_t *b, const int *pos,
                                   uint8_t *lds) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
@@ -462,50 +467,79 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
   if (p.cfg.representation == PCGRL_REP_WIDE) {
     // wrappers.py:502-526: plain one-hot of the map, (H, W, NT), no out-of-bounds channel
     const int row_bytes = W * NT, chunks = row_bytes >> 4;
-    for (int q = 0; q < chunks; q++) *(uint4 *)(lds + lds_addr(g.lane, q * 16)) = make_uint4(0, 0, 0, 0);
-    if (active && g.row < H)
-      for (int x = 0; x < W; x++) lds[lds_addr(g.lane, x * NT + tile_at<NB>(b, x))] = 1;
+    uint8_t *row = lds + g.lane * lds_row_stride(row_bytes);
+    for (int q = 0; q < chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
     if (active && g.row < H) {
+      for (int x = 0; x < W; x++) row[x * NT + tile_at<NB>(b, x)] = 1;
       uint8_t *dst = p.obs + ((size_t)env * H + g.row) * row_bytes;
-      for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = *(uint4 *)(lds + lds_addr(g.lane, q * 16));
+      for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = *(uint4 *)(row + q * 16);
     }
     return;
   }
   // wrappers.py:407-437 Cropped (map+1, zero pad, window of obs_window around pos) -> :232-257 one-hot with
   // C = NT+1 channels, channel 0 = out of bounds -> :140-150 channel-last image.
+  //
+  // Each lane builds the observation row of ITS map row in LDS (OOB pattern, then one 0/1 byte pair per map cell);
+  // LDS row 64 holds the pure out-of-bounds row.  The group then streams its env's observation out as consecutive
+  // 16-byte chunks (lane r takes chunks r, r+LPE, ...), i.e. 256 contiguous bytes per group per store instruction,
+  // picking each chunk from the LDS row of the lane that owns that map row or from the OOB row.
   constexpr int C = NT + 1;
-  const int OH = p.cfg.obs_window[0], OW = p.cfg.obs_window[1];
-  const int chunks = p.obs_chunks;  // OW*C/16
-  const int row_bytes = OW * C;
-  uint8_t *base = p.obs + (size_t)env * OH * row_bytes;
-  // obs row i shows map row i + pos_r - OH/2 ; visible map rows [r0, r1)
-  const int top = pos[0] - OH / 2;  // map row shown by obs row 0
-  const int r0 = max(0, top), r1 = min(H, top + OH);
-  const int nvis = max(0, r1 - r0), a = r0 - top;  // obs rows [a, a+nvis) are map rows
-  if (active) {
-    // (1) rows that are entirely out of bounds: constant pattern, spread over the group's lanes
-    const int n_oob = OH - nvis;
-    for (int k = g.row; k < n_oob; k += LPE) {
-      int i = k < a ? k : k + nvis;
-      uint8_t *dst = base + (size_t)i * row_bytes;
-      for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = oob_chunk_rt<C>(q);
+  constexpr int FW = 16, FOW = 32, FOH = 32;
+  const int OH = FAST ? FOH : p.cfg.obs_window[0], OW = FAST ? FOW : p.cfg.obs_window[1];
+  const int CW = FAST ? FW : W;
+  const int CH = FAST ? FOW * C / 16 : p.obs_chunks;  // 16-byte chunks per observation row
+  const int RB = OW * C, STRIDE = RB + 16;
+  uint8_t *row = lds + g.lane * STRIDE;
+  uint8_t *oob_row = lds + 64 * STRIDE;
+  const int top = pos[0] - OH / 2;   // map row shown by obs row 0
+  const int left = pos[1] - OW / 2;  // map column shown by obs column 0
+  if constexpr (FAST) {
+#pragma unroll
+    for (int q = 0; q < FOW * C / 16; q++) {
+      *(uint4 *)(row + q * 16) = oob_chunk<C>(q % C);
+      if (g.lane < 1) *(uint4 *)(oob_row + q * 16) = oob_chunk<C>(q % C);
     }
+#pragma unroll
+    for (int x = 0; x < FW; x++) {
+      int o = (x - left) * C;  // always inside the window when OW = 2 * W
+      row[o] = 0;
+      row[o + 1 + tile_at<NB>(b, x)] = 1;
+    }
+  } else {
+    for (int q = 0; q < CH; q++) {
+      *(uint4 *)(row + q * 16) = oob_chunk_rt<C>(q);
+      if (g.lane < 1) *(uint4 *)(oob_row + q * 16) = oob_chunk_rt<C>(q);
+    }
+    if (g.row < H)
+      for (int x = 0; x < CW; x++) {
+        int j = x - left;
+        if (j >= 0 && j < OW) {
+          row[j * C] = 0;
+          row[j * C + 1 + tile_at<NB>(b, x)] = 1;
+        }
+      }
   }
-  // (2) this lane's own map row
-  const bool vis = active && g.row >= r0 && g.row < r1;
-  for (int q = 0; q < chunks; q++) *(uint4 *)(lds + lds_addr(g.lane, q * 16)) = oob_chunk_rt<C>(q);
-  if (vis) {
-    const int left = pos[1] - OW / 2;  // map column shown by obs column 0
-    for (int x = 0; x < W; x++) {
-      int j = x - left;
-      if (j >= 0 && j < OW) {
-        int o = j * C;
-        lds[lds_addr(g.lane, o)] = 0;
-        lds[lds_addr(g.lane, o + 1 + tile_at<NB>(b, x))] = 1;
+  if (active) {
+    uint8_t *base = p.obs + (size_t)env * OH * RB;
+    const int total = OH * CH;
+    if constexpr (FAST) {
+      constexpr int FCH = FOW * C / 16;
+#pragma unroll
+      for (int it = 0; it < FOH * FCH / LPE; it++) {
+        int k = it * LPE + g.row;
+        int i = k / FCH, q = k - i * FCH;
+        int m = i + top;
+        const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
+        *(uint4 *)(base + (size_t)k * 16) = *(const uint4 *)src;
+      }
+    } else {
+      for (int k = g.row; k < total; k += LPE) {
+        int i = k / CH, q = k - i * CH;
+        int m = i + top;
+        const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
+        *(uint4 *)(base + (size_t)k * 16) = *(const uint4 *)src;
       }
     }
-    uint8_t *dst = base + (size_t)(g.row - top) * row_bytes;
-    for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = *(uint4 *)(lds + lds_addr(g.lane, q * 16));
   }
 }
 
@@ -579,12 +613,19 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
   return change;
 }
 
-template <int PROB, int LPE>
-__global__ __launch_bounds__(64) void step_kernel(Params p) {
+// One workgroup = two specialised wavefronts over the same 64/LPE envs:
+//   wave 0 "simulate": action -> stats -> reward/done -> auto-reset -> state write-back
+//   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
+// The two never exchange data: the observation depends only on the post-action grid and position, not on the
+// statistics, so the BFS latency chain and the LDS/HBM-store chain overlap instead of adding up.
+template <int PROB, int LPE, bool FAST>
+__global__ __launch_bounds__(128) void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   Grp<LPE> g;
   g.init();
+  const bool observer = threadIdx.x >= 64;  // wave-uniform
+  if (observer && p.obs == nullptr) return;  // (no barrier below is reached by wave 0 in that case either)
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   const int env = blockIdx.x * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
@@ -596,19 +637,32 @@ __global__ __launch_bounds__(64) void step_kernel(Params p) {
   load_planes<NB>(p, e, g.row, rowok, b);
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
-  int n_step = S->n_step, iteration = S->iteration, changes = S->changes, ep_len = S->ep_len;
-  double last_loss = S->last_loss, ep_return = S->ep_return;
-  int32_t st[NS];
-#pragma unroll
-  for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+  int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   const int action = active ? p.actions[e] : 0;
+  // both waves have read the old state before wave 0 may overwrite it
+  if (p.obs != nullptr) __syncthreads();
 
   // envs/pcgrl_env.py:267-342
   bool bad = false;
   iteration++;
   bool change = rep_update<PROB, LPE>(g, p, active, action, b, pos, n_step, bad);
-  if (bad && g.row == 0 && active) atomicOr(p.err, 1);
   changes += change ? 1 : 0;
+  bool done = iteration > p.cfg.max_iterations;
+  if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
+  const bool do_reset = active && done && p.auto_reset != 0;
+
+  if (observer) {
+    if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE>(g, p, e, do_reset, b, pos, /*commit=*/false);
+    encode_obs<PROB, LPE, FAST>(g, p, e, active, b, pos, lds);
+    return;
+  }
+
+  int ep_len = S->ep_len;
+  double last_loss = S->last_loss, ep_return = S->ep_return;
+  int32_t st[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+  if (bad && g.row == 0 && active) atomicOr(p.err, 1);
   if (__ballot(change) != 0) {
     int32_t ns[NS];
     compute_stats<PROB, LPE>(g, p, e, change, b, colmask, ns);
@@ -617,8 +671,6 @@ __global__ __launch_bounds__(64) void step_kernel(Params p) {
       for (int k = 0; k < NS; k++) st[k] = ns[k];
     }
   }
-  bool done = iteration > p.cfg.max_iterations;
-  if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
   // control_wrappers.py:216-244
   double loss = get_loss<NS>(p.cfg, st);
   double rew = loss - last_loss;
@@ -633,7 +685,6 @@ __global__ __launch_bounds__(64) void step_kernel(Params p) {
       for (int k = 0; k < NS; k++) p.stats_out[(size_t)e * NS + k] = st[k];
     }
   }
-  const bool do_reset = active && done && p.auto_reset != 0;
   if (__ballot(do_reset) != 0) {
     if (do_reset && g.row == 0) {
       S->last_ep_return = ep_return;
@@ -670,7 +721,6 @@ __global__ __launch_bounds__(64) void step_kernel(Params p) {
 #pragma unroll
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
   }
-  encode_obs<PROB, LPE>(g, p, e, active, b, pos, lds);
 }
 
 template <int PROB, int LPE>
@@ -726,7 +776,7 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   (void)lds;
 }
 
-template <int PROB, int LPE>
+template <int PROB, int LPE, bool FAST>
 __global__ __launch_bounds__(64) void observe_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, EPW = 64 / LPE;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -739,7 +789,7 @@ __global__ __launch_bounds__(64) void observe_kernel(Params p) {
   uint32_t b[NB];
   load_planes<NB>(p, e, g.row, rowok, b);
   int pos[2] = {p.st[e].pos[0], p.st[e].pos[1]};
-  encode_obs<PROB, LPE>(g, p, e, active, b, pos, lds);
+  encode_obs<PROB, LPE, FAST>(g, p, e, active, b, pos, lds);
 }
 
 template <int PROB, int LPE>
