@@ -52,6 +52,7 @@ struct Params {
   RngState *rng;
   const JumpEntry *jump;  // [H+1]: skip by row*W draws; entry H = H*W draws
   int32_t *err;           // device error word
+  void *soko;             // SokoPool* (sokoban solver workspace), else null
   // per-call I/O
   const int32_t *actions;
   uint8_t *obs;

@@ -310,7 +310,6 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
   p.init_grids = d_init_grids;
   p.init_pos = d_init_pos;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
-  if (p.cfg.problem == PCGRL_PROB_SOKOBAN) HIPCHK(sokoban_launch(p, h->lpe, (hipStream_t)stream));
   return PCGRL_OK;
 }
 
@@ -325,7 +324,6 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   p.done = d_done;
   p.stats_out = d_stats;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
-  if (p.cfg.problem == PCGRL_PROB_SOKOBAN) HIPCHK(sokoban_launch(p, h->lpe, (hipStream_t)stream));
   return PCGRL_OK;
 }
 
@@ -391,8 +389,7 @@ int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_g
     Params p = h->p;
     p.init_grids = d_grids;
     p.stats_out = d_stats;
-    hipError_t e1 = launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream);
-    hipError_t e2 = e1 == hipSuccess ? sokoban_launch(p, lpe, (hipStream_t)stream) : e1;
+    hipError_t e2 = launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream);
     hipError_t e3 = hipStreamSynchronize((hipStream_t)stream);
     pcgrl_destroy(h);
     if (e2 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e2));

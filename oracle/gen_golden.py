@@ -360,3 +360,53 @@ if __name__ == "__main__":
         gen_stats_sokoban()
     if "mc3d" in what:
         gen_stats_mc3d()
+
+
+def gen_stats_sokoban_solver(n=70):
+    """Harder solver cases (bigger rooms, 1-3 crates, walls inside) so that BFS wins, A* wins at each balance and
+    outright failures are all pinned.  Slow in the reference (seconds per level)."""
+    core = _problem("sokoban", (16, 16))
+    rng = np.random.default_rng(21)
+    E, S, P, C, T = range(5)
+    grids = []
+    while len(grids) < n:
+        g = np.full((16, 16), S, np.uint8)
+        h, w = int(rng.integers(3, 8)), int(rng.integers(3, 8))
+        y0, x0 = int(rng.integers(0, 17 - h)), int(rng.integers(0, 17 - w))
+        g[y0:y0 + h, x0:x0 + w] = E
+        for _ in range(int(rng.integers(0, 4))):  # a few inner walls
+            g[y0 + int(rng.integers(h)), x0 + int(rng.integers(w))] = S
+        free = np.argwhere(g == E)
+        k = int(rng.integers(1, 4))
+        if len(free) < 1 + 2 * k:
+            continue
+        sel = free[rng.permutation(len(free))[: 1 + 2 * k]]
+        for (y, x), t in zip(sel, [P] + [C] * k + [T] * k):
+            g[y, x] = t
+        grids.append(g)
+    # big open rooms: BFS runs into its 10000-iteration cap, the A* stages decide (seconds each in the reference)
+    for k, (h, w) in zip((2, 3, 3, 2, 3, 2, 3, 3), ((6, 7), (7, 7), (8, 6), (9, 9), (6, 6), (12, 5), (7, 8), (10, 10))):
+        g = np.full((16, 16), S, np.uint8)
+        y0, x0 = int(rng.integers(0, 17 - h)), int(rng.integers(0, 17 - w))
+        g[y0:y0 + h, x0:x0 + w] = E
+        inner = np.argwhere(g[y0 + 1:y0 + h - 1, x0 + 1:x0 + w - 1] == E) + [y0 + 1, x0 + 1]
+        free = np.argwhere(g == E)
+        cr = inner[rng.permutation(len(inner))[:k]]           # crates away from the walls (pushable)
+        for y, x in cr:
+            g[y, x] = C
+        rest = np.argwhere(g == E)
+        sel = rest[rng.permutation(len(rest))[: 1 + k]]
+        for (y, x), t in zip(sel, [P] + [T] * k):
+            g[y, x] = t
+        grids.append(g)
+    grids = np.array(grids, np.uint8)
+    stats = np.array([_get_stats(core, "sokoban", g) for g in grids], np.int32)
+    np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver.npz"), grids=grids, stats=stats,
+                        stat_keys=np.array(STAT_KEYS["sokoban"]))
+    ran = int((stats[:, 3] == 1).sum())
+    print("stats_sokoban_solver", grids.shape, "one-region", ran, "solved", int((stats[:, 5] > 0).sum()),
+          "max sol", stats[:, 5].max(), "failed with dist", int(((stats[:, 4] > 0) & (stats[:, 4] != 8192)).sum()))
+
+
+if __name__ == "__main__" and "sokoban_solver" in sys.argv[1:]:
+    gen_stats_sokoban_solver()

@@ -69,7 +69,8 @@ def test_golden_episode_replay(path):
 
 
 @pytest.mark.parametrize("problem,fname", [("binary", "stats_binary.npz"), ("zelda", "stats_zelda.npz"),
-                                           ("sokoban", "stats_sokoban.npz")])
+                                           ("sokoban", "stats_sokoban.npz"),
+                                           ("sokoban", "stats_sokoban_solver.npz")])
 def test_golden_stats_known_answers(problem, fname):
     z = np.load(os.path.join(GOLDEN, fname))
     env = _vec(problem, "narrow", z["grids"].shape[1:], 1, auto_reset=False)
