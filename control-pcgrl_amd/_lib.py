@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpcgrl_amd.so")
-SOURCES = ["pcgrl_engine.hip", "pcgrl_kernels2d.h", "pcgrl_sokoban.h", "pcgrl_common.h"]
+SOURCES = ["pcgrl_engine.hip", "pcgrl_kernels2d.h", "pcgrl_kernels3d.h", "pcgrl_sokoban.h", "pcgrl_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pcgrl_amd.h")
 
 PCGRL_MAX_STATS = 8

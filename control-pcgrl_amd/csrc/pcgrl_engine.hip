@@ -13,6 +13,7 @@
 #include "pcgrl_common.h"
 #include "pcgrl_kernels2d.h"
 #include "pcgrl_sokoban.h"
+#include "pcgrl_kernels3d.h"
 
 using namespace pcgrl;
 
@@ -32,6 +33,7 @@ struct pcgrl_engine {
   int device = 0;
   int lpe = 16;
   size_t lds_bytes = 0;
+  int cpl = 0;  // 3-D: cells per lane of the reset RNG split
   int64_t obs_bytes = 0;
   int obs_ndim = 0;
   int32_t obs_shape[4] = {0, 0, 0, 0};
@@ -115,7 +117,25 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   if (c.representation < 0 || c.representation > PCGRL_REP_WIDE) return fail(PCGRL_EINVAL, "unknown representation");
   if (c.n_stats != n_stats_of(c.problem)) return fail(PCGRL_EINVAL, "n_stats does not match the problem");
   const int nt = n_tiles_of(c.problem);
-  if (c.problem == PCGRL_PROB_MC3DMAZE) return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze kernels are not built yet");
+  if (c.problem == PCGRL_PROB_MC3DMAZE) {
+    if (c.ndim != 3) return fail(PCGRL_EINVAL, "minecraft_3D_maze needs ndim == 3");
+    if (c.representation != PCGRL_REP_NARROW)
+      return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze: only the narrow representation is on the accelerated path");
+    const int Z = c.dims[0], Y = c.dims[1], X = c.dims[2];
+    if (Z < 1 || Y < 1 || X < 1 || Z > 8 || Y * X > 63 || Z * Y * X > M3_MAXCELLS)
+      return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze: need Z <= 8, Y*X <= 63, Z*Y*X <= 512");
+    const int64_t cells = (int64_t)c.obs_window[0] * c.obs_window[1] * c.obs_window[2];
+    if (cells < 1 || cells % 4) return fail(PCGRL_EUNSUPPORTED, "3-D obs_window volume must be a positive multiple of 4");
+    lpe = 64;
+    obs_chunks = 0;
+    obs_bytes = cells * 4;
+    shape[0] = c.obs_window[0];
+    shape[1] = c.obs_window[1];
+    shape[2] = c.obs_window[2];
+    shape[3] = 4;  // out-of-bounds, AIR, DIRT, path overlay
+    ndim = 4;
+    return PCGRL_OK;
+  }
   if (c.ndim != 2) return fail(PCGRL_EINVAL, "2-D problem needs ndim == 2");
   const int H = c.dims[0], W = c.dims[1];
   if (H < 1 || W < 1 || H > 64 || W > 32) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 32");
@@ -145,14 +165,21 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   return PCGRL_OK;
 }
 
-static std::vector<JumpEntry> make_jump_table(int H, int W) {
+static std::vector<JumpEntry> make_jump_table(int H, int W, int last = -1) {
   // A_k = a^k, G_k = 1 + a + ... + a^(k-1)  (mod 2^128); entry r = skip r*W draws, entry H = H*W draws
+  // (or `last` draws when given: 3-D uses H = 64 lanes, W = cells per lane, last = n_cells)
   std::vector<JumpEntry> t(H + 1);
   U128 A{0, 1}, G{0, 0};
   const U128 a{PCG_MULT_HI, PCG_MULT_LO};
   int k = 0;
   for (int r = 0; r <= H; r++) {
-    while (k < r * W) {
+    const int want = (r == H && last >= 0) ? last : r * W;
+    if (want < k) {  // only for the final entry when last < H*W: restart
+      A = U128{0, 1};
+      G = U128{0, 0};
+      k = 0;
+    }
+    while (k < want) {
       G = add128(mul128(G, a), U128{0, 1});
       A = mul128(A, a);
       k++;
@@ -211,7 +238,23 @@ static hipError_t launch_p(KernelId id, int lpe, const Params &p, size_t lds, hi
   }
 }
 
-static hipError_t launch(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s) {
+static hipError_t launch3d(KernelId id, const Params &p, int cpl, hipStream_t s) {
+  dim3 grid(p.n_envs), block(64);
+  switch (id) {
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP>), grid, block, 0, s, p, cpl); break;
+    case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET>), grid, block, 0, s, p, cpl); break;
+    case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE>), grid, block, 0, s, p, cpl); break;
+    case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE>), grid, block, 0, s, p, cpl); break;
+    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((m3_kernel<M3_STATS_FOR_GRIDS>), grid, block, 0, s, p, cpl); break;
+    case K_LAST_EPISODE:
+      hipLaunchKernelGGL((last_episode_kernel<PCGRL_PROB_MC3DMAZE, 64>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
+      break;
+  }
+  return hipGetLastError();
+}
+
+static hipError_t launch(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s, int cpl = 0) {
+  if (p.cfg.problem == PCGRL_PROB_MC3DMAZE) return launch3d(id, p, cpl, s);
   switch (p.cfg.problem) {
     case PCGRL_PROB_BINARY: return launch_p<PCGRL_PROB_BINARY>(id, lpe, p, lds, s);
     case PCGRL_PROB_ZELDA: return launch_p<PCGRL_PROB_ZELDA>(id, lpe, p, lds, s);
@@ -245,9 +288,11 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   p.n_envs = n_envs;
   p.n_tiles = n_tiles_of(cfg->problem);
   p.n_bits = p.n_tiles <= 2 ? 1 : 3;
-  p.n_cells = cfg->dims[0] * cfg->dims[1];
+  const bool is3d = cfg->problem == PCGRL_PROB_MC3DMAZE;
+  p.n_cells = cfg->dims[0] * cfg->dims[1] * (is3d ? cfg->dims[2] : 1);
   p.obs_chunks = obs_chunks;
   e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * 65;  // one padded observation row per lane + the OOB row
+  e->cpl = is3d ? (p.n_cells + 63) / 64 : 0;
   const int H = cfg->dims[0], W = cfg->dims[1];
   auto dalloc = [&](void **ptr, size_t bytes) -> hipError_t {
     hipError_t err = hipMalloc(ptr, bytes);
@@ -265,11 +310,14 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
       return fail(PCGRL_EHIP, std::string(#x) + ": " + hipGetErrorString(_e));                       \
     }                                                                                                \
   } while (0)
-  CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * p.n_bits * H * sizeof(uint32_t)));
+  if (is3d)
+    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * M3_MAXW * sizeof(uint32_t)));  // [tile bits | path overlay bits]
+  else
+    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * p.n_bits * H * sizeof(uint32_t)));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
   CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 4));
-  std::vector<JumpEntry> jt = make_jump_table(H, W);
+  std::vector<JumpEntry> jt = is3d ? make_jump_table(64, e->cpl, p.n_cells) : make_jump_table(H, W);
   JumpEntry *djt = nullptr;
   CREATE_CHK(dalloc((void **)&djt, jt.size() * sizeof(JumpEntry)));
   CREATE_CHK(hipMemcpy(djt, jt.data(), jt.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
@@ -309,7 +357,7 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
   p.mask = d_mask;
   p.init_grids = d_init_grids;
   p.init_pos = d_init_pos;
-  HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
+  HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
 
@@ -323,7 +371,7 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   p.reward = d_reward;
   p.done = d_done;
   p.stats_out = d_stats;
-  HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
+  HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
 
@@ -331,7 +379,7 @@ int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream) {
   if (!h || !d_obs) return fail(PCGRL_EINVAL, "pcgrl_observe: bad arguments");
   Params p = h->p;
   p.obs = d_obs;
-  HIPCHK(launch(K_OBSERVE, h->lpe, p, h->lds_bytes, (hipStream_t)stream));
+  HIPCHK(launch(K_OBSERVE, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
 
@@ -354,7 +402,7 @@ int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d
   p.stats_out = d_stats;
   p.out_last_loss = d_last_loss;
   p.out_ep_return = d_ep_return;
-  HIPCHK(launch(K_GET_STATE, h->lpe, p, 0, (hipStream_t)stream));
+  HIPCHK(launch(K_GET_STATE, h->lpe, p, 0, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
 
@@ -366,7 +414,7 @@ int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_le
   p.out_ep_len = d_ep_len;
   p.stats_out = d_final_stats;
   p.out_n_episodes = d_n_episodes;
-  HIPCHK(launch(K_LAST_EPISODE, h->lpe, p, 0, (hipStream_t)stream));
+  HIPCHK(launch(K_LAST_EPISODE, h->lpe, p, 0, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
 
@@ -378,20 +426,23 @@ int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_g
   pcgrl_config c = *cfg;
   c.representation = PCGRL_REP_NARROW;
   c.obs_window[0] = 2 * c.dims[0];
-  c.obs_window[1] = 32;  // unused here; any legal value
+  c.obs_window[1] = c.ndim == 3 ? 2 * c.dims[1] : 32;  // unused here; any legal value
+  c.obs_window[2] = c.ndim == 3 ? 2 * c.dims[2] : 1;
   int rc = validate(c, lpe, obs_bytes, obs_chunks, shape, ndim);
   if (rc) return rc;
-  if (c.problem == PCGRL_PROB_SOKOBAN) {
-    // the solver needs engine-owned scratch: go through a transient engine
+  if (c.problem == PCGRL_PROB_SOKOBAN || c.problem == PCGRL_PROB_MC3DMAZE) {
+    // the solver / the overflow flag need engine-owned scratch: go through a transient engine
     pcgrl_handle h = nullptr;
     rc = pcgrl_create(&c, n, device, &h);
     if (rc) return rc;
     Params p = h->p;
     p.init_grids = d_grids;
     p.stats_out = d_stats;
-    hipError_t e2 = launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream);
+    hipError_t e2 = launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream, h->cpl);
     hipError_t e3 = hipStreamSynchronize((hipStream_t)stream);
+    int perr = pcgrl_poll_error(h);
     pcgrl_destroy(h);
+    if (perr) return perr;
     if (e2 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e2));
     if (e3 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e3));
     return PCGRL_OK;
@@ -420,6 +471,7 @@ int pcgrl_poll_error(pcgrl_handle h) {
     HIPCHK(hipMemset(h->p.err, 0, sizeof(flags)));
     if (flags[0] & 1) return fail(PCGRL_EACTION, "an action was outside the action space (the reference raises IndexError)");
     if (flags[0] & 2) return fail(PCGRL_EUNSUPPORTED, "sokoban solver: level exceeds the device solver's limits");
+    if (flags[0] & 4) return fail(PCGRL_EUNSUPPORTED, "3-D maze path search: queue overflow (more than 1536 entries)");
     return fail(PCGRL_EINVAL, "device error flag set");
   }
   return PCGRL_OK;

@@ -271,7 +271,11 @@ struct ProbTraits<PCGRL_PROB_SOKOBAN> {
   static constexpr int NT = 5, NB = 3, NS = 7;
 };
 
-struct SokobanWork;  // device-side solver scratch (pcgrl_sokoban.h)
+template <>
+struct ProbTraits<PCGRL_PROB_MC3DMAZE> {
+  static constexpr int NT = 2, NB = 1, NS = 3;
+};
+
 template <int LPE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);

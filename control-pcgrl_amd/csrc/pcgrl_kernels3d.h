@@ -1,0 +1,518 @@
+// pcgrl_kernels3d.h -- gfx950 kernels for minecraft_3D_maze (narrow representation), one wavefront per env.
+//
+// Reference (paths relative to control_pcgrl/): envs/probs/minecraft/minecraft_3D_maze_prob.py:143-181 get_stats,
+// :84-93 process_observation; envs/helper_3D.py: _passable :214-319, _flood_fill :354-383, calc_num_regions :396-406,
+// run_dijkstra :422-490, calc_longest_path :503-563, remove_stacked_path_tiles :657-675; envs/pcgrl_env.py:267-342.
+//
+// Lane roles inside the wavefront:
+//   lanes 0..Z-1   one z-plane each as a (Y*X)-bit mask: 6-neighbour flood fill = shifts by 1 / X inside the lane and a
+//                  DPP row_shr/row_shl between planes; start-candidate masks for the path search
+//   lanes 0..3     the four move directions of helper_3D._passable, evaluated together for each queue entry
+//   all 64 lanes   grid/overlay conversion, farthest-cell arg-max, path-overlay post-processing, reset RNG (LCG skip-ahead
+//                  per lane) and the observation (one 16-byte chunk = 4 cells x 4 one-hot channels per lane per store,
+//                  1 KiB contiguous per wave instruction)
+// The path search is the reference's FIFO label-correcting search and must keep its pop order (tie-breaks decide
+// n_jump, the farthest cell and the path drawn into the next observation), so its queue, the per-cell best-entry table
+// and the first-insertion order list live in LDS and one entry is popped per iteration.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pcgrl_common.h"
+#include "pcgrl_kernels2d.h"
+
+namespace pcgrl {
+
+constexpr int M3_MAXCELLS = 512;
+constexpr int M3_MAXW = M3_MAXCELLS / 32;  // bit words
+constexpr int M3_ENT_CAP = 1536;           // queue entries per search (LDS)
+constexpr int M3_NS = 3;
+
+struct M3Lds {
+  uint4 ent[M3_ENT_CAP];        // x | y<<8 | z<<16 | kind<<24 ; len | njump<<16 ; parent ; unused
+  uint16_t best[M3_MAXCELLS];   // per cell: accepted entry id (the `paths` dict), 0xFFFF = none
+  uint16_t order[M3_MAXCELLS];  // cells in first-insertion order
+  uint32_t dirt[M3_MAXW + 2];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
+  uint32_t pathm[M3_MAXW + 2];  // tiles of the best path
+  uint32_t over[M3_MAXW + 2];   // overlay mask (transposed index) for the observation
+  uint8_t col[64];              // per (y,x): AIR bits over z
+};
+
+struct M3Ctx {
+  int lane, Z, Y, X, n_cells, nw;
+};
+
+enum { M3_WALK = 0, M3_DOWN = 1, M3_UP = 2, M3_JFLAT = 3, M3_JUP = 4, M3_JDOWN = 5, M3_ROOT = 6 };
+
+__device__ inline bool m3_dirt(const M3Lds &L, int cell) { return (L.dirt[cell >> 5] >> (cell & 31)) & 1u; }
+
+// (Y*X)-bit AIR mask of plane z from the flat bit string
+__device__ inline uint64_t m3_plane_air(const M3Lds &L, const M3Ctx &c, int z) {
+  const int pbits = c.Y * c.X, b0 = z * pbits;
+  const int w = b0 >> 5, s = b0 & 31;
+  uint64_t lo = (uint64_t)L.dirt[w] | ((uint64_t)L.dirt[w + 1] << 32);
+  uint64_t v = lo >> s;
+  if (s) v |= (uint64_t)L.dirt[w + 2] << (64 - s);
+  const uint64_t pm = pbits >= 64 ? ~0ull : ((1ull << pbits) - 1ull);
+  return ~v & pm;
+}
+
+__device__ inline uint64_t dpp64_up(uint64_t v) {  // from lane-1 (0 into lane 0 of a DPP row)
+  uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x111, 0xF, 0xF, true);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x111, 0xF, 0xF, true);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ inline uint64_t dpp64_down(uint64_t v) {  // from lane+1
+  uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x101, 0xF, 0xF, true);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x101, 0xF, 0xF, true);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// helper_3D.py:396-406 calc_num_regions (6-neighbour components of AIR)
+__device__ inline int m3_regions(const M3Ctx &c, uint64_t air) {
+  uint64_t notx0 = 0, notxl = 0;  // plane bits whose x is not 0 / not X-1
+  for (int y = 0; y < c.Y; y++) {
+    uint64_t rowm = ((1ull << c.X) - 1ull) << (y * c.X);
+    notx0 |= rowm & ~(1ull << (y * c.X));
+    notxl |= rowm & ~(1ull << (y * c.X + c.X - 1));
+  }
+  uint64_t remaining = c.lane < c.Z ? air : 0ull;
+  int n = 0;
+  while (true) {
+    uint64_t b = __ballot(remaining != 0);
+    if (b == 0) break;
+    int fl = __builtin_ctzll(b);
+    uint64_t f = c.lane == fl ? (remaining & (0ull - remaining)) : 0ull;
+    while (true) {
+      uint64_t d = ((f & notxl) << 1) | ((f & notx0) >> 1) | (f << c.X) | (f >> c.X) | dpp64_up(f) | dpp64_down(f);
+      uint64_t nf = d & remaining & ~f;
+      if (__ballot(nf != 0) == 0) break;
+      f |= nf;
+    }
+    remaining &= ~f;
+    n++;
+  }
+  return n;
+}
+
+__device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+
+// One search of helper_3D.run_dijkstra from (sx,sy,sz).  Uniform over the wave; returns number of entries.
+// On overflow of the LDS queue sets *overflow.
+__device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, bool &overflow) {
+  for (int i = c.lane; i < c.n_cells; i += 64) L.best[i] = 0xFFFF;
+  if (c.lane == 0) L.ent[0] = make_uint4((uint32_t)sx | ((uint32_t)sy << 8) | ((uint32_t)sz << 16) | ((uint32_t)M3_ROOT << 24), 1u, 0xFFFFFFFFu, 0u);
+  int head = 0, tail = 1;
+  n_order = 0;
+  const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};  // helper_3D.py:220
+  const int dxl = c.lane < 4 ? DX[c.lane & 3] : 0, dyl = c.lane < 4 ? DY[c.lane & 3] : 0;
+  while (head < tail) {
+    const uint4 e = L.ent[head];
+    const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255;
+    const int len = e.y & 0xFFFF, nj = e.y >> 16;
+    const int ci = m3_cell(c, x, y, z);
+    const int b = L.best[ci];
+    bool accept = true;
+    if (b != 0xFFFF && (int)(L.ent[b].y & 0xFFFF) <= len) accept = false;      // :437-440
+    const uint32_t cc = L.col[y * c.X + x];
+    if (accept && (z + 1 == c.Z || !((cc >> (z + 1)) & 1u))) accept = false;    // :443-445 no head-room
+    if (!accept) {
+      head++;
+      continue;
+    }
+    if (c.lane == 0) {
+      if (b == 0xFFFF) L.order[n_order] = (uint16_t)ci;
+      L.best[ci] = (uint16_t)head;
+    }
+    if (b == 0xFFFF) n_order++;
+    // successors: lane d < 4 evaluates direction d (helper_3D.py:214-319)
+    bool ok = false;
+    int tx = 0, ty = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
+    if (c.lane < 4) {
+      const int nx = x + dxl, ny = y + dyl, nz = z, jx = x + 2 * dxl, jy = y + 2 * dyl;
+      if (nx >= 0 && ny >= 0 && nx < c.X && ny < c.Y) {
+        const uint32_t cn = L.col[ny * c.X + nx];
+        auto A = [&](uint32_t col, int k) -> bool { return (col >> k) & 1u; };
+        if ((nz == 0 || !A(cn, nz - 1)) && A(cn, nz) && A(cn, nz + 1)) {
+          ok = true; tx = nx; ty = ny; tz = nz; kind = M3_WALK; add = 1;
+        } else if (nz >= 1 && (nz - 1 == 0 || !A(cn, nz - 2)) && A(cn, nz - 1) && A(cn, nz) && A(cn, nz + 1)) {
+          ok = true; tx = nx; ty = ny; tz = nz - 1; kind = M3_DOWN; add = 2;
+        } else if (nz + 2 < c.Z && !A(cn, nz) && A(cn, nz + 1) && A(cn, nz + 2) && A(cc, nz + 2)) {
+          ok = true; tx = nx; ty = ny; tz = nz + 1; kind = M3_UP; add = 2;
+        } else if (nz - 2 >= 0 && nz + 2 < c.Z && A(cn, nz + 2) && A(cn, nz + 1) && A(cn, nz) && A(cn, nz - 1) && A(cn, nz - 2) &&
+                   A(cc, nz + 2) && jx >= 0 && jy >= 0 && jx < c.X && jy < c.Y) {
+          const uint32_t cj = L.col[jy * c.X + jx];
+          const int jz = z;
+          if (A(cj, jz + 1) && A(cj, jz + 2) && A(cj, jz) && !A(cj, jz - 1)) {
+            ok = true; tx = jx; ty = jy; tz = jz; kind = M3_JFLAT; add = 2; nj2 = nj + 1;
+          } else if (jz + 3 < c.Z && A(cj, jz + 3) && A(cj, jz + 2) && A(cj, jz + 1) && !A(cj, jz)) {
+            ok = true; tx = jx; ty = jy; tz = jz + 1; kind = M3_JUP; add = 3; nj2 = nj + 1;
+          } else if (A(cj, jz) && A(cj, jz + 1) && A(cj, jz - 1) && !A(cj, jz - 2)) {
+            ok = true; tx = jx; ty = jy; tz = jz - 1; kind = M3_JDOWN; add = 3; nj2 = nj + 1;
+          }
+        }
+      }
+    }
+    const uint64_t okb = __ballot(ok);
+    const int npush = __popcll(okb);
+    if (tail + npush > M3_ENT_CAP) {
+      overflow = true;
+      break;
+    }
+    if (ok) {
+      const int slot = tail + __popcll(okb & ((1ull << c.lane) - 1ull));
+      L.ent[slot] = make_uint4((uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)tz << 16) | ((uint32_t)kind << 24),
+                               (uint32_t)(len + add) | ((uint32_t)nj2 << 16), (uint32_t)head, 0u);
+    }
+    tail += npush;
+    head++;
+  }
+  return tail;
+}
+
+// first maximum of len(path) in first-insertion order (helper_3D.py:538-541); returns the cell, sets entry id
+__device__ inline int m3_farthest(const M3Lds &L, const M3Ctx &c, int n_order, int &entry) {
+  uint32_t key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
+  for (int k = c.lane; k < n_order; k += 64) {
+    uint32_t len = L.ent[L.best[L.order[k]]].y & 0xFFFF;
+    uint32_t kk = (len << 16) | (uint32_t)(0xFFFF - k);
+    key = kk > key ? kk : key;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t other = (uint32_t)__shfl_xor((int)key, o, 64);
+    key = other > key ? other : key;
+  }
+  const int k = 0xFFFF - (int)(key & 0xFFFF);
+  const int cell = L.order[k];
+  entry = L.best[cell];
+  return cell;
+}
+
+// helper_3D.calc_longest_path + remove_stacked_path_tiles + minecraft_3D_maze_prob.get_stats
+// air: this lane's plane (lanes < Z).  Results uniform over the wave.  L.over receives the new overlay mask.
+__device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t *st, bool &overflow) {
+  // per-(y,x) column masks for the move rules
+  if (c.lane < 64) {
+    for (int q = c.lane; q < c.Y * c.X; q += 64) {
+      uint32_t m = 0;
+      for (int z = 0; z < c.Z; z++) m |= (uint32_t)(!m3_dirt(L, z * c.Y * c.X + q)) << z;
+      L.col[q] = (uint8_t)m;
+    }
+  }
+  st[0] = m3_regions(c, air);
+  // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
+  const uint64_t above = dpp64_down(air), below = dpp64_up(air);
+  uint64_t cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : 0ull;
+  uint32_t marked = 0;  // z-planes of final_visited_map that are fully set (the fancy-index bug, :531)
+  int final_value = 0, n_jump = 0;
+  for (int i = c.lane; i < c.nw + 2; i += 64) {
+    L.pathm[i] = 0;
+    L.over[i] = 0;
+  }
+  while (true) {
+    const bool mine = c.lane < c.Z && cand != 0 && !((marked >> c.lane) & 1u);
+    const uint64_t b = __ballot(mine);
+    if (b == 0) break;
+    const int sz = __builtin_ctzll(b);
+    const int bit = (int)__shfl((int)__builtin_ctzll(cand | (1ull << 63)), sz, 64);
+    const int sy = bit / c.X, sx = bit - sy * c.X;
+    int n_order = 0, e1 = 0, e2 = 0;
+    m3_search(L, c, sx, sy, sz, n_order, overflow);
+    if (overflow) break;
+    // mark planes z = v for every coordinate value v of every reached cell
+    uint32_t mk = 0;
+    for (int k = c.lane; k < n_order; k += 64) {
+      int ci = L.order[k];
+      int x = ci % c.X, y = (ci / c.X) % c.Y, z = ci / (c.X * c.Y);
+      mk |= (1u << x) | (1u << y) | (1u << z);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mk |= (uint32_t)__shfl_xor((int)mk, o, 64);
+    marked |= mk & ((1u << c.Z) - 1u);
+    const int far = m3_farthest(L, c, n_order, e1);
+    const int fx = far % c.X, fy = (far / c.X) % c.Y, fz = far / (c.X * c.Y);
+    m3_search(L, c, fx, fy, fz, n_order, overflow);
+    if (overflow) break;
+    (void)m3_farthest(L, c, n_order, e2);
+    const uint4 fe = L.ent[e2];
+    const int max_dist = fe.y & 0xFFFF;
+    n_jump = fe.y >> 16;  // :553 overwritten by every processed component
+    if (max_dist > final_value) {
+      final_value = max_dist;
+      // materialise the tiles of paths[(mx,my,mz)] into a bit mask (lane 0 walks the parent chain)
+      for (int i = c.lane; i < c.nw + 2; i += 64) L.pathm[i] = 0;
+      if (c.lane == 0) {
+        int id = e2;
+        while (true) {
+          const uint4 e = L.ent[id];
+          const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255, kind = e.x >> 24;
+          auto mark = [&](int mx, int my, int mz) {
+            int ci = m3_cell(c, mx, my, mz);
+            L.pathm[ci >> 5] |= 1u << (ci & 31);
+          };
+          mark(x, y, z);
+          if (kind == M3_ROOT) break;
+          const uint4 pe = L.ent[e.z];
+          const int px = pe.x & 255, py = (pe.x >> 8) & 255, pz = (pe.x >> 16) & 255;
+          const int mxx = (px + x) >> 1, myy = (py + y) >> 1;  // the jumped-over column
+          switch (kind) {
+            case M3_DOWN: mark(x, y, pz); break;                              // [(nx, ny, nz)]
+            case M3_UP: mark(px, py, pz + 1); break;                          // [(x, y, nz+1)]
+            case M3_JFLAT: mark(mxx, myy, pz); break;                         // [(nx, ny, nz)]
+            case M3_JUP: mark(mxx, myy, pz); mark(mxx, myy, pz + 1); break;   // [(nx,ny,nz), (nx,ny,nz+1)]
+            case M3_JDOWN: mark(mxx, myy, pz); mark(mxx, myy, pz - 1); break; // [(nx,ny,nz), (nx,ny,nz-1)]
+            default: break;
+          }
+          id = (int)e.z;
+        }
+      }
+    }
+  }
+  // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
+  // path tile (x,y,z) is drawn at array index [x][y][z]
+  const int pbits = c.Y * c.X;
+  for (int ci = c.lane; ci < c.n_cells; ci += 64) {
+    bool in = (L.pathm[ci >> 5] >> (ci & 31)) & 1u;
+    if (in && ci >= pbits) {
+      int lo = ci - pbits;
+      if ((L.pathm[lo >> 5] >> (lo & 31)) & 1u) in = false;
+    }
+    if (in) {
+      int x = ci % c.X, y = (ci / c.X) % c.Y, z = ci / pbits;
+      int oi = (x * c.Y + y) * c.X + z;
+      if (x < c.Z && y < c.Y && z < c.X) atomicOr(&L.over[oi >> 5], 1u << (oi & 31));
+    }
+  }
+  st[1] = final_value;
+  st[2] = n_jump;
+}
+
+// observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay
+__device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Params &p, int env, const int *pos, bool show_path) {
+  if (p.obs == nullptr) return;
+  const int o0 = p.cfg.obs_window[0], o1 = p.cfg.obs_window[1], o2 = p.cfg.obs_window[2];
+  const int total = o0 * o1 * o2, chunks = total >> 2;
+  uint4 *dst = (uint4 *)(p.obs + (size_t)env * total * 4);
+  const int t0 = pos[0] - o0 / 2, t1 = pos[1] - o1 / 2, t2 = pos[2] - o2 / 2;
+  for (int ch = c.lane; ch < chunks; ch += 64) {
+    uint32_t w[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      int q = ch * 4 + t;
+      int k = q % o2, j = (q / o2) % o1, i = q / (o2 * o1);
+      int a = t0 + i, b = t1 + j, d = t2 + k;
+      int v = 0;
+      if ((unsigned)a < (unsigned)c.Z && (unsigned)b < (unsigned)c.Y && (unsigned)d < (unsigned)c.X) {
+        int ci = (a * c.Y + b) * c.X + d;
+        v = 1 + (int)m3_dirt(L, ci);
+        if (show_path && ((L.over[ci >> 5] >> (ci & 31)) & 1u)) v = 3;
+      }
+      w[t] = 1u << (8 * v);
+    }
+    dst[ch] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order)
+__device__ inline void m3_reset_rng(M3Lds &L, const M3Ctx &c, const Params &p, int env, int cpl) {
+  Pcg rp, rr;
+  rp.load(p.rng[env].prob);
+  rr.load(p.rng[env].rep);
+  double p0 = rp.next_double(), p1 = rp.next_double();
+  double total = 0.0;
+  total += p0;
+  total += p1;
+  double c0 = p0 / total, c1 = c0 + p1 / total;
+  c0 /= c1;  // cdf /= cdf[-1]
+  for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
+  Pcg end = rr;
+  end.jump(p.jump[64]);
+  rr.jump(p.jump[c.lane]);
+  uint32_t bits = 0;
+  const int first = c.lane * cpl;
+  for (int k = 0; k < cpl; k++) {
+    int ci = first + k;
+    if (ci < c.n_cells) {
+      double u = rr.next_double();
+      int idx = (c0 <= u ? 1 : 0) + (1.0 <= u ? 1 : 0);  // searchsorted(cdf, u, 'right') with cdf[-1] == 1.0
+      if (idx >= 1) bits |= 1u << k;
+    }
+  }
+  for (int k = 0; k < cpl; k++) {
+    int ci = first + k;
+    if (ci < c.n_cells && ((bits >> k) & 1u)) atomicOr(&L.dirt[ci >> 5], 1u << (ci & 31));
+  }
+  if (c.lane == 0) {
+    end.store(p.rng[env].rep);
+    rp.store(p.rng[env].prob);
+  }
+}
+
+enum M3Mode { M3_STEP = 0, M3_RESET = 1, M3_OBSERVE = 2, M3_STATS_FOR_GRIDS = 3, M3_GET_STATE = 4 };
+
+template <int MODE>
+__global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
+  __shared__ M3Lds L;
+  M3Ctx c;
+  c.lane = (int)__lane_id();
+  c.Z = p.cfg.dims[0];
+  c.Y = p.cfg.dims[1];
+  c.X = p.cfg.dims[2];
+  c.n_cells = c.Z * c.Y * c.X;
+  c.nw = (c.n_cells + 31) >> 5;
+  const int env = blockIdx.x;
+  constexpr int NS = M3_NS;
+  uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * M3_MAXW;  // [dirt words | overlay words]
+  EnvState *S = &p.st[env];
+
+  if constexpr (MODE == M3_STATS_FOR_GRIDS) {
+    for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
+    const uint8_t *src = p.init_grids + (size_t)env * c.n_cells;
+    for (int ci = c.lane; ci < c.n_cells; ci += 64)
+      if (src[ci]) atomicOr(&L.dirt[ci >> 5], 1u << (ci & 31));
+    uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
+    int32_t st[NS];
+    bool ovf = false;
+    m3_stats(L, c, air, st, ovf);
+    if (ovf && c.lane == 0) atomicOr(p.err, 4);
+    if (c.lane == 0)
+      for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
+    return;
+  }
+  if constexpr (MODE == M3_GET_STATE) {
+    if (p.out_grids)
+      for (int ci = c.lane; ci < c.n_cells; ci += 64) p.out_grids[(size_t)env * c.n_cells + ci] = (gd[ci >> 5] >> (ci & 31)) & 1u;
+    if (c.lane == 0) {
+      if (p.out_pos)
+        for (int d = 0; d < 3; d++) p.out_pos[(size_t)env * 3 + d] = S->pos[d];
+      if (p.out_counters) {
+        p.out_counters[(size_t)env * 4 + 0] = S->iteration;
+        p.out_counters[(size_t)env * 4 + 1] = S->changes;
+        p.out_counters[(size_t)env * 4 + 2] = S->n_step;
+        p.out_counters[(size_t)env * 4 + 3] = S->ep_len;
+      }
+      if (p.stats_out)
+        for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = S->stats[k];
+      if (p.out_last_loss) p.out_last_loss[env] = S->last_loss;
+      if (p.out_ep_return) p.out_ep_return[env] = S->ep_return;
+    }
+    return;
+  }
+
+  // load grid + overlay
+  for (int i = c.lane; i < c.nw + 2; i += 64) {
+    L.dirt[i] = i < c.nw ? gd[i] : 0u;
+    L.over[i] = i < c.nw ? gd[M3_MAXW + i] : 0u;
+  }
+  int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
+
+  if constexpr (MODE == M3_OBSERVE) {
+    // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
+    m3_encode_obs(L, c, p, env, pos, false);
+    return;
+  }
+
+  int n_step = S->n_step, iteration = S->iteration, changes = S->changes, ep_len = S->ep_len;
+  double last_loss = S->last_loss, ep_return = S->ep_return;
+  int32_t st[NS];
+  for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+  bool ovf = false;
+
+  if constexpr (MODE == M3_RESET) {
+    if (p.mask != nullptr && p.mask[env] == 0) return;
+    if (p.init_grids) {
+      for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
+      const uint8_t *src = p.init_grids + (size_t)env * c.n_cells;
+      for (int ci = c.lane; ci < c.n_cells; ci += 64)
+        if (src[ci]) atomicOr(&L.dirt[ci >> 5], 1u << (ci & 31));
+      pos[0] = pos[1] = pos[2] = 0;
+      if (p.init_pos)
+        for (int d = 0; d < 3; d++) pos[d] = p.init_pos[(size_t)env * 3 + d];
+    } else {
+      m3_reset_rng(L, c, p, env, cpl);
+      pos[0] = pos[1] = pos[2] = 0;
+    }
+    uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
+    m3_stats(L, c, air, st, ovf);
+    n_step = iteration = changes = ep_len = 0;
+    ep_return = 0.0;
+    last_loss = get_loss<NS>(p.cfg, st);
+  } else {
+    // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
+    const int action = p.actions[env];
+    const bool bad = action < 0 || action >= 2;
+    iteration++;
+    bool change = false;
+    if (!bad) {
+      const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
+      const bool old = m3_dirt(L, ci);
+      change = old != (action != 0);
+      if (change && c.lane == 0) L.dirt[ci >> 5] ^= 1u << (ci & 31);
+      const int idx = n_step % c.n_cells;  // Q1
+      pos[0] = idx / (c.Y * c.X);
+      pos[1] = (idx / c.X) % c.Y;
+      pos[2] = idx % c.X;
+      n_step++;
+    } else if (c.lane == 0) {
+      atomicOr(p.err, 1);
+    }
+    changes += change ? 1 : 0;
+    bool done = iteration > p.cfg.max_iterations;
+    if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
+    const bool do_reset = done && p.auto_reset != 0;
+    // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
+    // the previous stats update on the already edited map
+    if (!do_reset) m3_encode_obs(L, c, p, env, pos, true);
+    if (change) {
+      uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
+      m3_stats(L, c, air, st, ovf);
+    }
+    const double loss = get_loss<NS>(p.cfg, st);
+    const double rew = loss - last_loss;
+    last_loss = loss;
+    ep_return += rew;
+    ep_len++;
+    if (c.lane == 0) {
+      if (p.reward) p.reward[env] = (float)rew;
+      if (p.done) p.done[env] = done ? 1 : 0;
+      if (p.stats_out)
+        for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
+    }
+    if (do_reset) {
+      if (c.lane == 0) {
+        S->last_ep_return = ep_return;
+        S->last_ep_len = ep_len;
+        S->n_episodes += 1;
+        for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
+      }
+      m3_reset_rng(L, c, p, env, cpl);
+      pos[0] = pos[1] = pos[2] = 0;
+      uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
+      m3_stats(L, c, air, st, ovf);
+      n_step = iteration = changes = ep_len = 0;
+      ep_return = 0.0;
+      last_loss = get_loss<NS>(p.cfg, st);
+      m3_encode_obs(L, c, p, env, pos, false);
+    }
+  }
+  if (ovf && c.lane == 0) atomicOr(p.err, 4);
+  // write back
+  for (int i = c.lane; i < c.nw; i += 64) {
+    gd[i] = L.dirt[i];
+    gd[M3_MAXW + i] = L.over[i];
+  }
+  if (c.lane == 0) {
+    S->pos[0] = pos[0];
+    S->pos[1] = pos[1];
+    S->pos[2] = pos[2];
+    S->n_step = n_step;
+    S->iteration = iteration;
+    S->changes = changes;
+    S->ep_len = ep_len;
+    S->last_loss = last_loss;
+    S->ep_return = ep_return;
+    for (int k = 0; k < NS; k++) S->stats[k] = st[k];
+  }
+}
+
+}  // namespace pcgrl

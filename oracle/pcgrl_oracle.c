@@ -508,7 +508,8 @@ static void encode_obs(const orc_engine *e, const env_t *v, uint8_t *out, int sh
     if (show_path)
       for (int k = 0; k < v->path_len; k++) {
         int x = v->path_xyz[3 * k], y = v->path_xyz[3 * k + 1], z = v->path_xyz[3 * k + 2];
-        m[(x * c->dims[1] + y) * c->dims[2] + z] = (uint8_t)e->n_tiles;
+        /* non-cubic maps: the reference would raise IndexError here; out-of-range tiles are skipped */
+        if (x < c->dims[0] && y < c->dims[1] && z < c->dims[2]) m[(x * c->dims[1] + y) * c->dims[2] + z] = (uint8_t)e->n_tiles;
       }
     for (int i = 0; i < o0; i++)
       for (int j = 0; j < o1; j++)

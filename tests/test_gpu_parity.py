@@ -101,7 +101,7 @@ def _rollout_vs_oracle(problem, rep, shape, n_envs, n_steps, seed0=100, full_eve
             st, ost = env.get_state(), orc.get_state()
             assert np.array_equal(st.grids.cpu().numpy().reshape(n_envs, -1), ost["grids"]), f"grids @ {t}"
             if rep != "wide":
-                assert np.array_equal(st.pos.cpu().numpy()[:, :2], ost["pos"][:, :2])
+                assert np.array_equal(st.pos.cpu().numpy()[:, :len(shape)], ost["pos"][:, :len(shape)])
             assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"])
             assert np.array_equal(st.changes.cpu().numpy(), ost["changes"])
             assert np.allclose(st.ep_return.cpu().numpy(), ost["ep_return"], atol=REW_TOL)
@@ -112,6 +112,70 @@ def _rollout_vs_oracle(problem, rep, shape, n_envs, n_steps, seed0=100, full_eve
     assert np.allclose(le.ep_return.cpu().numpy(), ole["ep_return"], atol=REW_TOL)
     env.check_errors()
     return n_done
+
+
+MC3D_EPISODES = sorted(glob.glob(os.path.join(GOLDEN, "episode_mc3dmaze_*.npz")))
+
+
+@pytest.mark.parametrize("path", MC3D_EPISODES, ids=[os.path.basename(p)[8:-4] for p in MC3D_EPISODES])
+def test_golden_mc3dmaze_episode_replay(path):
+    """BASELINE configs[4] against the reference's ControlWrapper(PcgrlEnv3D) trace (the reference's image wrappers
+    crash on this problem): grid, pos, stats, reward, done bit-exact; the observation is checked against a
+    re-derivation from the reference's obs dict (map with path overlay + pos)."""
+    z = np.load(path)
+    shape = tuple(int(s) for s in z["map_shape"])
+    env = _vec("minecraft_3D_maze", "narrow", shape, 1, seeds=[int(z["seed"])], auto_reset=False)
+    T, ep_len = len(z["action"]), int(z["episode_len"])
+
+    def expected_obs(overlay_map, pos):
+        m = overlay_map.reshape(shape).astype(np.int64) + 1
+        ow = tuple(2 * s for s in shape)
+        padded = np.pad(m, [(w // 2, w // 2) for w in ow], constant_values=0)
+        sl = tuple(slice(int(p), int(p) + w) for p, w in zip(pos, ow))
+        return np.eye(4, dtype=np.uint8)[padded[sl]]
+
+    def check_reset(k):
+        obs, _ = env.reset()
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["reset_grid"][k]), "reset grid (RNG stream)"
+        assert np.array_equal(st.pos[0].cpu().numpy(), z["reset_pos"][k])
+        assert np.array_equal(st.stats[0].cpu().numpy(), z["reset_stats"][k])
+        assert np.array_equal(obs[0].cpu().numpy(), expected_obs(z["reset_obs"][k], z["reset_pos"][k]))
+
+    check_reset(0)
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    for t in range(T):
+        obs, rew, done, _, info = env.step(acts[t:t + 1])
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["grid"][t]), f"grid @ {t}"
+        assert np.array_equal(st.pos[0].cpu().numpy(), z["pos"][t]), f"pos @ {t}"
+        got = info["stats"][0].cpu().numpy()
+        assert np.array_equal(got, z["stats"][t]), f"stats @ {t}: {got} vs {z['stats'][t]}"
+        assert abs(float(rew[0]) - z["reward"][t]) <= REW_TOL, f"reward @ {t}"
+        assert bool(done[0]) == bool(z["done"][t]), f"done @ {t}"
+        assert np.array_equal(obs[0].cpu().numpy(), expected_obs(z["overlay"][t], z["pos"][t])), f"obs/overlay @ {t}"
+        if t == ep_len - 1:
+            check_reset(1)
+    env.check_errors()
+
+
+def test_golden_mc3dmaze_stats_known_answers():
+    z = np.load(os.path.join(GOLDEN, "stats_mc3dmaze.npz"))
+    env = _vec("minecraft_3D_maze", "narrow", (7, 7, 7), 1, auto_reset=False)
+    got = env.stats_for_grids(torch.as_tensor(z["grids"])).cpu().numpy()
+    bad = np.nonzero((got != z["stats"]).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} grids differ, first {bad[:5]}: got {got[bad[:3]]} want {z['stats'][bad[:3]]}"
+
+
+def test_mc3dmaze_1024_envs_vs_oracle():
+    """BASELINE configs[4]: minecraft_3D_maze-narrow 7x7x7, 1024 envs/GPU, across the auto-reset (1031 steps)."""
+    n_done = _rollout_vs_oracle("minecraft_3D_maze", "narrow", (7, 7, 7), 1024, 1050, full_every=211)
+    assert n_done == 1024
+
+
+def test_mc3dmaze_other_shapes_vs_oracle():
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (5, 6, 7), 33, 300, full_every=41)
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (8, 7, 9), 17, 300, full_every=41)
 
 
 def test_binary_narrow_4096_envs_vs_oracle():
