@@ -313,7 +313,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   if (is3d)
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * M3_MAXW * sizeof(uint32_t)));  // [tile bits | path overlay bits]
   else
-    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * p.n_bits * H * sizeof(uint32_t)));
+    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * sizeof(uint32_t)));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
   CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 4));

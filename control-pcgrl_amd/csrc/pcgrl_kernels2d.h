@@ -178,21 +178,27 @@ __device__ inline int count_regions(const Grp<LPE> &g, uint32_t avail) {
   return n;
 }
 
-// helper.py:255-276 calc_longest_path + :200-210 calc_num_regions over the same passable set.
-// Per component (row-major order of first cell): level-synchronous BFS from the first cell; the last
-// non-empty frontier holds the farthest cells and np.argmax picks its first cell in row-major order.
-// The second BFS runs from all "far" cells at once (components are disjoint): the number of levels until
-// every frontier is empty is max over components of the eccentricity = the reference's final_value.
+// helper.py:255-276 calc_longest_path + :200-210 calc_num_regions over the same passable set, split into pieces:
+//
+//   component_fars(comps)      for every component of `comps` (row-major order of first cell): level-synchronous BFS
+//                              from its first cell; the last non-empty frontier holds the farthest cells and np.argmax
+//                              picks its first cell in row-major order (:265).  Isolated cells are their own "far".
+//   eccentricity(src, pass)    multi-source BFS from a set of far cells (components are disjoint): number of levels
+//                              until every frontier is empty = max over those components of the second sweep's maximum
+//                              (:266-268), plus the last non-empty frontier (marks the component(s) attaining it).
+//   flood(seed, avail)         all cells connected to `seed`.
+//
+// regions = number of far cells (one per component); path-length = eccentricity(all fars).
+//
+// INCREMENTAL UPDATE.  A step edits ONE cell, and a component's far cell depends only on that component's cells, so
+// the far cells of every component that does not touch the edited cell are unchanged.  The engine keeps two extra
+// row masks per env -- `fars` and `best` (last frontier of the sweep that produced the current path-length) -- and on a
+// change re-runs the first sweep only inside the affected component(s); the second sweep runs from the new far cells
+// only, unless a component that attained the old maximum was touched (then from all far cells).
 template <int LPE>
-__device__ inline void regions_and_longest_path(const Grp<LPE> &g, uint32_t pass, int &regions, int &path_len) {
-  uint32_t remaining = pass, fars = 0;
-  int reg = 0;
-  // isolated cells are components of their own with path length 0: count them in one shot
-  {
-    uint32_t iso = pass & ~expand(g, pass);
-    reg += (int)g.gsum((uint32_t)__popc(iso));
-    remaining &= ~iso;
-  }
+__device__ inline uint32_t component_fars(const Grp<LPE> &g, uint32_t comps) {
+  const uint32_t iso = comps & ~expand(g, comps);
+  uint32_t remaining = comps & ~iso, fars = iso;
   while (true) {
     uint64_t gb = g.gballot(remaining != 0);
     if (__ballot(gb != 0) == 0) break;
@@ -209,20 +215,72 @@ __device__ inline void regions_and_longest_path(const Grp<LPE> &g, uint32_t pass
     }
     fars |= first_rowmajor(g, last);
     remaining &= ~vis;
-    reg += gb != 0;
   }
-  uint32_t front = fars, vis = fars;
-  int len = 0;
+  return fars;
+}
+
+template <int LPE>
+__device__ inline void eccentricity(const Grp<LPE> &g, uint32_t src, uint32_t pass, int &len, uint32_t &last) {
+  uint32_t front = src, vis = src;
+  len = 0;
+  last = 0;
   while (true) {
     uint32_t nb = expand(g, front) & pass & ~vis;
-    uint64_t gn = g.gballot(nb != 0);
-    if (__ballot(gn != 0) == 0) break;
+    uint64_t bb = __ballot(nb != 0);
+    if (bb == 0) break;
+    const bool ga = g.gslice(bb) != 0;
     vis |= nb;
     front = nb;
-    len += gn != 0;
+    len += ga;
+    last = ga ? nb : last;
   }
-  regions = reg;
-  path_len = len;
+}
+
+template <int LPE>
+__device__ inline uint32_t flood(const Grp<LPE> &g, uint32_t seed, uint32_t avail) {
+  uint32_t f = hfill(seed & avail, avail);
+  while (true) {
+    uint32_t v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
+    if (__ballot(v != 0) == 0) break;
+    f = hfill(f | v, avail);
+  }
+  return f;
+}
+
+// from scratch (reset / stats_for_grids)
+template <int LPE>
+__device__ inline void binary_stats_full(const Grp<LPE> &g, uint32_t pass, int &regions, int &path_len, uint32_t &fars,
+                                         uint32_t &best) {
+  fars = component_fars(g, pass);
+  regions = (int)g.gsum((uint32_t)__popc(fars));
+  eccentricity(g, fars, pass, path_len, best);
+}
+
+// after editing the single cell `x` (row mask, 0 for groups without a change): old passable set p_old, new p_new
+template <int LPE>
+__device__ inline void binary_stats_update(const Grp<LPE> &g, uint32_t x, uint32_t p_old, uint32_t p_new, int &regions,
+                                           int &path_len, uint32_t &fars, uint32_t &best) {
+  const bool became_pass = g.gany((x & p_new) != 0);
+  // cells of the affected components in the NEW map: the merged component of x, or the old component of x minus x
+  uint32_t K = flood(g, x, became_pass ? p_new : p_old);
+  K = became_pass ? K : (K & ~x);
+  const uint32_t touched = K | x;
+  const bool hit = g.gany((best & touched) != 0);
+  const uint32_t newfars = component_fars(g, K);
+  fars = (fars & ~touched) | newfars;
+  const bool changed = g.gany(x != 0);
+  int l;
+  uint32_t b;
+  eccentricity(g, hit ? fars : newfars, p_new, l, b);
+  if (changed) {
+    regions = (int)g.gsum((uint32_t)__popc(fars));
+    if (hit || l > path_len) {
+      path_len = l;
+      best = b;
+    }
+  } else {
+    (void)g.gsum(0u);  // keep the cross-lane reduction in uniform control flow
+  }
 }
 
 // helper.py:225-240 run_dijkstra from a single source, reduced to "distance to the first target cell":
@@ -261,19 +319,23 @@ struct ProbTraits;
 template <>
 struct ProbTraits<PCGRL_PROB_BINARY> {
   static constexpr int NT = 2, NB = 1, NS = 2;
+  static constexpr int NAUX = 2;  // fars, best (incremental path-length state)
 };
 template <>
 struct ProbTraits<PCGRL_PROB_ZELDA> {
   static constexpr int NT = 8, NB = 3, NS = 7;
+  static constexpr int NAUX = 0;
 };
 template <>
 struct ProbTraits<PCGRL_PROB_SOKOBAN> {
   static constexpr int NT = 5, NB = 3, NS = 7;
+  static constexpr int NAUX = 0;
 };
 
 template <>
 struct ProbTraits<PCGRL_PROB_MC3DMAZE> {
   static constexpr int NT = 2, NB = 1, NS = 3;
+  static constexpr int NAUX = 0;
 };
 
 template <int LPE>
@@ -281,15 +343,20 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
 
 template <int PROB, int LPE>
-__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, const uint32_t *b,
+__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, uint32_t *b,
                                      uint32_t colmask, int32_t *st) {
   if constexpr (PROB == PCGRL_PROB_BINARY) {
-    // binary_prob.py:152-158: regions and path-length over "empty" (tile 0)
+    // binary_prob.py:152-158: regions and path-length over "empty" (tile 0); b[1], b[2] receive fars / best
     uint32_t pass = active ? (~b[0] & colmask) : 0u;
     int reg, len;
-    regions_and_longest_path(g, pass, reg, len);
+    uint32_t fars, best;
+    binary_stats_full(g, pass, reg, len, fars, best);
     st[0] = reg;
     st[1] = len;
+    if (active) {
+      b[1] = fars;
+      b[2] = best;
+    }
   } else if constexpr (PROB == PCGRL_PROB_ZELDA) {
     // zelda_ctrl_prob.py:90-168.  ids: 0 empty 1 solid 2 player 3 key 4 door 5 bat 6 scorpion 7 spider
     uint32_t cm = active ? colmask : 0u;
@@ -548,20 +615,21 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-template <int NB>
+constexpr int ROW_WORDS = 3;  // words per map row in HBM: tile bit-planes (1 or 3) [+ fars, best for binary]
+template <int N>
 __device__ inline void load_planes(const Params &p, int env, int row, bool ok, uint32_t *b) {
   const uint32_t *pl = (const uint32_t *)p.planes;
   const int H = p.cfg.dims[0];
 #pragma unroll
-  for (int k = 0; k < NB; k++) b[k] = ok ? pl[((size_t)env * NB + k) * H + row] : 0u;
+  for (int k = 0; k < N; k++) b[k] = ok ? pl[((size_t)env * ROW_WORDS + k) * H + row] : 0u;
 }
-template <int NB>
+template <int N>
 __device__ inline void store_planes(const Params &p, int env, int row, bool ok, const uint32_t *b) {
   uint32_t *pl = (uint32_t *)p.planes;
   const int H = p.cfg.dims[0];
   if (ok) {
 #pragma unroll
-    for (int k = 0; k < NB; k++) pl[((size_t)env * NB + k) * H + row] = b[k];
+    for (int k = 0; k < N; k++) pl[((size_t)env * ROW_WORDS + k) * H + row] = b[k];
   }
 }
 
@@ -625,6 +693,7 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
 template <int PROB, int LPE, bool FAST>
 __global__ __launch_bounds__(128) void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
+  constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   Grp<LPE> g;
   g.init();
@@ -637,14 +706,18 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
   const int e = active ? env : 0;
 
-  uint32_t b[NB];
-  load_planes<NB>(p, e, g.row, rowok, b);
+  uint32_t b[NW];
+  if (observer)
+    load_planes<NB>(p, e, g.row, rowok, b);
+  else
+    load_planes<NW>(p, e, g.row, rowok, b);
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   const int action = active ? p.actions[e] : 0;
   // both waves have read the old state before wave 0 may overwrite it
   if (p.obs != nullptr) __syncthreads();
+  const uint32_t tile0_old = b[0];
 
   // envs/pcgrl_env.py:267-342
   bool bad = false;
@@ -668,11 +741,25 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
   if (bad && g.row == 0 && active) atomicOr(p.err, 1);
   if (__ballot(change) != 0) {
-    int32_t ns[NS];
-    compute_stats<PROB, LPE>(g, p, e, change, b, colmask, ns);
-    if (change) {
+    if constexpr (PROB == PCGRL_PROB_BINARY) {
+      // incremental: only the component(s) touching the edited cell are re-swept
+      const uint32_t x = change ? (tile0_old ^ b[0]) & colmask : 0u;
+      int reg = st[0], len = st[1];
+      uint32_t fars = b[1], best = b[2];
+      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
+      if (change) {
+        st[0] = reg;
+        st[1] = len;
+        b[1] = fars;
+        b[2] = best;
+      }
+    } else {
+      int32_t ns[NS];
+      compute_stats<PROB, LPE>(g, p, e, change, b, colmask, ns);
+      if (change) {
 #pragma unroll
-      for (int k = 0; k < NS; k++) st[k] = ns[k];
+        for (int k = 0; k < NS; k++) st[k] = ns[k];
+      }
     }
   }
   // control_wrappers.py:216-244
@@ -712,7 +799,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
     }
   }
   // write back state
-  if (change || do_reset) store_planes<NB>(p, e, g.row, rowok, b);
+  if (change || do_reset) store_planes<NW>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
@@ -740,11 +827,12 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   const bool active = inb && (p.mask == nullptr || p.mask[e] != 0);
   const bool rowok = active && g.row < H;
   const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
+  constexpr int NW = NB + ProbTraits<PROB>::NAUX;
   EnvState *S = &p.st[e];
-  uint32_t b[NB];
+  uint32_t b[NW];
   int pos[2] = {0, 0};
 #pragma unroll
-  for (int k = 0; k < NB; k++) b[k] = 0;
+  for (int k = 0; k < NW; k++) b[k] = 0;
   if (p.init_grids) {  // inject: bytes -> planes (envs/pcgrl_ctrl_env.py:12-14 set_map)
     if (rowok) {
       const uint8_t *src = p.init_grids + ((size_t)e * H + g.row) * W;
@@ -763,7 +851,7 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   }
   int32_t st[NS];
   compute_stats<PROB, LPE>(g, p, e, active, b, colmask, st);
-  store_planes<NB>(p, e, g.row, rowok, b);
+  store_planes<NW>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
@@ -855,9 +943,9 @@ __global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
   const int e = active ? env : 0;
   const bool rowok = active && g.row < H;
   const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
-  uint32_t b[NB];
+  uint32_t b[NB + ProbTraits<PROB>::NAUX];
 #pragma unroll
-  for (int k = 0; k < NB; k++) b[k] = 0;
+  for (int k = 0; k < NB + ProbTraits<PROB>::NAUX; k++) b[k] = 0;
   if (rowok) {
     const uint8_t *src = p.init_grids + ((size_t)e * H + g.row) * W;
     for (int x = 0; x < W; x++) {

@@ -39,7 +39,7 @@ def main():
         env = VecPcgrlEnv(problem, rep, (16, 16), n, device=dev, seeds=np.arange(n), auto_reset=True)
         env.reset()
         g = torch.Generator(device=dev).manual_seed(1)
-        pool = torch.randint(0, env.num_actions, (256, n), generator=g, device=dev, dtype=torch.int32)
+        pool = torch.randint(0, env.num_actions, (1021, n), generator=g, device=dev, dtype=torch.int32)
         stream = torch.cuda.current_stream(dev)
         sp = stream.cuda_stream
         L, h = env._L, env._h
@@ -47,11 +47,11 @@ def main():
 
         def full():
             k[0] += 1
-            env.step_raw(pool[k[0] & 255].data_ptr(), sp)
+            env.step_raw(pool[k[0] % 1021].data_ptr(), sp)
 
         def noobs():
             k[0] += 1
-            L.pcgrl_step(h, pool[k[0] & 255].data_ptr(), 1, None, env._ptrs[1], env._ptrs[2], env._ptrs[3], sp)
+            L.pcgrl_step(h, pool[k[0] % 1021].data_ptr(), 1, None, env._ptrs[1], env._ptrs[2], env._ptrs[3], sp)
 
         def obs_only():
             L.pcgrl_observe(h, env._ptrs[0], sp)
