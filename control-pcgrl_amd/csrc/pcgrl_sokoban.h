@@ -19,7 +19,7 @@
 
 namespace pcgrl {
 
-constexpr int SK_MAXC = 32;      // crates (= targets) the device solver supports
+constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
 constexpr int SK_MAXDIM = 34;    // bordered level side (W+2, H+2 <= 34)
 constexpr int SK_VCAP = 1 << 15; // visited table slots (>= 2 x iterations per stage)
 
@@ -73,12 +73,12 @@ __device__ inline bool sk_win(const SokoCtx &c, const uint8_t *cr) {  // engine.
   return true;
 }
 __device__ inline int sk_heuristic(const SokoCtx &c, const uint8_t *cr) {  // engine.py:282-296
-  uint32_t used = 0;  // targets already matched (the reference deletes them from a list: order is preserved)
+  uint32_t used[SK_MAXC / 32] = {0};  // targets already matched (the reference deletes them from a list: order is preserved)
   int distance = 0;
   for (int k = 0; k < c.ncr; k++) {
     int best = c.lv->w + c.lv->h, match = -1, first_free = -1;
     for (int i = 0; i < c.lv->ntg; i++) {
-      if ((used >> i) & 1u) continue;
+      if ((used[i >> 5] >> (i & 31)) & 1u) continue;
       if (first_free < 0) first_free = i;
       int d = abs((int)cr[2 * k] - (int)c.lv->tx[i]) + abs((int)cr[2 * k + 1] - (int)c.lv->ty[i]);
       if (best > d) {
@@ -88,7 +88,7 @@ __device__ inline int sk_heuristic(const SokoCtx &c, const uint8_t *cr) {  // en
     }
     if (match < 0) match = first_free;  // bestMatch = 0 default: first remaining target
     distance += abs((int)c.lv->tx[match] - (int)cr[2 * k]) + abs((int)c.lv->ty[match] - (int)cr[2 * k + 1]);
-    used |= 1u << match;
+    used[match >> 5] |= 1u << (match & 31);
   }
   return distance;
 }

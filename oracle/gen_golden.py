@@ -399,6 +399,15 @@ def gen_stats_sokoban_solver(n=70):
         for (y, x), t in zip(sel, [P] + [T] * k):
             g[y, x] = t
         grids.append(g)
+    # dense levels as random resets produce them (tile probabilities are themselves random): one player, 40..127
+    # crate/target pairs, no walls -> one region, solver precondition met, almost every move blocked
+    for k in (40, 62, 89, 105, 120, 127):
+        g = np.full(256, E, np.uint8)
+        cells = rng.permutation(256)
+        g[cells[0]] = P
+        g[cells[1:1 + k]] = C
+        g[cells[1 + k:1 + 2 * k]] = T
+        grids.append(g.reshape(16, 16))
     grids = np.array(grids, np.uint8)
     stats = np.array([_get_stats(core, "sokoban", g) for g in grids], np.int32)
     np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver.npz"), grids=grids, stats=stats,
