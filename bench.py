@@ -25,7 +25,12 @@ sys.path.insert(0, ROOT)
 # reward/done/stats/pos out)
 ALGO_BYTES = {"binary-narrow": 4 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               "zelda-turtle": 4 + 257 + 32 * 32 * 9 + (4 + 1 + 28 + 2),
-              "sokoban-wide": 4 + 257 + 16 * 16 * 5 + (4 + 1 + 28 + 0)}
+              "sokoban-wide": 4 + 257 + 16 * 16 * 5 + (4 + 1 + 28 + 0),
+              "minecraft_3D_maze-narrow": 4 + 344 + 14 ** 3 * 4 + (4 + 1 + 12 + 3)}
+# BASELINE.json configs: (problem, representation, map_shape, envs per GPU)
+WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtle": ("zelda", "turtle", (16, 16), 4096),
+             "sokoban-wide": ("sokoban", "wide", (16, 16), 2048),
+             "minecraft_3D_maze-narrow": ("minecraft_3D_maze", "narrow", (7, 7, 7), 1024)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -34,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's)")
     ap.add_argument("--workload", default="binary-narrow", choices=sorted(ALGO_BYTES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -56,10 +61,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    problem, rep = args.workload.split("-")
-    N, K, W = args.envs, args.steps, args.warmup
+    problem, rep, shape, default_envs = WORKLOADS[args.workload]
+    N, K, W = (args.envs or default_envs), args.steps, args.warmup
     total_envs = N * world
-    env = VecPcgrlEnv(problem, rep, (16, 16), N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world),
+    env = VecPcgrlEnv(problem, rep, shape, N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world),
                       auto_reset=True)
     env.reset()
     reducer = EpisodeStatsReducer(env.n_stats, dev)
@@ -116,24 +121,39 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload} 16x16, {N} envs/GPU, uniform random actions, auto-reset, "
+            "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, uniform random actions, auto-reset, "
                                    "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(args.workload, N),
                          "kernel": "pcgrl::step_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": kernel_ms * 1e3},
             "episodes": ep,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, rep, N, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(problem, rep, n_envs, target_s):
+def profiled_traffic(workload, n_envs):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*_summary.json: WRITE_SIZE + 2 x FETCH_SIZE); None when not profiled."""
+    if workload != "binary-narrow" or n_envs != 4096:
+        return None
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            best = json.load(open(f))["hbm_traffic_per_launch"]["traffic_bytes"]
+        except Exception:
+            pass
+    return best
+
+
+def cpu_baseline(problem, rep, shape, n_envs, target_s):
     """The oracle (a C port of the reference's algorithm, OpenMP over envs) on the host cores of this box:
     same workload, bounded sample."""
     import numpy as np
@@ -153,7 +173,7 @@ def cpu_baseline(problem, rep, n_envs, target_s):
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
     def rate(threads, seconds):
-        orc = po.OracleVecEnv(problem, rep, (16, 16), n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads)
+        orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads)
         orc.reset()
         for k in range(2):
             orc.step(acts[k], auto_reset=True)
@@ -168,7 +188,8 @@ def cpu_baseline(problem, rep, n_envs, target_s):
         return n_envs * steps / dt, steps, dt
 
     rng = np.random.default_rng(1234)
-    n_act = {"narrow": po.N_TILES[problem], "turtle": po.N_TILES[problem] + 4, "wide": 256 * po.N_TILES[problem]}[rep]
+    n_act = {"narrow": po.N_TILES[problem], "turtle": po.N_TILES[problem] + 4,
+             "wide": int(np.prod(shape)) * po.N_TILES[problem]}[rep]
     acts = rng.integers(0, n_act, size=(64, n_envs), dtype=np.int32)
     # pick the thread count that this box actually rewards (short calibration), then time the sample
     cands = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)})
