@@ -55,11 +55,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test hooks (a 1-GPU box can still exercise the multi-process path): all ranks on one device, gloo collectives
+    if os.environ.get("PCGRL_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("PCGRL_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     problem, rep, shape, default_envs = WORKLOADS[args.workload]
     N, K, W = (args.envs or default_envs), args.steps, args.warmup
@@ -86,7 +94,7 @@ def main():
     run(W)
     # warm the reporting path too (first use loads torch's reduction kernels), then start from clean accumulators
     reducer.update_from_env(env)
-    reducer.reduce()
+    reducer.reduce(device=coll_dev)
     reducer.reset()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -99,7 +107,7 @@ def main():
     ev1.record(stream)
     # the path's only exchange: episodic-return reduction (one small all-reduce over RCCL when world > 1)
     reducer.update_from_env(env)
-    ep = reducer.reduce()
+    ep = reducer.reduce(device=coll_dev)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -108,7 +116,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
     env.check_errors()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -127,7 +135,7 @@ def main():
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(args.workload, N),
-                         "kernel": "pcgrl::step_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": kernel_ms * 1e3},
             "episodes": ep,
         }

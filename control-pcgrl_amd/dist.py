@@ -45,9 +45,12 @@ class EpisodeStatsReducer:
         self._seen = le.n_episodes.clone()
         self.update(new, le.ep_return, le.ep_len, le.final_stats)
 
-    def reduce(self, group=None):
-        """Returns dict of global means; collective over `group` when torch.distributed is initialised."""
+    def reduce(self, group=None, device=None):
+        """Returns dict of global means; collective over `group` when torch.distributed is initialised.
+        `device`: where the all-reduce runs (default: the accumulator's device; "cpu" for a gloo group)."""
         v = self.acc.clone()
+        if device is not None:
+            v = v.to(device)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
         n = max(float(v[2].item()), 1.0)
