@@ -41,6 +41,7 @@ SYMBOLS = {
     "pcgrl_stats_for_grids": (C.c_int, [C.POINTER(PcgrlConfig), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p]),
     "pcgrl_poll_error": (C.c_int, [C.c_void_p]),
+    "pcgrl_debug_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "pcgrl_last_error": (C.c_char_p, []),
     "pcgrl_version": (C.c_char_p, []),
 }

@@ -316,7 +316,8 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * sizeof(uint32_t)));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
-  CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 4));
+  // [0..3] error flags; from int 64 on: per-workgroup phase-timing accumulators (PCGRL_PHASE_TIMING builds)
+  CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 64 + sizeof(uint64_t) * 8 * (size_t)(n_envs + 64)));
   std::vector<JumpEntry> jt = is3d ? make_jump_table(64, e->cpl, p.n_cells) : make_jump_table(H, W);
   JumpEntry *djt = nullptr;
   CREATE_CHK(dalloc((void **)&djt, jt.size() * sizeof(JumpEntry)));
@@ -458,6 +459,15 @@ int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_g
   p.init_grids = d_grids;
   p.stats_out = d_stats;
   HIPCHK(launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_debug_counters(pcgrl_handle h, uint64_t *out, int32_t n) {
+  if (!h || !out || n < 1 || n > 8 * (h->p.n_envs + 64)) return fail(PCGRL_EINVAL, "pcgrl_debug_counters: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->p.err + 64, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(h->p.err + 64, 0, sizeof(uint64_t) * n));
   return PCGRL_OK;
 }
 

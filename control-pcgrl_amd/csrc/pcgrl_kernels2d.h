@@ -24,6 +24,38 @@
 
 namespace pcgrl {
 
+// Development aid: -DPCGRL_PHASE_TIMING accumulates s_memtime deltas of the simulate wave's phases into p.err[8..]
+// (read back by tools/phase_timing.py).  Not compiled into the shipped library.
+#ifdef PCGRL_PHASE_TIMING
+#define PHASE_DECL() uint32_t _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t _t_prev = __builtin_readcyclecounter(); uint64_t _w0 = wall_clock64()
+#define PHASE_ARG , uint32_t *_ph, uint64_t &_t_prev
+#define PHASE_PASS , _ph, _t_prev
+#define PHASE_MARK(i)                                  \
+  do {                                                 \
+    uint64_t _t = __builtin_readcyclecounter();        \
+    _ph[i] += (uint32_t)(_t - _t_prev);                \
+    _t_prev = _t;                                      \
+  } while (0)
+#define PHASE_FLUSH()                                                                              \
+  do {                                                                                             \
+    _ph[7] = (uint32_t)(wall_clock64() - _w0);                                                     \
+    if (threadIdx.x == 0)                                                                          \
+      for (int _i = 0; _i < 8; _i++) ((unsigned long long *)(p.err + 64))[blockIdx.x * 8 + _i] += _ph[_i]; \
+  } while (0)
+#else
+#define PHASE_DECL() \
+  do {               \
+  } while (0)
+#define PHASE_ARG
+#define PHASE_PASS
+#define PHASE_MARK(i) \
+  do {                \
+  } while (0)
+#define PHASE_FLUSH() \
+  do {                \
+  } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ PCG64
 struct U128 {
   uint64_t hi, lo;
@@ -259,19 +291,22 @@ __device__ inline void binary_stats_full(const Grp<LPE> &g, uint32_t pass, int &
 // after editing the single cell `x` (row mask, 0 for groups without a change): old passable set p_old, new p_new
 template <int LPE>
 __device__ inline void binary_stats_update(const Grp<LPE> &g, uint32_t x, uint32_t p_old, uint32_t p_new, int &regions,
-                                           int &path_len, uint32_t &fars, uint32_t &best) {
+                                           int &path_len, uint32_t &fars, uint32_t &best PHASE_ARG) {
   const bool became_pass = g.gany((x & p_new) != 0);
   // cells of the affected components in the NEW map: the merged component of x, or the old component of x minus x
   uint32_t K = flood(g, x, became_pass ? p_new : p_old);
   K = became_pass ? K : (K & ~x);
   const uint32_t touched = K | x;
   const bool hit = g.gany((best & touched) != 0);
+  PHASE_MARK(3);  // flood
   const uint32_t newfars = component_fars(g, K);
+  PHASE_MARK(4);  // first sweeps
   fars = (fars & ~touched) | newfars;
   const bool changed = g.gany(x != 0);
   int l;
   uint32_t b;
   eccentricity(g, hit ? fars : newfars, p_new, l, b);
+  PHASE_MARK(5);  // second sweep
   if (changed) {
     regions = (int)g.gsum((uint32_t)__popc(fars));
     if (hit || l > path_len) {
@@ -494,6 +529,17 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
 // its map row into it, and streams it out with 16-byte stores.
 __device__ inline int lds_row_stride(int row_bytes) { return row_bytes + 16; }
 
+// 16-byte observation store, write-through (sc1): the line leaves the XCD's L2 while the kernel is still running
+// instead of being written back at the kernel boundary (MI355X_MICROARCH.md "boundary" / "publish-large" rows: a
+// launch that leaves ~13 MB dirty pays ~3 us at its end).  Nothing in the kernel reads these bytes again.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ inline void store_obs16(void *dst, uint4 v) {
+  u32x4_t w = {v.x, v.y, v.z, v.w};
+  // the trailing s_nop covers the gfx9 hazard "VALU overwrites the data VGPRs of a >64-bit VMEM store" (2 wait states),
+  // which the compiler's hazard recognizer cannot see through an asm statement
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
+}
+
 // 16-byte chunk q of the all-out-of-bounds row pattern (byte k is 1 iff k % C == 0)
 template <int C>
 __device__ inline uint4 oob_chunk(int q) {
@@ -543,7 +589,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     if (active && g.row < H) {
       for (int x = 0; x < W; x++) row[x * NT + tile_at<NB>(b, x)] = 1;
       uint8_t *dst = p.obs + ((size_t)env * H + g.row) * row_bytes;
-      for (int q = 0; q < chunks; q++) *(uint4 *)(dst + q * 16) = *(uint4 *)(row + q * 16);
+      for (int q = 0; q < chunks; q++) store_obs16(dst + q * 16, *(uint4 *)(row + q * 16));
     }
     return;
   }
@@ -601,14 +647,14 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
         int i = k / FCH, q = k - i * FCH;
         int m = i + top;
         const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
-        *(uint4 *)(base + (size_t)k * 16) = *(const uint4 *)src;
+        store_obs16(base + (size_t)k * 16, *(const uint4 *)src);
       }
     } else {
       for (int k = g.row; k < total; k += LPE) {
         int i = k / CH, q = k - i * CH;
         int m = i + top;
         const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
-        *(uint4 *)(base + (size_t)k * 16) = *(const uint4 *)src;
+        store_obs16(base + (size_t)k * 16, *(const uint4 *)src);
       }
     }
   }
@@ -699,6 +745,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   g.init();
   const bool observer = threadIdx.x >= 64;  // wave-uniform
   if (observer && p.obs == nullptr) return;  // (no barrier below is reached by wave 0 in that case either)
+  PHASE_DECL();
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   const int env = blockIdx.x * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
@@ -717,6 +764,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   const int action = active ? p.actions[e] : 0;
   // both waves have read the old state before wave 0 may overwrite it
   if (p.obs != nullptr) __syncthreads();
+  PHASE_MARK(0);  // loads + barrier
   const uint32_t tile0_old = b[0];
 
   // envs/pcgrl_env.py:267-342
@@ -740,13 +788,14 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
 #pragma unroll
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
   if (bad && g.row == 0 && active) atomicOr(p.err, 1);
+  PHASE_MARK(1);  // action + second state loads
   if (__ballot(change) != 0) {
     if constexpr (PROB == PCGRL_PROB_BINARY) {
       // incremental: only the component(s) touching the edited cell are re-swept
       const uint32_t x = change ? (tile0_old ^ b[0]) & colmask : 0u;
       int reg = st[0], len = st[1];
       uint32_t fars = b[1], best = b[2];
-      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
+      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS);
       if (change) {
         st[0] = reg;
         st[1] = len;
@@ -762,6 +811,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
       }
     }
   }
+  PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
   double loss = get_loss<NS>(p.cfg, st);
   double rew = loss - last_loss;
@@ -812,6 +862,8 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
 #pragma unroll
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
   }
+  PHASE_MARK(6);  // loss, outputs, write-back
+  PHASE_FLUSH();
 }
 
 template <int PROB, int LPE>

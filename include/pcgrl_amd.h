@@ -109,6 +109,9 @@ int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_g
 /* Synchronises the device and returns PCGRL_EACTION if any kernel saw an out-of-range action since the
  * last poll (the reference raises IndexError there), PCGRL_EHIP on a pending HIP error, else 0. */
 int pcgrl_poll_error(pcgrl_handle h);
+/* Development aid: copies n 64-bit device counters to `out` (HOST pointer) and zeroes them.  They are only written by
+ * a library built with -DPCGRL_PHASE_TIMING (tools/phase_timing.py); otherwise all zero. */
+int pcgrl_debug_counters(pcgrl_handle h, uint64_t *out, int32_t n);
 const char *pcgrl_last_error(void);
 const char *pcgrl_version(void);
 

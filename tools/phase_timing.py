@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the simulate wave (shader-clock cycles, summed over workgroups' lane 0) using a library built
+with -DPCGRL_PHASE_TIMING.  Build here (hipcc cross-compiles):  python tools/phase_timing.py --build
+then on the GPU box:                                            python tools/phase_timing.py"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from control_pcgrl_amd import _lib
+
+TIMING_LIB = os.path.join(_lib.CSRC, "libpcgrl_amd_timing.so")
+NAMES = ["loads+barrier", "action+state", "stats refresh (total)", "  flood", "  first sweeps", "  second sweep",
+         "loss/outputs/write-back"]
+
+if "--build" in sys.argv:
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                    "-shared", "-DPCGRL_PHASE_TIMING", "-o", TIMING_LIB, os.path.join(_lib.CSRC, "pcgrl_engine.hip")],
+                   check=True)
+    print("built", TIMING_LIB)
+    sys.exit(0)
+
+import numpy as np
+import torch
+
+_lib.LIB_PATH = TIMING_LIB
+from control_pcgrl_amd import VecPcgrlEnv
+
+n, iters = 4096, 2000
+env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+env.reset()
+g = torch.Generator(device="cuda").manual_seed(1)
+pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
+sp = torch.cuda.current_stream().cuda_stream
+for k in range(300):
+    env.step_raw(pool[k % 1021].data_ptr(), sp)
+blocks = n // 4
+out = np.zeros(8 * blocks, np.uint64)
+env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
+for k in range(iters):
+    env.step_raw(pool[k % 1021].data_ptr(), sp)
+env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
+out = out.reshape(blocks, 8).astype(np.float64).sum(0)
+tot = 0
+for i, nm in enumerate(NAMES):
+    cyc = float(out[i]) / (iters * blocks)
+    if not nm.startswith("  "):
+        tot += cyc
+    print(f"{nm:28s} {cyc:9.0f} cycles/launch/wave")
+print(f"{'sum of top-level phases':28s} {tot:9.0f}")
+wall = float(out[7]) / (iters * blocks)  # 100 MHz constant clock ticks
+print(f"simulate wave lifetime: {wall * 10:.0f} ns  => effective shader clock {sum(out[:7]) / (iters * blocks) / (wall * 10):.2f} GHz")
