@@ -29,7 +29,7 @@ constexpr int M3_NS = 3;
 
 struct M3Lds {
   uint4 ent[M3_ENT_CAP];        // x | y<<8 | z<<16 | kind<<24 ; len | njump<<16 ; parent ; unused
-  uint16_t best[M3_MAXCELLS];   // per cell: accepted entry id (the `paths` dict), 0xFFFF = none
+  uint32_t best[M3_MAXCELLS];   // per cell: len << 16 | accepted entry id (the `paths` dict), 0xFFFFFFFF = none
   uint16_t order[M3_MAXCELLS];  // cells in first-insertion order
   uint32_t dirt[M3_MAXW + 2];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
   uint32_t pathm[M3_MAXW + 2];  // tiles of the best path
@@ -99,7 +99,7 @@ __device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z *
 // One search of helper_3D.run_dijkstra from (sx,sy,sz).  Uniform over the wave; returns number of entries.
 // On overflow of the LDS queue sets *overflow.
 __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, bool &overflow) {
-  for (int i = c.lane; i < c.n_cells; i += 64) L.best[i] = 0xFFFF;
+  for (int i = c.lane; i < c.n_cells; i += 64) L.best[i] = 0xFFFFFFFFu;
   if (c.lane == 0) L.ent[0] = make_uint4((uint32_t)sx | ((uint32_t)sy << 8) | ((uint32_t)sz << 16) | ((uint32_t)M3_ROOT << 24), 1u, 0xFFFFFFFFu, 0u);
   int head = 0, tail = 1;
   n_order = 0;
@@ -110,9 +110,9 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255;
     const int len = e.y & 0xFFFF, nj = e.y >> 16;
     const int ci = m3_cell(c, x, y, z);
-    const int b = L.best[ci];
+    const uint32_t b = L.best[ci];
     bool accept = true;
-    if (b != 0xFFFF && (int)(L.ent[b].y & 0xFFFF) <= len) accept = false;      // :437-440
+    if (b != 0xFFFFFFFFu && (int)(b >> 16) <= len) accept = false;             // :437-440
     const uint32_t cc = L.col[y * c.X + x];
     if (accept && (z + 1 == c.Z || !((cc >> (z + 1)) & 1u))) accept = false;    // :443-445 no head-room
     if (!accept) {
@@ -120,10 +120,10 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
       continue;
     }
     if (c.lane == 0) {
-      if (b == 0xFFFF) L.order[n_order] = (uint16_t)ci;
-      L.best[ci] = (uint16_t)head;
+      if (b == 0xFFFFFFFFu) L.order[n_order] = (uint16_t)ci;
+      L.best[ci] = ((uint32_t)len << 16) | (uint32_t)head;
     }
-    if (b == 0xFFFF) n_order++;
+    if (b == 0xFFFFFFFFu) n_order++;
     // successors: lane d < 4 evaluates direction d (helper_3D.py:214-319)
     bool ok = false;
     int tx = 0, ty = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
@@ -152,6 +152,16 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
         }
       }
     }
+    // Push-time pruning (exact): an entry whose cell already holds a path that is not longer, or whose cell has no
+    // head-room, is a no-op when popped (:437-445; best lengths only ever decrease), so it is never queued.
+    if (ok) {
+      const uint32_t ct = L.col[ty * c.X + tx];
+      if (tz + 1 == c.Z || !((ct >> (tz + 1)) & 1u)) ok = false;
+      if (ok) {
+        const uint32_t bt = L.best[m3_cell(c, tx, ty, tz)];
+        if (bt != 0xFFFFFFFFu && (int)(bt >> 16) <= len + add) ok = false;
+      }
+    }
     const uint64_t okb = __ballot(ok);
     const int npush = __popcll(okb);
     if (tail + npush > M3_ENT_CAP) {
@@ -173,7 +183,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
 __device__ inline int m3_farthest(const M3Lds &L, const M3Ctx &c, int n_order, int &entry) {
   uint32_t key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
   for (int k = c.lane; k < n_order; k += 64) {
-    uint32_t len = L.ent[L.best[L.order[k]]].y & 0xFFFF;
+    uint32_t len = L.best[L.order[k]] >> 16;
     uint32_t kk = (len << 16) | (uint32_t)(0xFFFF - k);
     key = kk > key ? kk : key;
   }
@@ -184,13 +194,13 @@ __device__ inline int m3_farthest(const M3Lds &L, const M3Ctx &c, int n_order, i
   }
   const int k = 0xFFFF - (int)(key & 0xFFFF);
   const int cell = L.order[k];
-  entry = L.best[cell];
+  entry = (int)(L.best[cell] & 0xFFFFu);
   return cell;
 }
 
 // helper_3D.calc_longest_path + remove_stacked_path_tiles + minecraft_3D_maze_prob.get_stats
 // air: this lane's plane (lanes < Z).  Results uniform over the wave.  L.over receives the new overlay mask.
-__device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t *st, bool &overflow) {
+__device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t *st, bool &overflow PHASE_ARG) {
   // per-(y,x) column masks for the move rules
   if (c.lane < 64) {
     for (int q = c.lane; q < c.Y * c.X; q += 64) {
@@ -199,7 +209,9 @@ __device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t 
       L.col[q] = (uint8_t)m;
     }
   }
+  PHASE_MARK(2);  // column masks
   st[0] = m3_regions(c, air);
+  PHASE_MARK(3);  // regions
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
   const uint64_t above = dpp64_down(air), below = dpp64_up(air);
   uint64_t cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : 0ull;
@@ -268,6 +280,7 @@ __device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t 
       }
     }
   }
+  PHASE_MARK(4);  // path searches
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
   // path tile (x,y,z) is drawn at array index [x][y][z]
   const int pbits = c.Y * c.X;
@@ -285,6 +298,7 @@ __device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t 
   }
   st[1] = final_value;
   st[2] = n_jump;
+  PHASE_MARK(5);  // overlay post-processing
 }
 
 // observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay
@@ -294,22 +308,35 @@ __device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Param
   const int total = o0 * o1 * o2, chunks = total >> 2;
   uint4 *dst = (uint4 *)(p.obs + (size_t)env * total * 4);
   const int t0 = pos[0] - o0 / 2, t1 = pos[1] - o1 / 2, t2 = pos[2] - o2 / 2;
+  const int o12 = o1 * o2;
+  const float inv12 = 1.0f / (float)o12, inv2 = 1.0f / (float)o2;
   for (int ch = c.lane; ch < chunks; ch += 64) {
     uint32_t w[4];
+    // (i, j, k) of the chunk's first cell: floor((q + 0.5) / d) is exact in fp32 for these sizes (q < 2^20)
+    const int q0 = ch * 4;
+    int i = (int)(((float)q0 + 0.5f) * inv12);
+    const int r = q0 - i * o12;
+    int j = (int)(((float)r + 0.5f) * inv2);
+    int k = r - j * o2;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      int q = ch * 4 + t;
-      int k = q % o2, j = (q / o2) % o1, i = q / (o2 * o1);
-      int a = t0 + i, b = t1 + j, d = t2 + k;
+      const int a = t0 + i, b = t1 + j, d = t2 + k;
       int v = 0;
       if ((unsigned)a < (unsigned)c.Z && (unsigned)b < (unsigned)c.Y && (unsigned)d < (unsigned)c.X) {
-        int ci = (a * c.Y + b) * c.X + d;
+        const int ci = (a * c.Y + b) * c.X + d;
         v = 1 + (int)m3_dirt(L, ci);
         if (show_path && ((L.over[ci >> 5] >> (ci & 31)) & 1u)) v = 3;
       }
       w[t] = 1u << (8 * v);
+      if (++k == o2) {  // raster order carry
+        k = 0;
+        if (++j == o1) {
+          j = 0;
+          ++i;
+        }
+      }
     }
-    dst[ch] = make_uint4(w[0], w[1], w[2], w[3]);
+    store_obs16(dst + ch, make_uint4(w[0], w[1], w[2], w[3]));
   }
 }
 
@@ -362,6 +389,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
   c.nw = (c.n_cells + 31) >> 5;
   const int env = blockIdx.x;
   constexpr int NS = M3_NS;
+  PHASE_DECL();
   uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * M3_MAXW;  // [dirt words | overlay words]
   EnvState *S = &p.st[env];
 
@@ -373,7 +401,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
     int32_t st[NS];
     bool ovf = false;
-    m3_stats(L, c, air, st, ovf);
+    m3_stats(L, c, air, st, ovf PHASE_PASS);
     if (ovf && c.lane == 0) atomicOr(p.err, 4);
     if (c.lane == 0)
       for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
@@ -433,7 +461,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       pos[0] = pos[1] = pos[2] = 0;
     }
     uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-    m3_stats(L, c, air, st, ovf);
+    m3_stats(L, c, air, st, ovf PHASE_PASS);
     n_step = iteration = changes = ep_len = 0;
     ep_return = 0.0;
     last_loss = get_loss<NS>(p.cfg, st);
@@ -462,10 +490,12 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     const bool do_reset = done && p.auto_reset != 0;
     // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
     // the previous stats update on the already edited map
+    PHASE_MARK(0);  // loads + action
     if (!do_reset) m3_encode_obs(L, c, p, env, pos, true);
+    PHASE_MARK(1);  // observation
     if (change) {
       uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-      m3_stats(L, c, air, st, ovf);
+      m3_stats(L, c, air, st, ovf PHASE_PASS);
     }
     const double loss = get_loss<NS>(p.cfg, st);
     const double rew = loss - last_loss;
@@ -488,7 +518,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       m3_reset_rng(L, c, p, env, cpl);
       pos[0] = pos[1] = pos[2] = 0;
       uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-      m3_stats(L, c, air, st, ovf);
+      m3_stats(L, c, air, st, ovf PHASE_PASS);
       n_step = iteration = changes = ep_len = 0;
       ep_return = 0.0;
       last_loss = get_loss<NS>(p.cfg, st);
@@ -513,6 +543,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     S->ep_return = ep_return;
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
   }
+  PHASE_MARK(6);
+  PHASE_FLUSH();
 }
 
 }  // namespace pcgrl

@@ -27,15 +27,20 @@ import torch
 _lib.LIB_PATH = TIMING_LIB
 from control_pcgrl_amd import VecPcgrlEnv
 
-n, iters = 4096, 2000
-env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+three_d = "--3d" in sys.argv
+n, iters = (1024, 1000) if three_d else (4096, 2000)
+if three_d:
+    NAMES = ["loads+action", "observation", "column masks", "regions", "path searches", "overlay", "loss/outputs/write-back"]
+    env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
+else:
+    env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
 for k in range(300):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
-blocks = n // 4
+blocks = n if three_d else n // 4
 out = np.zeros(8 * blocks, np.uint64)
 env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
 for k in range(iters):
