@@ -25,7 +25,9 @@ constexpr int SK_VCAP = 1 << 15; // visited table slots (>= 2 x iterations per s
 
 struct SokoLevel {
   int32_t w, h, ncr, ntg;
+  int32_t use_order, n_dead_cur;  // heuristic via the per-cell target order table; crates of the expanded node on dead cells
   uint64_t solid[SK_MAXDIM], dead[SK_MAXDIM], tgt[SK_MAXDIM];
+  uint64_t occ[SK_MAXDIM];        // crate occupancy of the node being expanded
   uint8_t tx[SK_MAXC], ty[SK_MAXC];
 };
 struct SokoNode {
@@ -49,6 +51,7 @@ struct SokoCtx {
   uint8_t *crates;  // [max_nodes][2*SK_MAXC]
   uint32_t *vis;    // [SK_VCAP]  (epoch << 17) | (node + 1)
   int32_t *q;       // [max_nodes] BFS queue / A* heap / scratch
+  uint8_t *order;   // [SK_MAXDIM * SK_MAXDIM][SK_MAXC] targets sorted by (Manhattan distance, index) per cell
   int32_t n_nodes, max_nodes, ncr;
   uint32_t epoch;
 };
@@ -72,13 +75,46 @@ __device__ inline bool sk_win(const SokoCtx &c, const uint8_t *cr) {  // engine.
     if (sk_crate_at(c, cr, c.lv->tx[t], c.lv->ty[t]) < 0) return false;
   return true;
 }
-__device__ inline int sk_heuristic(const SokoCtx &c, const uint8_t *cr) {  // engine.py:282-296
-  uint32_t used[SK_MAXC / 32] = {0};  // targets already matched (the reference deletes them from a list: order is preserved)
+// engine.py:282-296 getHeuristic: crates in list order greedily take the nearest remaining target (first minimum in
+// list order).  With many targets the scan over all targets per crate dominates the whole search, so levels with more
+// than 8 targets use a per-cell table of the targets sorted by (distance, index): the nearest REMAINING target is the
+// first unused entry of the crate cell's row -- the same choice, found without computing all distances.
+__device__ inline void sk_build_order(SokoCtx &c) {
+  SokoLevel *lv = c.lv;
+  const int nt = lv->ntg, maxd = lv->w + lv->h;
+  int32_t *cnt = c.q;  // scratch: maxd + 2 counters
+  for (int y = 1; y < lv->h - 1; y++)
+    for (int x = 1; x < lv->w - 1; x++) {
+      uint8_t *row = c.order + (size_t)(y * SK_MAXDIM + x) * SK_MAXC;
+      for (int d = 0; d <= maxd + 1; d++) cnt[d] = 0;
+      for (int t = 0; t < nt; t++) cnt[abs(x - (int)lv->tx[t]) + abs(y - (int)lv->ty[t]) + 1]++;
+      for (int d = 1; d <= maxd + 1; d++) cnt[d] += cnt[d - 1];
+      for (int t = 0; t < nt; t++) {  // stable: equal distances keep index order
+        int d = abs(x - (int)lv->tx[t]) + abs(y - (int)lv->ty[t]);
+        row[cnt[d]++] = (uint8_t)t;
+      }
+    }
+}
+
+__device__ inline int sk_heuristic(const SokoCtx &c, const uint8_t *cr) {
+  uint64_t used0 = 0, used1 = 0;  // targets already matched (the reference deletes them from a list: order is preserved)
   int distance = 0;
+  const int nt = c.lv->ntg;
+  if (c.lv->use_order) {
+    for (int k = 0; k < c.ncr; k++) {
+      const int cx = cr[2 * k], cy = cr[2 * k + 1];
+      const uint8_t *row = c.order + (size_t)(cy * SK_MAXDIM + cx) * SK_MAXC;
+      int r = 0, t = row[0];
+      while (((t < 64 ? used0 : used1) >> (t & 63)) & 1ull) t = row[++r];  // ncr == ntg: an unused target always exists
+      distance += abs((int)c.lv->tx[t] - cx) + abs((int)c.lv->ty[t] - cy);
+      if (t < 64) used0 |= 1ull << t; else used1 |= 1ull << (t & 63);
+    }
+    return distance;
+  }
   for (int k = 0; k < c.ncr; k++) {
     int best = c.lv->w + c.lv->h, match = -1, first_free = -1;
-    for (int i = 0; i < c.lv->ntg; i++) {
-      if ((used[i >> 5] >> (i & 31)) & 1u) continue;
+    for (int i = 0; i < nt; i++) {
+      if (((i < 64 ? used0 : used1) >> (i & 63)) & 1ull) continue;
       if (first_free < 0) first_free = i;
       int d = abs((int)cr[2 * k] - (int)c.lv->tx[i]) + abs((int)cr[2 * k + 1] - (int)c.lv->ty[i]);
       if (best > d) {
@@ -88,7 +124,7 @@ __device__ inline int sk_heuristic(const SokoCtx &c, const uint8_t *cr) {  // en
     }
     if (match < 0) match = first_free;  // bestMatch = 0 default: first remaining target
     distance += abs((int)c.lv->tx[match] - (int)cr[2 * k]) + abs((int)c.lv->ty[match] - (int)cr[2 * k + 1]);
-    used[match >> 5] |= 1u << (match & 31);
+    if (match < 64) used0 |= 1ull << match; else used1 |= 1ull << (match & 63);
   }
   return distance;
 }
@@ -175,39 +211,61 @@ __device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n) {
   }
 }
 
-// Node.getChildren engine.py:14-25 + State.update :298-328
+// crate occupancy of node n as row bit masks, and how many of its crates stand on dead cells
+__device__ inline void sk_load_occupancy(SokoCtx &c, int n) {
+  SokoLevel *lv = c.lv;
+  for (int y = 0; y < lv->h; y++) lv->occ[y] = 0;
+  const uint8_t *cr = sk_crates(c, n);
+  int nd = 0;
+  for (int k = 0; k < c.ncr; k++) {
+    lv->occ[cr[2 * k + 1]] |= 1ull << cr[2 * k];
+    nd += sk_bit(lv->dead, cr[2 * k], cr[2 * k + 1]) ? 1 : 0;
+  }
+  lv->n_dead_cur = nd;
+}
+__device__ inline bool sk_win_occ(const SokoCtx &c) {  // engine.py:272-280 on the occupancy masks
+  if (c.lv->ntg != c.ncr || c.ncr == 0) return false;
+  for (int y = 0; y < c.lv->h; y++)
+    if (c.lv->tgt[y] & ~c.lv->occ[y]) return false;
+  return true;
+}
+
+// Node.getChildren engine.py:14-25 + State.update :298-328 (the expanded node's occupancy is loaded)
 __device__ inline int sk_children(SokoCtx &c, int n, int *out) {
   const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
+  const SokoLevel *lv = c.lv;
   int cnt = 0;
   const uint8_t *cr = sk_crates(c, n);
-  if (sk_win(c, cr)) return 0;
   const int px = c.nodes[n].px, py = c.nodes[n].py;
+  auto free_cell = [&](int x, int y) {  // checkMovableLocation :269-270
+    if (x < 0 || y < 0 || x > lv->w - 1 || y > lv->h - 1) return false;
+    return !sk_bit(lv->solid, x, y) && !sk_bit(lv->occ, x, y);
+  };
   for (int d = 0; d < 4; d++) {
     int nx = px + DX[d], ny = py + DY[d];
     int moved = -1;
-    if (!sk_movable(c, cr, nx, ny)) {
-      int k = sk_crate_at(c, cr, nx, ny);
-      if (k < 0) continue;
-      if (!sk_movable(c, cr, nx + DX[d], ny + DY[d])) continue;
-      moved = k;
+    if (!free_cell(nx, ny)) {
+      if (nx < 0 || ny < 0 || nx > lv->w - 1 || ny > lv->h - 1 || !sk_bit(lv->occ, nx, ny)) continue;
+      if (!free_cell(nx + DX[d], ny + DY[d])) continue;
+      moved = sk_crate_at(c, cr, nx, ny);
     }
     if (c.n_nodes >= c.max_nodes) continue;  // cannot happen: <= 1 + 4 * iterations nodes per stage
+    if (moved >= 0) {  // engine.py:22-23 checkDeadlock over all crates of the child
+      int nd = lv->n_dead_cur - (sk_bit(lv->dead, nx, ny) ? 1 : 0) + (sk_bit(lv->dead, nx + DX[d], ny + DY[d]) ? 1 : 0);
+      if (nd > 0) continue;
+    }
     int k = c.n_nodes++;
     uint8_t *ncr = sk_crates(c, k);
     for (int i = 0; i < 2 * c.ncr; i++) ncr[i] = cr[i];
     if (moved >= 0) {
       ncr[2 * moved] = (uint8_t)(nx + DX[d]);
       ncr[2 * moved + 1] = (uint8_t)(ny + DY[d]);
-      if (sk_deadlock(c, ncr)) {  // engine.py:22-23
-        c.n_nodes--;
-        continue;
-      }
     }
     c.nodes[k].parent = n;
     c.nodes[k].depth = (int16_t)(c.nodes[n].depth + 1);
     c.nodes[k].px = (uint8_t)nx;
     c.nodes[k].py = (uint8_t)ny;
-    c.nodes[k].h = (int16_t)sk_heuristic(c, ncr);
+    c.nodes[k].h = moved >= 0 ? (int16_t)sk_heuristic(c, ncr) : c.nodes[n].h;  // h depends on the crates only
     out[cnt++] = k;
   }
   return cnt;
@@ -270,7 +328,8 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, doub
         cur = last;
       }
     }
-    if (sk_win(c, sk_crates(c, cur))) {
+    sk_load_occupancy(c, cur);
+    if (sk_win_occ(c)) {
       res_h = c.nodes[cur].h;
       res_depth = c.nodes[cur].depth;
       return true;
@@ -327,6 +386,8 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
       c.vis = (uint32_t *)b;
       b += sizeof(uint32_t) * SK_VCAP;
       c.q = (int32_t *)b;
+      b += sizeof(int32_t) * (size_t)c.max_nodes;
+      c.order = b;
       c.lv->w = W + 2;
       c.lv->h = H + 2;
       const uint64_t full = (1ull << (W + 2)) - 1ull;
@@ -378,6 +439,8 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
         c.lv->ncr = ncr;
         c.lv->ntg = ntg;
         sk_init_deadlocks(c);
+        c.lv->use_order = ntg > 8 ? 1 : 0;
+        if (c.lv->use_order) sk_build_order(c);
         c.nodes[0].parent = -1;
         c.nodes[0].depth = 0;
         c.nodes[0].px = (uint8_t)px;
@@ -423,6 +486,7 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs) {
   size_t sz = (sizeof(SokoLevel) + 15) & ~(size_t)15;
   sz += sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * 2 * SK_MAXC;
   sz += sizeof(uint32_t) * SK_VCAP + sizeof(int32_t) * (size_t)pool.max_nodes;
+  sz += (size_t)SK_MAXDIM * SK_MAXDIM * SK_MAXC;  // per-cell target order table
   pool.slot_bytes = (sz + 255) & ~(size_t)255;
   hipError_t e;
   void *base = nullptr, *locks = nullptr, *epochs = nullptr, *dpool = nullptr;
