@@ -419,3 +419,70 @@ def gen_stats_sokoban_solver(n=70):
 
 if __name__ == "__main__" and "sokoban_solver" in sys.argv[1:]:
     gen_stats_sokoban_solver()
+
+
+def run_control_episode(name, controls, seed, n_steps=120):
+    """Controllable generation (control_wrappers.py:27-121, :189-214): ctrl_metrics given, targets queued with
+    set_trgs() and applied at reset().  cfg.evaluate=True keeps make_env from adding UniformNoiseyTargets, which is
+    broken at this commit (its __init__ reads self.num_params); targets are drawn here uniformly from cond_bounds, which
+    is what that wrapper does (:453-460)."""
+    problem, rep, shape = CONFIGS[name]
+    cfg = ref_env.make_cfg(problem, rep, shape)
+    cfg.controls = list(controls)
+    cfg.evaluate = True
+    env = ref_env.make_reference_env(cfg, seed=seed)
+    core = env.unwrapped
+    n_act = env.action_space.n
+    arng = np.random.default_rng(2000 + seed)
+    trng = np.random.default_rng(3000 + seed)
+    K = len(controls)
+    rec = dict(action=[], reward=[], done=[], stats=[], ctrl=[], obs_crc=[], trg=[], reset_at=[])
+    t = 0
+
+    def new_targets():
+        trgs = {}
+        for k in controls:
+            lb, ub = env.cond_bounds[k]
+            trgs[k] = float(trng.random() * (ub - lb) + lb)
+        env.set_trgs(trgs)
+        return [trgs[k] for k in controls]
+
+    def split(obs):
+        o = np.asarray(obs)
+        ctrl = o[0, 0, :2 * K].astype(np.float64).copy()
+        assert np.all(o[..., :2 * K] == ctrl), "control planes must be constant"
+        return ctrl, obs_u8(o[..., 2 * K:])
+
+    resets = dict(ctrl=[], obs_crc=[], stats=[], trg=[])
+    for ep in range(2):
+        trg = new_targets()
+        obs, _ = env.reset()
+        ctrl, u = split(obs)
+        resets["ctrl"].append(ctrl); resets["obs_crc"].append(zlib.crc32(u.tobytes()))
+        resets["stats"].append(stats_vec(problem, core._rep_stats)); resets["trg"].append(trg)
+        rec["reset_at"].append(t)
+        for _ in range(n_steps):
+            a = int(arng.integers(n_act))
+            obs, r, d, tr, info = env.step(a)
+            ctrl, u = split(obs)
+            rec["action"].append(a); rec["reward"].append(float(r)); rec["done"].append(bool(d))
+            rec["stats"].append(stats_vec(problem, core._rep_stats)); rec["ctrl"].append(ctrl)
+            rec["obs_crc"].append(zlib.crc32(u.tobytes()))
+            t += 1
+    out = dict(problem=problem, representation=rep, map_shape=np.array(shape), seed=seed, controls=np.array(controls),
+               stat_keys=np.array(STAT_KEYS[problem]), steps_per_episode=n_steps,
+               action=np.array(rec["action"], np.int32), reward=np.array(rec["reward"], np.float64),
+               done=np.array(rec["done"]), stats=np.array(rec["stats"], np.int32), ctrl=np.array(rec["ctrl"], np.float64),
+               obs_crc=np.array(rec["obs_crc"], np.uint32), reset_at=np.array(rec["reset_at"], np.int32),
+               reset_ctrl=np.array(resets["ctrl"], np.float64), reset_obs_crc=np.array(resets["obs_crc"], np.uint32),
+               reset_stats=np.array(resets["stats"], np.int32), reset_trg=np.array(resets["trg"], np.float64))
+    path = os.path.join(OUT, f"control_{name}_s{seed}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "ret", sum(rec["reward"]), "ctrl[0]", rec["ctrl"][0])
+
+
+if __name__ == "__main__" and "control" in sys.argv[1:]:
+    run_control_episode("binary_narrow", ["regions", "path-length"], 7)
+    run_control_episode("zelda_turtle", ["nearest-enemy", "path-length"], 8)
+    run_control_episode("sokoban_wide", ["crate", "sol-length"], 9)
+    run_control_episode("binary_wide", ["path-length"], 10)

@@ -126,6 +126,9 @@ typedef struct {
   int32_t last_ep_len;
   int32_t final_stats[ORC_MAX_STATS];
   int64_t n_episodes;
+  /* controllable mode: active targets and targets queued for the next reset */
+  double trg_lo[ORC_MAX_STATS], trg_hi[ORC_MAX_STATS], pend_lo[ORC_MAX_STATS], pend_hi[ORC_MAX_STATS];
+  int32_t has_pending;
   /* 3-D maze: path overlay shown in the NEXT observation (minecraft_3D_maze_prob.py:84-93) */
   int16_t *path_xyz;
   int32_t path_len;
@@ -340,13 +343,13 @@ void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids,
 }
 
 /* control_wrappers.py:318-345 get_loss: sum over static targets of -w * distance(value, target). */
-static double get_loss(const orc_config *cfg, const int32_t *st) {
+static double get_loss(const orc_config *cfg, const env_t *ev, const int32_t *st) {
   double loss = 0.0;
   for (int k = 0; k < cfg->n_stats; k++) {
     if (!cfg->has_trg[k]) continue;
     double v = (double)st[k], d = 0.0;
-    if (v < cfg->trg_lo[k]) d = cfg->trg_lo[k] - v;
-    else if (v > cfg->trg_hi[k]) d = v - cfg->trg_hi[k];
+    if (v < ev->trg_lo[k]) d = ev->trg_lo[k] - v;
+    else if (v > ev->trg_hi[k]) d = v - ev->trg_hi[k];
     loss += (-d) * cfg->weights[k];
   }
   return loss;
@@ -424,6 +427,14 @@ static int rep_update(const orc_engine *e, env_t *v, int action) {
 static void env_reset(const orc_engine *e, env_t *v, const uint8_t *init_grid, const int32_t *init_pos) {
   const orc_config *cfg = &e->cfg;
   int nt = e->n_tiles;
+  if (v->has_pending) { /* control_wrappers.py:174-178: queued targets take effect at reset */
+    for (int k = 0; k < cfg->n_ctrl; k++) {
+      int s = cfg->ctrl_idx[k];
+      v->trg_lo[s] = v->pend_lo[s];
+      v->trg_hi[s] = v->pend_hi[s];
+    }
+    v->has_pending = 0;
+  }
   v->changes = 0;
   v->iteration = 0;
   v->n_step = 0;
@@ -462,7 +473,7 @@ static void env_reset(const orc_engine *e, env_t *v, const uint8_t *init_grid, c
      * process_observation (pcgrl_env.py:180-188); the path found here shows from the first step on. */
   }
   if (!init_grid && cfg->problem == ORC_PROB_BINARY) (void)pcg64_double(&v->rng_prob); /* binary_prob.py:139-143 */
-  v->last_loss = get_loss(cfg, v->stats);
+  v->last_loss = get_loss(cfg, v, v->stats);
   v->ep_return = 0.0;
   v->ep_len = 0;
 }
@@ -543,6 +554,8 @@ orc_engine *orc_create(const orc_config *cfg, int32_t n_envs) {
     e->envs[i].path_xyz = e->path_pool + (size_t)i * path_cap * 3;
     pcg64_seed(&e->envs[i].rng_rep, (uint64_t)i);
     pcg64_seed(&e->envs[i].rng_prob, (uint64_t)i);
+    memcpy(e->envs[i].trg_lo, cfg->trg_lo, sizeof(cfg->trg_lo));
+    memcpy(e->envs[i].trg_hi, cfg->trg_hi, sizeof(cfg->trg_hi));
   }
   return e;
 }
@@ -596,7 +609,7 @@ void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t
     int d = v->iteration > cfg->max_iterations; /* :307 */
     if (cfg->max_changes >= 0) d = d || (v->changes > cfg->max_changes); /* :308-309 */
     /* control_wrappers.py:216-244 */
-    double loss = get_loss(cfg, v->stats);
+    double loss = get_loss(cfg, v, v->stats);
     double r = loss - v->last_loss;
     v->last_loss = loss;
     v->ep_return += r;
@@ -640,6 +653,32 @@ void orc_get_state(orc_engine *e, uint8_t *grids, int32_t *pos, int32_t *counter
       for (int k = 0; k < e->cfg.n_stats; k++) stats[(size_t)i * e->cfg.n_stats + k] = v->stats[k];
     if (last_loss) last_loss[i] = v->last_loss;
     if (ep_return) ep_return[i] = v->ep_return;
+  }
+}
+
+void orc_queue_targets(orc_engine *e, const uint8_t *mask, const double *trg_lo, const double *trg_hi) {
+  int S = e->cfg.n_stats;
+  for (int i = 0; i < e->n_envs; i++) {
+    if (mask && !mask[i]) continue;
+    env_t *v = &e->envs[i];
+    for (int k = 0; k < S; k++) {
+      v->pend_lo[k] = trg_lo[(size_t)i * S + k];
+      v->pend_hi[k] = trg_hi[(size_t)i * S + k];
+    }
+    v->has_pending = 1;
+  }
+}
+
+void orc_get_ctrl_obs(orc_engine *e, double *out) {
+  const orc_config *c = &e->cfg;
+  for (int i = 0; i < e->n_envs; i++) {
+    const env_t *v = &e->envs[i];
+    for (int k = 0; k < c->n_ctrl; k++) {
+      int s = c->ctrl_idx[k];
+      double trg = (v->trg_lo[s] + v->trg_hi[s]) / 2; /* tuple target -> its midpoint (:203-204) */
+      out[(size_t)i * 2 * c->n_ctrl + 2 * k] = trg / c->ctrl_range[k];
+      out[(size_t)i * 2 * c->n_ctrl + 2 * k + 1] = (double)v->stats[s] / c->ctrl_range[k];
+    }
   }
 }
 

@@ -42,6 +42,10 @@ typedef struct {
   double trg_lo[ORC_MAX_STATS];    /* inclusive target interval: scalar t -> [t,t]; tuple (lo,hi) -> */
   double trg_hi[ORC_MAX_STATS];    /*   [lo, last element of arange(lo,hi)]  (control_wrappers.py:337-341) */
   int32_t solver_power;     /* sokoban: iterations per solver stage (sokoban_prob.py:40) */
+  /* controllable generation (control_wrappers.py:27-121): stats observed + re-targeted per episode */
+  int32_t n_ctrl;
+  int32_t ctrl_idx[ORC_MAX_STATS];   /* stat index of each control metric, in cfg.controls order */
+  double ctrl_range[ORC_MAX_STATS];  /* param_ranges[k] = |cond_bounds[k][1] - cond_bounds[k][0]|  (:70-73) */
 } orc_config;
 
 typedef struct orc_engine orc_engine;
@@ -70,6 +74,12 @@ void orc_get_state(orc_engine *e, uint8_t *grids, int32_t *pos, int32_t *counter
 /* results of the last finished episode per env (valid after an auto-reset): return, length, final stats */
 void orc_get_last_episode(orc_engine *e, double *ep_return, int32_t *ep_len, int32_t *final_stats,
                           int64_t *n_episodes);
+
+/* set_trgs() (control_wrappers.py:168-172): queue per-env targets [N][n_stats] (inclusive interval lo..hi; only the
+ * control metrics' columns are read); they replace the env's targets at its next reset (:174-178). mask NULL = all. */
+void orc_queue_targets(orc_engine *e, const uint8_t *mask, const double *trg_lo, const double *trg_hi);
+/* observe_metric_trgs (:189-214): per env 2*n_ctrl values (target / range, metric / range), float64 */
+void orc_get_ctrl_obs(orc_engine *e, double *out);
 
 /* Stateless Problem.get_stats() on n grids. */
 void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out);

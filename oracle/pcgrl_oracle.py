@@ -67,7 +67,30 @@ class OrcConfig(C.Structure):
         ("max_iterations", C.c_int32), ("max_changes", C.c_int32), ("n_stats", C.c_int32),
         ("has_trg", C.c_int32 * 8), ("weights", C.c_double * 8), ("trg_lo", C.c_double * 8),
         ("trg_hi", C.c_double * 8), ("solver_power", C.c_int32),
+        ("n_ctrl", C.c_int32), ("ctrl_idx", C.c_int32 * 8), ("ctrl_range", C.c_double * 8),
     ]
+
+
+def cond_bounds(problem, map_shape):
+    """Problem.cond_bounds (only the keys usable as controls), evaluated for `map_shape`."""
+    if problem == "binary":  # probs/binary/binary_prob.py:66-84
+        h, w = map_shape
+        return {"regions": (0, w * math.ceil(h / 2)), "path-length": (0, math.ceil(w / 2) * h + math.floor(h / 2))}
+    if problem == "zelda":  # probs/zelda/zelda_ctrl_prob.py:55-73
+        h, w = map_shape
+        n = w * h
+        return {"nearest-enemy": (0, math.ceil(w / 2 + 1) * h), "enemies": (0, n - 2), "player": (0, n - 2),
+                "key": (0, n - 2), "door": (0, n - 2), "regions": (0, n / 2),
+                "path-length": (0, (math.ceil(w / 2) * h + math.floor(h / 2)) * 2 - 1)}
+    if problem == "sokoban":  # probs/sokoban/sokoban_ctrl_prob.py:37-49, frozen at 5x5 (Q10)
+        w = h = 5
+        mp = math.ceil(w / 2 + 1) * h
+        return {"player": (1, w * h), "crate": (1, w * h / 2 - max(w, h)), "target": (1, w * h), "ratio": (0, w * h),
+                "dist-win": (0, w * h * (w + h)), "sol-length": (0, 2 * mp), "regions": (0, w * h / 2)}
+    if problem == "minecraft_3D_maze":  # minecraft_3D_maze_prob.py:52-58, sizes frozen at 15 (Q11)
+        mp = 2 * (15 // 3) * (math.ceil(15 / 2) * 15 + math.floor(15 / 2))
+        return {"regions": (0, math.ceil(15 * 15 / 2 * 15)), "path-length": (0, mp), "n_jump": (0, mp // 2)}
+    raise ValueError(problem)
 
 
 def build(force=False):
@@ -100,13 +123,15 @@ def lib():
         L.orc_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.orc_get_last_episode.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.orc_stats_for_grids.argtypes = [C.POINTER(OrcConfig), C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_queue_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_get_ctrl_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
 
 def make_config(problem, representation, map_shape, obs_window=None, weights=None, max_board_scans=3,
-                change_percentage=None, solver_power=10000):
+                change_percentage=None, solver_power=10000, controls=None):
     map_shape = tuple(int(s) for s in map_shape)
     ndim = len(map_shape)
     if obs_window is None:
@@ -137,6 +162,12 @@ def make_config(problem, representation, map_shape, obs_window=None, weights=Non
             else:
                 cfg.trg_lo[i] = cfg.trg_hi[i] = float(t)
     cfg.solver_power = solver_power
+    controls = list(controls or [])
+    cfg.n_ctrl = len(controls)
+    bounds = cond_bounds(problem, map_shape)
+    for i, k in enumerate(controls):  # control_wrappers.py:66-73
+        cfg.ctrl_idx[i] = keys.index(k)
+        cfg.ctrl_range[i] = abs(bounds[k][1] - bounds[k][0])
     return cfg
 
 
@@ -213,6 +244,21 @@ class OracleVecEnv:
                             last_loss.ctypes.data, ep_ret.ctypes.data)
         return dict(grids=grids, pos=pos, iteration=counters[:, 0], changes=counters[:, 1], n_step=counters[:, 2],
                     ep_len=counters[:, 3], stats=stats, last_loss=last_loss, ep_return=ep_ret)
+
+    def queue_targets(self, trgs, mask=None):
+        """set_trgs (control_wrappers.py:168-172): `trgs` = {metric: value or [N] values}; applied at the next reset."""
+        keys = STAT_KEYS[self.problem]
+        lo = np.zeros((self.n, self.n_stats), np.float64)
+        hi = np.zeros((self.n, self.n_stats), np.float64)
+        for k, v in trgs.items():
+            lo[:, keys.index(k)] = hi[:, keys.index(k)] = np.broadcast_to(np.asarray(v, np.float64), (self.n,))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_queue_targets(self.h, None if m is None else m.ctypes.data, lo.ctypes.data, hi.ctypes.data)
+
+    def ctrl_obs(self):
+        out = np.zeros((self.n, 2 * self.cfg.n_ctrl), np.float64)
+        lib().orc_get_ctrl_obs(self.h, out.ctypes.data)
+        return out
 
     def last_episode(self):
         ret = np.empty(self.n, np.float64)
