@@ -22,6 +22,7 @@ class PcgrlConfig(C.Structure):
         ("has_trg", C.c_int32 * PCGRL_MAX_STATS), ("weights", C.c_double * PCGRL_MAX_STATS),
         ("trg_lo", C.c_double * PCGRL_MAX_STATS), ("trg_hi", C.c_double * PCGRL_MAX_STATS),
         ("solver_power", C.c_int32),
+        ("n_ctrl", C.c_int32), ("ctrl_idx", C.c_int32 * PCGRL_MAX_STATS), ("ctrl_range", C.c_double * PCGRL_MAX_STATS),
     ]
 
 
@@ -33,6 +34,10 @@ SYMBOLS = {
     "pcgrl_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "pcgrl_step_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_queue_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_ctrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_obs_bytes": (C.c_int64, [C.c_void_p]),
     "pcgrl_obs_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 4), C.POINTER(C.c_int32)]),

@@ -116,6 +116,10 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   if (c.problem < 0 || c.problem > PCGRL_PROB_MC3DMAZE) return fail(PCGRL_EINVAL, "unknown problem");
   if (c.representation < 0 || c.representation > PCGRL_REP_WIDE) return fail(PCGRL_EINVAL, "unknown representation");
   if (c.n_stats != n_stats_of(c.problem)) return fail(PCGRL_EINVAL, "n_stats does not match the problem");
+  if (c.n_ctrl < 0 || c.n_ctrl > c.n_stats) return fail(PCGRL_EINVAL, "n_ctrl out of range");
+  for (int j = 0; j < c.n_ctrl; j++)
+    if (c.ctrl_idx[j] < 0 || c.ctrl_idx[j] >= c.n_stats || !(c.ctrl_range[j] > 0.0) || !c.has_trg[c.ctrl_idx[j]])
+      return fail(PCGRL_EINVAL, "control metric: bad stat index, non-positive range, or a stat without a target");
   const int nt = n_tiles_of(c.problem);
   if (c.problem == PCGRL_PROB_MC3DMAZE) {
     if (c.ndim != 3) return fail(PCGRL_EINVAL, "minecraft_3D_maze needs ndim == 3");
@@ -324,6 +328,18 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   CREATE_CHK(hipMemcpy(djt, jt.data(), jt.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
   p.jump = djt;
   if (cfg->problem == PCGRL_PROB_SOKOBAN) CREATE_CHK(sokoban_alloc(p, e->allocs));
+  if (cfg->n_ctrl > 0) {  // controllable mode: per-env targets, initialised with the static ones
+    std::vector<double> init((size_t)n_envs * PCGRL_MAX_STATS * 2, 0.0);
+    for (int i = 0; i < n_envs; i++)
+      for (int k = 0; k < PCGRL_MAX_STATS; k++) {
+        init[((size_t)i * PCGRL_MAX_STATS + k) * 2] = cfg->trg_lo[k];
+        init[((size_t)i * PCGRL_MAX_STATS + k) * 2 + 1] = cfg->trg_hi[k];
+      }
+    CREATE_CHK(dalloc((void **)&p.trg, init.size() * sizeof(double)));
+    CREATE_CHK(dalloc((void **)&p.trg_pending, init.size() * sizeof(double)));
+    CREATE_CHK(dalloc((void **)&p.trg_flag, (size_t)n_envs * sizeof(int32_t)));
+    CREATE_CHK(hipMemcpy(p.trg, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
 #undef CREATE_CHK
   *out = e;
   // default seeding: env i gets seed i (callers normally call pcgrl_seed)
@@ -373,6 +389,48 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   p.done = d_done;
   p.stats_out = d_stats;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
+                  double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream) {
+  if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step_ex: bad arguments");
+  if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_step_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
+  Params p = h->p;
+  p.actions = d_actions;
+  p.auto_reset = auto_reset;
+  p.obs = d_obs;
+  p.reward = d_reward;
+  p.reward64 = d_reward64;
+  p.done = d_done;
+  p.stats_out = d_stats;
+  p.ctrl_obs = d_ctrl_obs;
+  HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_trg_lo, const double *d_trg_hi, void *stream) {
+  if (!h || !d_trg_lo || !d_trg_hi) return fail(PCGRL_EINVAL, "pcgrl_queue_targets: bad arguments");
+  if (h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_queue_targets: the engine was created without control metrics");
+  Params p = h->p;
+  p.mask = d_mask;
+  hipLaunchKernelGGL(queue_targets_kernel, dim3((p.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, d_trg_lo, d_trg_hi);
+  HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream) {
+  if (!h || !d_ctrl_obs) return fail(PCGRL_EINVAL, "pcgrl_ctrl_observe: bad arguments");
+  if (h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_ctrl_observe: the engine was created without control metrics");
+  Params p = h->p;
+  p.ctrl_obs = d_ctrl_obs;
+  dim3 grid((p.n_envs + 63) / 64), block(64);
+  switch (p.cfg.n_stats) {
+    case 2: hipLaunchKernelGGL((ctrl_observe_kernel<2>), grid, block, 0, (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL((ctrl_observe_kernel<3>), grid, block, 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL((ctrl_observe_kernel<7>), grid, block, 0, (hipStream_t)stream, p); break;
+  }
+  HIPCHK(hipGetLastError());
   return PCGRL_OK;
 }
 

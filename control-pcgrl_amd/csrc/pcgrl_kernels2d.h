@@ -443,18 +443,74 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
   }
 }
 
-// control_wrappers.py:318-345
+// Target intervals of one env.  Plain mode: the config's static targets.  Controllable mode (control_wrappers.py:27-121):
+// per-env targets in HBM; targets queued by pcgrl_queue_targets replace the control metrics' targets at the env's next
+// reset (:174-178), which is when `take_pending` is set.
 template <int NS>
-__device__ inline double get_loss(const pcgrl_config &c, const int32_t *st) {
-  double loss = 0.0;
+struct EnvTargets {
+  double lo[NS], hi[NS];
+  bool took_pending;
+  __device__ inline void load(const Params &p, int env, bool at_reset) {
+    took_pending = false;
+    if (p.trg == nullptr) {
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
-    double v = (double)st[k];
-    double d = v < c.trg_lo[k] ? c.trg_lo[k] - v : (v > c.trg_hi[k] ? v - c.trg_hi[k] : 0.0);
-    loss += c.has_trg[k] ? (-d) * c.weights[k] : 0.0;
+      for (int k = 0; k < NS; k++) {
+        lo[k] = p.cfg.trg_lo[k];
+        hi[k] = p.cfg.trg_hi[k];
+      }
+      return;
+    }
+    const double *a = p.trg + (size_t)env * PCGRL_MAX_STATS * 2;
+    const double *q = p.trg_pending + (size_t)env * PCGRL_MAX_STATS * 2;
+    took_pending = at_reset && p.trg_flag[env] != 0;
+    uint32_t ctrl_mask = 0;
+    for (int j = 0; j < p.cfg.n_ctrl; j++) ctrl_mask |= 1u << p.cfg.ctrl_idx[j];
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const bool pend = took_pending && ((ctrl_mask >> k) & 1u);
+      lo[k] = pend ? q[2 * k] : a[2 * k];
+      hi[k] = pend ? q[2 * k + 1] : a[2 * k + 1];
+    }
   }
-  return loss;
-}
+  // one lane per env makes the queued targets the active ones
+  __device__ inline void commit(const Params &p, int env) const {
+    if (p.trg == nullptr || !took_pending) return;
+    double *a = p.trg + (size_t)env * PCGRL_MAX_STATS * 2;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      a[2 * k] = lo[k];
+      a[2 * k + 1] = hi[k];
+    }
+    p.trg_flag[env] = 0;
+  }
+  // control_wrappers.py:318-345 get_loss
+  __device__ inline double loss(const pcgrl_config &c, const int32_t *st) const {
+    double l = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      double v = (double)st[k];
+      double d = v < lo[k] ? lo[k] - v : (v > hi[k] ? v - hi[k] : 0.0);
+      l += c.has_trg[k] ? (-d) * c.weights[k] : 0.0;
+    }
+    return l;
+  }
+  // control_wrappers.py:189-214 observe_metric_trgs: (target / range, metric / range) per control metric
+  __device__ inline void write_ctrl_obs(const Params &p, int env, const int32_t *st) const {
+    if (p.ctrl_obs == nullptr) return;
+    for (int j = 0; j < p.cfg.n_ctrl; j++) {
+      const int s = p.cfg.ctrl_idx[j];
+      double t = 0.0, v = 0.0;
+#pragma unroll
+      for (int k = 0; k < NS; k++)
+        if (k == s) {
+          t = (lo[k] + hi[k]) / 2;  // tuple target -> midpoint (:203-204)
+          v = (double)st[k];
+        }
+      p.ctrl_obs[(size_t)env * 2 * p.cfg.n_ctrl + 2 * j] = (float)(t / p.cfg.ctrl_range[j]);
+      p.ctrl_obs[(size_t)env * 2 * p.cfg.n_ctrl + 2 * j + 1] = (float)(v / p.cfg.ctrl_range[j]);
+    }
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ tile <-> planes
 template <int NB>
@@ -813,13 +869,16 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   }
   PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
-  double loss = get_loss<NS>(p.cfg, st);
+  EnvTargets<NS> trg;
+  trg.load(p, e, false);
+  double loss = trg.loss(p.cfg, st);
   double rew = loss - last_loss;
   last_loss = loss;
   ep_return += rew;
   ep_len++;
   if (active && g.row == 0) {
     if (p.reward) p.reward[e] = (float)rew;
+    if (p.reward64) p.reward64[e] = rew;
     if (p.done) p.done[e] = done ? 1 : 0;
     if (p.stats_out) {
 #pragma unroll
@@ -845,12 +904,15 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
       n_step = 0;
       ep_len = 0;
       ep_return = 0.0;
-      last_loss = get_loss<NS>(p.cfg, st);
+      trg.load(p, e, true);  // queued control targets take effect with the new episode
+      last_loss = trg.loss(p.cfg, st);
     }
   }
   // write back state
   if (change || do_reset) store_planes<NW>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
+    trg.write_ctrl_obs(p, e, st);
+    trg.commit(p, e);
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
     S->n_step = n_step;
@@ -913,11 +975,39 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
     S->changes = 0;
     S->ep_len = 0;
     S->ep_return = 0.0;
-    S->last_loss = get_loss<NS>(p.cfg, st);
+    EnvTargets<NS> trg;
+    trg.load(p, e, true);
+    S->last_loss = trg.loss(p.cfg, st);
+    trg.write_ctrl_obs(p, e, st);
+    trg.commit(p, e);
 #pragma unroll
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
   }
   (void)lds;
+}
+
+// control observation of the current state (pcgrl_ctrl_observe) and target queueing (pcgrl_queue_targets)
+template <int NS>
+__global__ __launch_bounds__(64) void ctrl_observe_kernel(Params p) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= p.n_envs) return;
+  EnvTargets<NS> trg;
+  trg.load(p, env, false);
+  int32_t st[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) st[k] = p.st[env].stats[k];
+  trg.write_ctrl_obs(p, env, st);
+}
+
+__global__ __launch_bounds__(64) void queue_targets_kernel(Params p, const double *lo, const double *hi) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= p.n_envs || (p.mask != nullptr && p.mask[env] == 0)) return;
+  double *q = p.trg_pending + (size_t)env * PCGRL_MAX_STATS * 2;
+  for (int k = 0; k < p.cfg.n_stats; k++) {
+    q[2 * k] = lo[(size_t)env * p.cfg.n_stats + k];
+    q[2 * k + 1] = hi[(size_t)env * p.cfg.n_stats + k];
+  }
+  p.trg_flag[env] = 1;
 }
 
 template <int PROB, int LPE, bool FAST>

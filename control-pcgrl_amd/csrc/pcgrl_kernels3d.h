@@ -445,6 +445,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
   int32_t st[NS];
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
   bool ovf = false;
+  EnvTargets<NS> trg;
+  trg.load(p, env, false);
 
   if constexpr (MODE == M3_RESET) {
     if (p.mask != nullptr && p.mask[env] == 0) return;
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     m3_stats(L, c, air, st, ovf PHASE_PASS);
     n_step = iteration = changes = ep_len = 0;
     ep_return = 0.0;
-    last_loss = get_loss<NS>(p.cfg, st);
+    trg.load(p, env, true);
+    last_loss = trg.loss(p.cfg, st);
   } else {
     // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
     const int action = p.actions[env];
@@ -497,13 +500,14 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
       m3_stats(L, c, air, st, ovf PHASE_PASS);
     }
-    const double loss = get_loss<NS>(p.cfg, st);
+    const double loss = trg.loss(p.cfg, st);
     const double rew = loss - last_loss;
     last_loss = loss;
     ep_return += rew;
     ep_len++;
     if (c.lane == 0) {
       if (p.reward) p.reward[env] = (float)rew;
+      if (p.reward64) p.reward64[env] = rew;
       if (p.done) p.done[env] = done ? 1 : 0;
       if (p.stats_out)
         for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
@@ -521,7 +525,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       m3_stats(L, c, air, st, ovf PHASE_PASS);
       n_step = iteration = changes = ep_len = 0;
       ep_return = 0.0;
-      last_loss = get_loss<NS>(p.cfg, st);
+      trg.load(p, env, true);
+      last_loss = trg.loss(p.cfg, st);
       m3_encode_obs(L, c, p, env, pos, false);
     }
   }
@@ -532,6 +537,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     gd[M3_MAXW + i] = L.over[i];
   }
   if (c.lane == 0) {
+    trg.write_ctrl_obs(p, env, st);
+    trg.commit(p, env);
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
     S->pos[2] = pos[2];

@@ -47,12 +47,15 @@ class PcgrlGymEnv:
         assert self._vec.num_envs == 1 and not self._vec.auto_reset
         v = self._vec
         # wrappers.py:121-123 ToImage: Box(low=0, high=max tile value, shape=(H, W, C)) float32
-        self.observation_space = Box(low=0, high=1, shape=v.obs_shape, dtype=np.float32)
+        # controllable mode prepends 2 * len(controls) constant planes (control_wrappers.py:86-104, :189-214)
+        self._n_ctrl_planes = 2 * len(v.controls)
+        shape = v.obs_shape[:-1] + (v.obs_shape[-1] + self._n_ctrl_planes,)
+        self.observation_space = Box(low=0, high=1, shape=shape, dtype=np.float32)
         self.action_space = Discrete(v.num_actions)  # narrow_rep.py:65-68, turtle_rep.py:70-71, wrappers.py:297
         self.static_trgs = dict(v.spec.static_trgs)
         self.metric_trgs = self.static_trgs
         self.cond_bounds = dict(v.spec.cond_bounds)
-        self.ctrl_metrics = []
+        self.ctrl_metrics = list(v.controls)
         self.metric_weights = {k: float(v.cfg.weights[i]) for i, k in enumerate(v.stat_keys)}
         self.metrics = {k: None for k in self.static_trgs}
         self._rep_stats = None
@@ -67,6 +70,19 @@ class PcgrlGymEnv:
             self._vec.seed([int(seed)])
         return [seed]
 
+    def set_trgs(self, trgs):
+        """ControlWrapper.set_trgs (control_wrappers.py:168-172): takes effect at the next reset()."""
+        self._vec.queue_targets({k: float(x) if not isinstance(x, tuple) else x for k, x in trgs.items()})
+        self.metric_trgs.update(trgs)
+
+    def _with_ctrl_planes(self, obs, info):
+        o = obs[0].float().cpu().numpy()
+        if not self._n_ctrl_planes:
+            return o
+        c = info["ctrl_obs"][0].cpu().numpy()
+        planes = np.broadcast_to(c, o.shape[:-1] + (self._n_ctrl_planes,)).astype(np.float32)
+        return np.concatenate((planes, o), axis=-1)  # control planes first (:210)
+
     def _stats_dict(self, stats_row):
         vals = stats_row.tolist()
         return {k: int(x) for k, x in zip(self._vec.stat_keys, vals)}
@@ -74,11 +90,11 @@ class PcgrlGymEnv:
     def reset(self, *, seed=None, options=None):
         if seed is not None:
             self.seed(seed)
-        obs, _ = self._vec.reset()
+        obs, info = self._vec.reset()
         st = self._vec.get_state()
         self._rep_stats = self._stats_dict(st.stats[0].cpu())
         self.metrics = self._rep_stats
-        return obs[0].float().cpu().numpy(), {}
+        return self._with_ctrl_planes(obs, info), {}
 
     def step(self, action):
         a = int(action)
@@ -96,7 +112,7 @@ class PcgrlGymEnv:
         out_info.update(iterations=int(st.iteration[0]), changes=int(st.changes[0]),
                         max_iterations=int(self._vec.cfg.max_iterations),
                         max_changes=None if self._vec.cfg.max_changes < 0 else int(self._vec.cfg.max_changes))
-        return obs[0].float().cpu().numpy(), float(rew[0].item()), d, d, out_info
+        return self._with_ctrl_planes(obs, info), float(rew[0].item()), d, d, out_info
 
     def get_map(self):
         return self._vec.get_state().grids[0].cpu().numpy()

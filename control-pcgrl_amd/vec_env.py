@@ -25,7 +25,7 @@ def _cfg_get(cfg, path, default=None):
 
 
 def build_config(problem, representation, map_shape, obs_window=None, weights=None, max_board_scans=3,
-                 change_percentage=None, solver_power=10000, static_trgs=None):
+                 change_percentage=None, solver_power=10000, static_trgs=None, controls=None):
     """cfg fields -> pcgrl_config (include/pcgrl_amd.h)."""
     if representation not in REPRESENTATIONS:
         raise ValueError(f"Unknown representation: {representation}")  # rl/envs.py:65
@@ -61,6 +61,13 @@ def build_config(problem, representation, map_shape, obs_window=None, weights=No
             c.has_trg[i] = 1
             c.trg_lo[i], c.trg_hi[i] = target_interval(trgs[k])
     c.solver_power = int(solver_power)
+    controls = list(controls or [])
+    c.n_ctrl = len(controls)
+    for i, k in enumerate(controls):  # control_wrappers.py:66-73: param_ranges[k] = |bounds[1] - bounds[0]|
+        if k not in spec.stat_keys or k not in spec.cond_bounds:
+            raise ValueError(f"control metric '{k}' is not a metric of problem '{problem}'")
+        c.ctrl_idx[i] = spec.stat_keys.index(k)
+        c.ctrl_range[i] = abs(spec.cond_bounds[k][1] - spec.cond_bounds[k][0])
     return c, spec, obs_window
 
 
@@ -77,7 +84,7 @@ class VecPcgrlEnv:
 
     def __init__(self, problem, representation, map_shape, num_envs, device="cuda:0", obs_window=None, weights=None,
                  max_board_scans=3, change_percentage=None, seeds=None, auto_reset=True, solver_power=10000,
-                 static_trgs=None):
+                 static_trgs=None, controls=None, reward_dtype=torch.float32):
         if not torch.cuda.is_available():
             raise RuntimeError("VecPcgrlEnv needs a GPU (ROCm device); there is no CPU fallback in the product path")
         self.device = torch.device(device)
@@ -87,7 +94,8 @@ class VecPcgrlEnv:
         self.auto_reset = bool(auto_reset)
         self.cfg, self.spec, self.obs_window = build_config(
             problem, representation, map_shape, obs_window, weights, max_board_scans, change_percentage, solver_power,
-            static_trgs)
+            static_trgs, controls)
+        self.controls = list(controls or [])
         self.stat_keys = list(self.spec.stat_keys)
         self.n_stats = len(self.stat_keys)
         self.n_cells = int(np.prod(self.map_shape))
@@ -110,6 +118,10 @@ class VecPcgrlEnv:
         self._done = torch.empty(N, dtype=torch.uint8, device=dev)
         self._stats = torch.empty((N, self.n_stats), dtype=torch.int32, device=dev)
         self._ptrs = (self._obs.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._stats.data_ptr())
+        # controllable mode / float64 rewards go through pcgrl_step_ex
+        self._reward64 = torch.empty(N, dtype=torch.float64, device=dev) if reward_dtype == torch.float64 else None
+        self._ctrl_obs = torch.zeros((N, 2 * len(self.controls)), dtype=torch.float32, device=dev) if self.controls else None
+        self._ex = self._reward64 is not None or self._ctrl_obs is not None
         if seeds is not None:
             self.seed(seeds)
 
@@ -153,17 +165,63 @@ class VecPcgrlEnv:
                                        g.data_ptr() if g is not None else None,
                                        p.data_ptr() if p is not None else None, self._stream()), "pcgrl_reset")
         _lib.check(self._L.pcgrl_observe(self._h, self._ptrs[0], self._stream()), "pcgrl_observe")
+        if self._ctrl_obs is not None:
+            _lib.check(self._L.pcgrl_ctrl_observe(self._h, self._ctrl_obs.data_ptr(), self._stream()), "pcgrl_ctrl_observe")
+            return self._obs, {"ctrl_obs": self._ctrl_obs}
         return self._obs, {}
 
     def step(self, actions):
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
-        rc = self._L.pcgrl_step(self._h, actions.data_ptr(), 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
-                                self._ptrs[2], self._ptrs[3], self._stream())
+        if self._ex:
+            rc = self._L.pcgrl_step_ex(
+                self._h, actions.data_ptr(), 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
+                self._reward64.data_ptr() if self._reward64 is not None else None, self._ptrs[2], self._ptrs[3],
+                self._ctrl_obs.data_ptr() if self._ctrl_obs is not None else None, self._stream())
+        else:
+            rc = self._L.pcgrl_step(self._h, actions.data_ptr(), 1 if self.auto_reset else 0, self._ptrs[0],
+                                    self._ptrs[1], self._ptrs[2], self._ptrs[3], self._stream())
         if rc:
             _lib.check(rc, "pcgrl_step")
         done = self._done.view(torch.bool)
-        return self._obs, self._reward, done, done, {"stats": self._stats}
+        info = {"stats": self._stats}
+        if self._ctrl_obs is not None:
+            info["ctrl_obs"] = self._ctrl_obs
+        return self._obs, (self._reward64 if self._reward64 is not None else self._reward), done, done, info
+
+    # -- controllable generation (control_wrappers.py:27-121) -----------------------------------------------------
+    def queue_targets(self, trgs, mask=None):
+        """ControlWrapper.set_trgs: `trgs` = {metric: scalar | (lo, hi) | tensor [N]}; the targets take effect at each
+        env's next reset (explicit or automatic), like the reference's _ctrl_trg_queue."""
+        if not self.controls:
+            raise ValueError("this env was built without `controls`")
+        N, dev = self.num_envs, self.device
+        lo = torch.zeros((N, self.n_stats), dtype=torch.float64, device=dev)
+        hi = torch.zeros((N, self.n_stats), dtype=torch.float64, device=dev)
+        for k, v in trgs.items():
+            if k not in self.controls:
+                raise ValueError(f"'{k}' is not a control metric of this env ({self.controls})")
+            j = self.stat_keys.index(k)
+            if isinstance(v, tuple):
+                a, b = target_interval(v)
+                lo[:, j], hi[:, j] = a, b
+            else:
+                t = torch.as_tensor(v, dtype=torch.float64, device=dev)
+                lo[:, j] = t
+                hi[:, j] = t
+        m = None if mask is None else torch.as_tensor(mask, device=dev).to(torch.uint8).contiguous()
+        _lib.check(self._L.pcgrl_queue_targets(self._h, m.data_ptr() if m is not None else None, lo.data_ptr(),
+                                               hi.data_ptr(), self._stream()), "pcgrl_queue_targets")
+
+    def sample_uniform_targets(self, generator=None, mask=None):
+        """UniformNoiseyTargets.set_rand_trgs (control_wrappers.py:453-460): each control target ~ U(cond_bounds)."""
+        trgs = {}
+        for k in self.controls:
+            lb, ub = self.spec.cond_bounds[k]
+            u = torch.rand(self.num_envs, generator=generator, device=self.device, dtype=torch.float64)
+            trgs[k] = u * (ub - lb) + lb
+        self.queue_targets(trgs, mask=mask)
+        return trgs
 
     def step_raw(self, actions_ptr, stream):
         """Lowest-overhead launch: device pointer of int32 actions + raw hipStream_t."""
@@ -221,7 +279,7 @@ def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
     object (attributes or dict keys): task.problem, task.map_shape, task.obs_window, task.weights,
     representation, max_board_scans, change_percentage."""
     unsupported = {
-        "controls": _cfg_get(cfg, "controls"), "act_window": _cfg_get(cfg, "act_window"),
+        "act_window": _cfg_get(cfg, "act_window"),
         "static_prob": _cfg_get(cfg, "static_prob"), "n_static_walls": _cfg_get(cfg, "n_static_walls"),
         "n_aux_tiles": _cfg_get(cfg, "n_aux_tiles", 0) or None,
         "show_agents": _cfg_get(cfg, "show_agents", False) or None,
@@ -235,4 +293,5 @@ def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
         map_shape=tuple(_cfg_get(cfg, "task.map_shape")), num_envs=num_envs, device=device,
         obs_window=_cfg_get(cfg, "task.obs_window"), weights=_cfg_get(cfg, "task.weights"),
         max_board_scans=_cfg_get(cfg, "max_board_scans", 3), change_percentage=_cfg_get(cfg, "change_percentage"),
-        seeds=seeds, auto_reset=auto_reset)
+        seeds=seeds, auto_reset=auto_reset, controls=_cfg_get(cfg, "controls"),
+        reward_dtype=torch.float64 if _cfg_get(cfg, "controls") else torch.float32)

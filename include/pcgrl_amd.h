@@ -68,6 +68,10 @@ typedef struct {
   double trg_lo[PCGRL_MAX_STATS];   /* inclusive target interval; scalar target t: lo = hi = t;        */
   double trg_hi[PCGRL_MAX_STATS];   /* tuple (a, b): [a, last of arange(a, b)] (control_wrappers.py:337) */
   int32_t solver_power;             /* sokoban solver iterations per stage (sokoban_prob.py:40) */
+  /* controllable generation (control_wrappers.py:27-121): ctrl_metrics observed and re-targeted per episode */
+  int32_t n_ctrl;                       /* len(cfg.controls), 0 = plain mode */
+  int32_t ctrl_idx[PCGRL_MAX_STATS];    /* stat column of each control metric, in cfg.controls order */
+  double ctrl_range[PCGRL_MAX_STATS];   /* param_ranges[k] = |cond_bounds[k][1] - cond_bounds[k][0]| (:70-73) */
 } pcgrl_config;
 
 typedef struct pcgrl_engine *pcgrl_handle;
@@ -91,6 +95,23 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
  * and the finished episode's return / length / final stats are latched for pcgrl_get_last_episode. */
 int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                uint8_t *d_done, int32_t *d_stats, void *stream);
+
+/* pcgrl_step with the extra outputs of the controllable mode (any pointer may be NULL):
+ *   d_reward64 double [N]         the reward in float64 (float targets make the loss non-integral)
+ *   d_ctrl_obs float [N][2*n_ctrl] observe_metric_trgs (control_wrappers.py:189-214): for control k, column 2k =
+ *                                 target / range, column 2k+1 = metric / range -- the values of the 2*n_ctrl constant
+ *                                 planes the reference prepends to the observation. */
+int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
+                  double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream);
+
+/* ControlWrapper.set_trgs (control_wrappers.py:168-172): queue per-env targets; they replace the env's targets at its
+ * next reset (explicit or automatic), exactly like the reference's _ctrl_trg_queue (:174-178).
+ * d_trg_lo / d_trg_hi: double [N][n_stats], inclusive interval per stat (lo == hi for a scalar target); only the
+ * control metrics' columns are used.  d_mask NULL = every env.  Requires cfg.n_ctrl > 0. */
+int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_trg_lo, const double *d_trg_hi,
+                        void *stream);
+/* the control observation of the current state (after reset): float [N][2*n_ctrl] */
+int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream);
 
 int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream);
 int64_t pcgrl_obs_bytes(pcgrl_handle h); /* bytes per env: prod(obs_shape) */

@@ -286,3 +286,95 @@ def test_gym_adapter_matches_golden():
         assert info["iterations"] == z["iterations"][t] and info["changes"] == z["changes"][t]
     with pytest.raises(IndexError):
         env.step(2)
+
+
+CONTROL = sorted(glob.glob(os.path.join(GOLDEN, "control_*.npz")))
+
+
+@pytest.mark.parametrize("path", CONTROL, ids=[os.path.basename(p)[8:-4] for p in CONTROL])
+def test_golden_controllable_episode_replay(path):
+    """Controllable generation against the reference's ControlWrapper(ctrl_metrics=...) trace: queued float targets
+    applied at reset, float64 reward (tolerance 1e-9: the reference's own sum order is a Python-set order), control
+    planes of the observation (float32 here, float64 in the reference: tolerance 1e-6)."""
+    z = np.load(path)
+    problem, rep = str(z["problem"]), str(z["representation"])
+    shape = tuple(int(s) for s in z["map_shape"])
+    controls = [str(c) for c in z["controls"]]
+    env = _vec(problem, rep, shape, 1, seeds=[int(z["seed"])], auto_reset=False, controls=controls,
+               reward_dtype=torch.float64)
+    n = int(z["steps_per_episode"])
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    t = 0
+    for ep in range(len(z["reset_at"])):
+        env.queue_targets({k: float(v) for k, v in zip(controls, z["reset_trg"][ep])})
+        obs, info = env.reset()
+        assert np.array_equal(env.get_state().stats[0].cpu().numpy(), z["reset_stats"][ep])
+        assert zlib.crc32(obs[0].cpu().numpy().tobytes()) == int(z["reset_obs_crc"][ep])
+        assert np.allclose(info["ctrl_obs"][0].cpu().numpy(), z["reset_ctrl"][ep], rtol=1e-6, atol=1e-7)
+        for _ in range(n):
+            obs, rew, done, _, info = env.step(acts[t:t + 1])
+            assert np.array_equal(info["stats"][0].cpu().numpy(), z["stats"][t]), f"stats @ {t}"
+            assert abs(float(rew[0]) - z["reward"][t]) <= 1e-9, f"reward @ {t}"
+            assert zlib.crc32(obs[0].cpu().numpy().tobytes()) == int(z["obs_crc"][t])
+            assert np.allclose(info["ctrl_obs"][0].cpu().numpy(), z["ctrl"][t], rtol=1e-6, atol=1e-7), f"ctrl @ {t}"
+            t += 1
+    env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep,shape,controls", [("binary", "narrow", (16, 16), ["regions", "path-length"]),
+                                                        ("zelda", "turtle", (16, 16), ["nearest-enemy", "path-length"]),
+                                                        ("minecraft_3D_maze", "narrow", (7, 7, 7), ["n_jump", "path-length"])])
+def test_controllable_batch_vs_oracle(problem, rep, shape, controls):
+    """random per-env targets re-drawn for every episode (what UniformNoiseyTargets does), auto-reset, vs the oracle"""
+    n = 257
+    T = 2 * (int(np.prod(shape)) * 3 + 2) + 25
+    seeds = 31 + np.arange(n)
+    env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=True, controls=controls, reward_dtype=torch.float64)
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, controls=controls, threads=8)
+    rng = np.random.default_rng(0)
+    bounds = po.cond_bounds(problem, shape)
+
+    def draw():
+        return {k: rng.random(n) * (bounds[k][1] - bounds[k][0]) + bounds[k][0] for k in controls}
+
+    trg = draw()
+    env.queue_targets({k: torch.as_tensor(v) for k, v in trg.items()})
+    orc.queue_targets(trg)
+    obs, info = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.reset())
+    assert np.allclose(info["ctrl_obs"].cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7)
+    g = torch.Generator().manual_seed(1)
+    for t in range(T):
+        if t % 97 == 0:  # keep fresh targets queued: they apply whenever an env resets
+            trg = draw()
+            env.queue_targets({k: torch.as_tensor(v) for k, v in trg.items()})
+            orc.queue_targets(trg)
+        a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a.to(env.device))
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=(t % 50 == 0))
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy() - orew)) <= 1e-9, f"reward @ {t}"
+        assert np.array_equal(done.cpu().numpy(), odone)
+        assert np.allclose(info["ctrl_obs"].cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), f"ctrl @ {t}"
+        if t % 50 == 0:
+            assert np.array_equal(obs.cpu().numpy(), oobs)
+    env.check_errors()
+
+
+def test_gym_adapter_controllable_planes():
+    from types import SimpleNamespace as NS
+    from control_pcgrl_amd import make_env
+    z = np.load(os.path.join(GOLDEN, "control_binary_narrow_s7.npz"))
+    cfg = NS(representation="narrow", max_board_scans=3, change_percentage=None, controls=["regions", "path-length"],
+             task=NS(problem="binary", map_shape=(16, 16), obs_window=(32, 32), weights={"path-length": 1, "regions": 1}),
+             multiagent=NS(n_agents=0))
+    env = make_env(cfg)
+    env.unwrapped.seed(int(z["seed"]))
+    env.set_trgs({"regions": float(z["reset_trg"][0][0]), "path-length": float(z["reset_trg"][0][1])})
+    obs, _ = env.reset()
+    assert obs.shape == (32, 32, 7) and env.observation_space.shape == (32, 32, 7)
+    assert np.allclose(obs[5, 9, :4], z["reset_ctrl"][0], rtol=1e-6) and np.all(obs[..., :4] == obs[0, 0, :4])
+    for t in range(20):
+        obs, r, d, _, _ = env.step(int(z["action"][t]))
+        assert abs(r - z["reward"][t]) <= 1e-9
+        assert np.allclose(obs[0, 0, :4], z["ctrl"][t], rtol=1e-6)
