@@ -73,6 +73,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            build()  # in-tree build of the HIP extension (never a CPU fallback)
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "

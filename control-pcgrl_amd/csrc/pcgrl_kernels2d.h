@@ -120,7 +120,8 @@ struct Grp {
       r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, true);
       if constexpr (LPE < 16) r = row == 0 ? 0u : r;
     } else {
-      r = (uint32_t)__shfl_up((int)v, 1, 64);
+      // gfx9 DPP wave shift: one lane across the whole wavefront (crosses the 16-lane DPP rows)
+      r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
       r = row == 0 ? 0u : r;
     }
     return r;
@@ -131,7 +132,7 @@ struct Grp {
       r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xF, 0xF, true);
       if constexpr (LPE < 16) r = row == LPE - 1 ? 0u : r;
     } else {
-      r = (uint32_t)__shfl_down((int)v, 1, 64);
+      r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
       r = row == LPE - 1 ? 0u : r;
     }
     return r;
