@@ -142,7 +142,9 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   }
   if (c.ndim != 2) return fail(PCGRL_EINVAL, "2-D problem needs ndim == 2");
   const int H = c.dims[0], W = c.dims[1];
-  if (H < 1 || W < 1 || H > 64 || W > 32) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 32");
+  if (H < 1 || W < 1 || H > 64 || W > 64) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 64");
+  if (W > 32 && H <= 16) return fail(PCGRL_EUNSUPPORTED, "maps wider than 32 need more than 16 rows (64-bit row-mask kernels)");
+  if (W > 32 && c.problem == PCGRL_PROB_SOKOBAN) return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32");
   lpe = H <= 8 ? 8 : (H <= 16 ? 16 : (H <= 32 ? 32 : 64));
   if (c.representation == PCGRL_REP_WIDE) {
     if (c.obs_window[0] != H || c.obs_window[1] != W)
@@ -196,49 +198,63 @@ static std::vector<JumpEntry> make_jump_table(int H, int W, int last = -1) {
 // ---------------------------------------------------------------------------------------------- dispatch
 enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS };
 
-template <int PROB, int LPE>
+// LDS above the 64 KiB default needs an explicit opt-in per kernel (64x64 zelda rows are 1152 B x 65 = 74 KiB)
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <int PROB, int LPE, typename M>
 static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_t s) {
   const int epw = 64 / LPE;
   dim3 grid((p.n_envs + epw - 1) / epw), block(64);
   // compile-time specialised observation path: 16x16 map, 32x32 window (reference default obs_window = 2*map)
   const bool fast = p.cfg.representation != PCGRL_REP_WIDE && p.cfg.dims[0] == 16 && p.cfg.dims[1] == 16 &&
                     p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32;
+  hipError_t e = hipSuccess;
   switch (id) {
     case K_STEP:
-      if constexpr (LPE == 16) {
+      if constexpr (LPE == 16 && sizeof(M) == 4) {
         if (fast) {
-          hipLaunchKernelGGL((step_kernel<PROB, LPE, true>), grid, dim3(128), lds, s, p);
+          hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true>), grid, dim3(128), lds, s, p);
           break;
         }
       }
-      hipLaunchKernelGGL((step_kernel<PROB, LPE, false>), grid, dim3(128), lds, s, p);
+      if ((e = allow_lds(step_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false>), grid, dim3(128), lds, s, p);
       break;
-    case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE>), grid, block, 0, s, p); break;
+    case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
     case K_OBSERVE:
-      if constexpr (LPE == 16) {
+      if constexpr (LPE == 16 && sizeof(M) == 4) {
         if (fast) {
-          hipLaunchKernelGGL((observe_kernel<PROB, LPE, true>), grid, block, lds, s, p);
+          hipLaunchKernelGGL((observe_kernel<PROB, LPE, M, true>), grid, block, lds, s, p);
           break;
         }
       }
-      hipLaunchKernelGGL((observe_kernel<PROB, LPE, false>), grid, block, lds, s, p);
+      if ((e = allow_lds(observe_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((observe_kernel<PROB, LPE, M, false>), grid, block, lds, s, p);
       break;
-    case K_GET_STATE: hipLaunchKernelGGL((get_state_kernel<PROB, LPE>), grid, block, 0, s, p); break;
+    case K_GET_STATE: hipLaunchKernelGGL((get_state_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
     case K_LAST_EPISODE:
       hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
       break;
-    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE>), grid, block, 0, s, p); break;
+    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
   }
   return hipGetLastError();
 }
 
 template <int PROB>
 static hipError_t launch_p(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s) {
+  if (p.cfg.dims[1] > 32) {  // 64-bit row masks (W <= 64); validate() guarantees lpe >= 32 here
+    if (lpe == 32) return launch_pl<PROB, 32, uint64_t>(id, p, lds, s);
+    return launch_pl<PROB, 64, uint64_t>(id, p, lds, s);
+  }
   switch (lpe) {
-    case 8: return launch_pl<PROB, 8>(id, p, lds, s);
-    case 16: return launch_pl<PROB, 16>(id, p, lds, s);
-    case 32: return launch_pl<PROB, 32>(id, p, lds, s);
-    default: return launch_pl<PROB, 64>(id, p, lds, s);
+    case 8: return launch_pl<PROB, 8, uint32_t>(id, p, lds, s);
+    case 16: return launch_pl<PROB, 16, uint32_t>(id, p, lds, s);
+    case 32: return launch_pl<PROB, 32, uint32_t>(id, p, lds, s);
+    default: return launch_pl<PROB, 64, uint32_t>(id, p, lds, s);
   }
 }
 
@@ -317,7 +333,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   if (is3d)
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * M3_MAXW * sizeof(uint32_t)));  // [tile bits | path overlay bits]
   else
-    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * sizeof(uint32_t)));
+    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
   // [0..3] error flags; from int 64 on: per-workgroup phase-timing accumulators (PCGRL_PHASE_TIMING builds)

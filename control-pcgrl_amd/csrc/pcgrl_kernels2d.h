@@ -103,6 +103,15 @@ struct Pcg {
   }
 };
 
+// ------------------------------------------------------------------------------------------------ row-mask helpers
+// A map row is a bit mask M: uint32_t for W <= 32, uint64_t for W <= 64.
+__device__ inline int popc_m(uint32_t x) { return __popc(x); }
+__device__ inline int popc_m(uint64_t x) { return __popcll(x); }
+__device__ inline int ctz_m(uint32_t x) { return __builtin_ctz(x); }
+__device__ inline int ctz_m(uint64_t x) { return __builtin_ctzll(x); }
+__device__ inline uint32_t brev_m(uint32_t x) { return __brev(x); }
+__device__ inline uint64_t brev_m(uint64_t x) { return __brevll(x); }
+
 // ------------------------------------------------------------------------------------------------ lane groups
 template <int LPE>
 struct Grp {
@@ -137,6 +146,12 @@ struct Grp {
     }
     return r;
   }
+  __device__ inline uint64_t from_above(uint64_t v) const {
+    return (uint64_t)from_above((uint32_t)v) | ((uint64_t)from_above((uint32_t)(v >> 32)) << 32);
+  }
+  __device__ inline uint64_t from_below(uint64_t v) const {
+    return (uint64_t)from_below((uint32_t)v) | ((uint64_t)from_below((uint32_t)(v >> 32)) << 32);
+  }
   // this group's slice of a wave ballot
   __device__ inline uint64_t gballot(bool p) const {
     uint64_t b = __ballot(p);
@@ -166,42 +181,43 @@ struct Grp {
 
 // 4-neighbour dilation of a row-mask set (without the set itself; callers AND with the passable mask,
 // which also removes the bit shifted past column W-1)
-template <int LPE>
-__device__ inline uint32_t expand(const Grp<LPE> &g, uint32_t f) {
+template <int LPE, typename M>
+__device__ inline M expand(const Grp<LPE> &g, M f) {
   return (f << 1) | (f >> 1) | g.from_above(f) | g.from_below(f);
 }
 
 // first set cell in row-major order: one bit in one lane of the group (0 everywhere if the set is empty)
-template <int LPE>
-__device__ inline uint32_t first_rowmajor(const Grp<LPE> &g, uint32_t x) {
+template <int LPE, typename M>
+__device__ inline M first_rowmajor(const Grp<LPE> &g, M x) {
   uint64_t gb = g.gballot(x != 0);
   int fl = gb ? __builtin_ctzll(gb) : -1;
-  return g.row == fl ? (x & (0u - x)) : 0u;
+  return g.row == fl ? (x & (M(0) - x)) : M(0);
 }
 
 // all cells of the horizontal runs of `a` that contain a bit of s (s subset of a): carry-propagation fill
-__device__ inline uint32_t hfill(uint32_t s, uint32_t a) {
-  uint32_t up = (a & ~(a + s)) | s;
-  uint32_t ar = __brev(a), sr = __brev(s);
-  uint32_t dn = __brev((ar & ~(ar + sr)) | sr);
+template <typename M>
+__device__ inline M hfill(M s, M a) {
+  M up = (a & ~(a + s)) | s;
+  M ar = brev_m(a), sr = brev_m(s);
+  M dn = brev_m((ar & ~(ar + sr)) | sr);
   return up | dn;
 }
 
 // helper.py:200-210 calc_num_regions: number of 4-connected components of `avail`.
 // Components are peeled off in row-major order of their first cell; each fill alternates an O(1) horizontal
 // run fill with a one-row vertical step until it stops growing.
-template <int LPE>
-__device__ inline int count_regions(const Grp<LPE> &g, uint32_t avail) {
-  uint32_t remaining = avail;
+template <int LPE, typename M>
+__device__ inline int count_regions(const Grp<LPE> &g, M avail) {
+  M remaining = avail;
   int n = 0;
   while (true) {
     uint64_t gb = g.gballot(remaining != 0);
     if (__ballot(gb != 0) == 0) break;
     int fl = gb ? __builtin_ctzll(gb) : -1;
-    uint32_t f = g.row == fl ? (remaining & (0u - remaining)) : 0u;
+    M f = g.row == fl ? (remaining & (M(0) - remaining)) : M(0);
     f = hfill(f, remaining);
     while (true) {
-      uint32_t v = (g.from_above(f) | g.from_below(f)) & remaining & ~f;
+      M v = (g.from_above(f) | g.from_below(f)) & remaining & ~f;
       if (__ballot(v != 0) == 0) break;
       f = hfill(f | v, remaining);
     }
@@ -228,18 +244,18 @@ __device__ inline int count_regions(const Grp<LPE> &g, uint32_t avail) {
 // row masks per env -- `fars` and `best` (last frontier of the sweep that produced the current path-length) -- and on a
 // change re-runs the first sweep only inside the affected component(s); the second sweep runs from the new far cells
 // only, unless a component that attained the old maximum was touched (then from all far cells).
-template <int LPE>
-__device__ inline uint32_t component_fars(const Grp<LPE> &g, uint32_t comps) {
-  const uint32_t iso = comps & ~expand(g, comps);
-  uint32_t remaining = comps & ~iso, fars = iso;
+template <int LPE, typename M>
+__device__ inline M component_fars(const Grp<LPE> &g, M comps) {
+  const M iso = comps & ~expand(g, comps);
+  M remaining = comps & ~iso, fars = iso;
   while (true) {
     uint64_t gb = g.gballot(remaining != 0);
     if (__ballot(gb != 0) == 0) break;
     int fl = gb ? __builtin_ctzll(gb) : -1;
-    uint32_t seed = g.row == fl ? (remaining & (0u - remaining)) : 0u;
-    uint32_t front = seed, vis = seed, last = seed;
+    M seed = g.row == fl ? (remaining & (M(0) - remaining)) : M(0);
+    M front = seed, vis = seed, last = seed;
     while (true) {
-      uint32_t nb = expand(g, front) & remaining & ~vis;
+      M nb = expand(g, front) & remaining & ~vis;
       uint64_t bb = __ballot(nb != 0);
       if (bb == 0) break;
       vis |= nb;
@@ -252,13 +268,13 @@ __device__ inline uint32_t component_fars(const Grp<LPE> &g, uint32_t comps) {
   return fars;
 }
 
-template <int LPE>
-__device__ inline void eccentricity(const Grp<LPE> &g, uint32_t src, uint32_t pass, int &len, uint32_t &last) {
-  uint32_t front = src, vis = src;
+template <int LPE, typename M>
+__device__ inline void eccentricity(const Grp<LPE> &g, M src, M pass, int &len, M &last) {
+  M front = src, vis = src;
   len = 0;
-  last = 0;
+  last = M(0);
   while (true) {
-    uint32_t nb = expand(g, front) & pass & ~vis;
+    M nb = expand(g, front) & pass & ~vis;
     uint64_t bb = __ballot(nb != 0);
     if (bb == 0) break;
     const bool ga = g.gslice(bb) != 0;
@@ -269,11 +285,11 @@ __device__ inline void eccentricity(const Grp<LPE> &g, uint32_t src, uint32_t pa
   }
 }
 
-template <int LPE>
-__device__ inline uint32_t flood(const Grp<LPE> &g, uint32_t seed, uint32_t avail) {
-  uint32_t f = hfill(seed & avail, avail);
+template <int LPE, typename M>
+__device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
+  M f = hfill(seed & avail, avail);
   while (true) {
-    uint32_t v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
+    M v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
     if (__ballot(v != 0) == 0) break;
     f = hfill(f | v, avail);
   }
@@ -281,35 +297,35 @@ __device__ inline uint32_t flood(const Grp<LPE> &g, uint32_t seed, uint32_t avai
 }
 
 // from scratch (reset / stats_for_grids)
-template <int LPE>
-__device__ inline void binary_stats_full(const Grp<LPE> &g, uint32_t pass, int &regions, int &path_len, uint32_t &fars,
-                                         uint32_t &best) {
+template <int LPE, typename M>
+__device__ inline void binary_stats_full(const Grp<LPE> &g, M pass, int &regions, int &path_len, M &fars,
+                                         M &best) {
   fars = component_fars(g, pass);
-  regions = (int)g.gsum((uint32_t)__popc(fars));
+  regions = (int)g.gsum((uint32_t)popc_m(fars));
   eccentricity(g, fars, pass, path_len, best);
 }
 
 // after editing the single cell `x` (row mask, 0 for groups without a change): old passable set p_old, new p_new
-template <int LPE>
-__device__ inline void binary_stats_update(const Grp<LPE> &g, uint32_t x, uint32_t p_old, uint32_t p_new, int &regions,
-                                           int &path_len, uint32_t &fars, uint32_t &best PHASE_ARG) {
+template <int LPE, typename M>
+__device__ inline void binary_stats_update(const Grp<LPE> &g, M x, M p_old, M p_new, int &regions,
+                                           int &path_len, M &fars, M &best PHASE_ARG) {
   const bool became_pass = g.gany((x & p_new) != 0);
   // cells of the affected components in the NEW map: the merged component of x, or the old component of x minus x
-  uint32_t K = flood(g, x, became_pass ? p_new : p_old);
+  M K = flood(g, x, became_pass ? p_new : p_old);
   K = became_pass ? K : (K & ~x);
-  const uint32_t touched = K | x;
+  const M touched = K | x;
   const bool hit = g.gany((best & touched) != 0);
   PHASE_MARK(3);  // flood
-  const uint32_t newfars = component_fars(g, K);
+  const M newfars = component_fars(g, K);
   PHASE_MARK(4);  // first sweeps
   fars = (fars & ~touched) | newfars;
   const bool changed = g.gany(x != 0);
   int l;
-  uint32_t b;
+  M b;
   eccentricity(g, hit ? fars : newfars, p_new, l, b);
   PHASE_MARK(5);  // second sweep
   if (changed) {
-    regions = (int)g.gsum((uint32_t)__popc(fars));
+    regions = (int)g.gsum((uint32_t)popc_m(fars));
     if (hit || l > path_len) {
       path_len = l;
       best = b;
@@ -321,20 +337,20 @@ __device__ inline void binary_stats_update(const Grp<LPE> &g, uint32_t x, uint32
 
 // helper.py:225-240 run_dijkstra from a single source, reduced to "distance to the first target cell":
 // level k >= 1 at which the frontier first meets targetA / targetB, or -1 if the frontier dies first.
-template <int LPE>
-__device__ inline void bfs_first_hit(const Grp<LPE> &g, uint32_t src, uint32_t avail, uint32_t targetA, uint32_t targetB,
+template <int LPE, typename M>
+__device__ inline void bfs_first_hit(const Grp<LPE> &g, M src, M avail, M targetA, M targetB,
                                      int &dA, int &dB) {
-  uint32_t front = src & avail, vis = front;
+  M front = src & avail, vis = front;
   bool needA = g.gany(targetA != 0), needB = g.gany(targetB != 0);
   dA = -1;
   dB = -1;
   int lev = 0;
   while (true) {
-    uint32_t nb = expand(g, front) & avail & ~vis;
+    M nb = expand(g, front) & avail & ~vis;
     bool alive = g.gany(nb != 0) && (needA || needB);
     if (__ballot(alive) == 0) break;
     lev++;
-    nb = alive ? nb : 0u;
+    nb = alive ? nb : M(0);
     vis |= nb;
     front = nb;
     bool hitA = g.gany((nb & targetA) != 0), hitB = g.gany((nb & targetB) != 0);
@@ -378,14 +394,13 @@ template <int LPE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
 
-template <int PROB, int LPE>
-__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, uint32_t *b,
-                                     uint32_t colmask, int32_t *st) {
+template <int PROB, int LPE, typename M>
+__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, M colmask, int32_t *st) {
   if constexpr (PROB == PCGRL_PROB_BINARY) {
     // binary_prob.py:152-158: regions and path-length over "empty" (tile 0); b[1], b[2] receive fars / best
-    uint32_t pass = active ? (~b[0] & colmask) : 0u;
+    M pass = active ? (~b[0] & colmask) : M(0);
     int reg, len;
-    uint32_t fars, best;
+    M fars, best;
     binary_stats_full(g, pass, reg, len, fars, best);
     st[0] = reg;
     st[1] = len;
@@ -395,12 +410,12 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     }
   } else if constexpr (PROB == PCGRL_PROB_ZELDA) {
     // zelda_ctrl_prob.py:90-168.  ids: 0 empty 1 solid 2 player 3 key 4 door 5 bat 6 scorpion 7 spider
-    uint32_t cm = active ? colmask : 0u;
-    uint32_t solid = b[0] & ~b[1] & ~b[2] & cm, door = ~b[0] & ~b[1] & b[2] & cm;
-    uint32_t player = ~b[0] & b[1] & ~b[2] & cm, key = b[0] & b[1] & ~b[2] & cm, enemy = b[2] & (b[0] | b[1]) & cm;
-    uint32_t walk = cm & ~(solid | door), walkd = cm & ~solid;
-    uint32_t c01 = g.gsum((uint32_t)__popc(player) | ((uint32_t)__popc(key) << 16));
-    uint32_t c23 = g.gsum((uint32_t)__popc(door) | ((uint32_t)__popc(enemy) << 16));
+    M cm = active ? colmask : M(0);
+    M solid = b[0] & ~b[1] & ~b[2] & cm, door = ~b[0] & ~b[1] & b[2] & cm;
+    M player = ~b[0] & b[1] & ~b[2] & cm, key = b[0] & b[1] & ~b[2] & cm, enemy = b[2] & (b[0] | b[1]) & cm;
+    M walk = cm & ~(solid | door), walkd = cm & ~solid;
+    uint32_t c01 = g.gsum((uint32_t)popc_m(player) | ((uint32_t)popc_m(key) << 16));
+    uint32_t c23 = g.gsum((uint32_t)popc_m(door) | ((uint32_t)popc_m(enemy) << 16));
     int n_player = c01 & 0xFFFF, n_key = c01 >> 16, n_door = c23 & 0xFFFF, n_enemy = c23 >> 16;
     st[0] = n_player;
     st[1] = n_key;
@@ -413,10 +428,10 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     bool want_path = one_player && n_key == 1 && n_door == 1;
     if (__ballot(want_enemy || want_path) != 0) {
       int dE, dK, dD, dummy;
-      bfs_first_hit(g, (want_enemy || want_path) ? player : 0u, walk, want_enemy ? enemy : 0u, want_path ? key : 0u, dE, dK);
+      bfs_first_hit(g, (want_enemy || want_path) ? player : M(0), walk, want_enemy ? enemy : M(0), want_path ? key : M(0), dE, dK);
       if (want_enemy) nearest = dE > 0 ? dE : 0;
       if (__ballot(want_path) != 0) {
-        bfs_first_hit(g, want_path ? key : 0u, walkd, want_path ? door : 0u, 0u, dD, dummy);
+        bfs_first_hit(g, want_path ? key : M(0), walkd, want_path ? door : M(0), M(0), dD, dummy);
         if (want_path) plen = dK + dD;  // each term is -1 when unreachable
       }
     }
@@ -424,16 +439,19 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     st[6] = plen;
   } else {
     // sokoban_prob.py:160-180 + sokoban_ctrl_prob.py:58-65.  ids: 0 empty 1 solid 2 player 3 crate 4 target
-    uint32_t cm = active ? colmask : 0u;
-    uint32_t solid = b[0] & ~b[1] & ~b[2] & cm, player = ~b[0] & b[1] & ~b[2] & cm;
-    uint32_t crate = b[0] & b[1] & ~b[2] & cm, target = ~b[0] & ~b[1] & b[2] & cm;
-    uint32_t c01 = g.gsum((uint32_t)__popc(player) | ((uint32_t)__popc(crate) << 16));
-    int n_player = c01 & 0xFFFF, n_crate = c01 >> 16, n_target = (int)g.gsum((uint32_t)__popc(target));
+    M cm = active ? colmask : M(0);
+    M solid = b[0] & ~b[1] & ~b[2] & cm, player = ~b[0] & b[1] & ~b[2] & cm;
+    M crate = b[0] & b[1] & ~b[2] & cm, target = ~b[0] & ~b[1] & b[2] & cm;
+    uint32_t c01 = g.gsum((uint32_t)popc_m(player) | ((uint32_t)popc_m(crate) << 16));
+    int n_player = c01 & 0xFFFF, n_crate = c01 >> 16, n_target = (int)g.gsum((uint32_t)popc_m(target));
     int regions = count_regions(g, cm & ~solid);
     int dist_win = p.cfg.dims[0] * p.cfg.dims[1] * (p.cfg.dims[0] + p.cfg.dims[1]);
     int sol_len = 0;
     bool need = active && n_player == 1 && n_crate == n_target && n_crate > 0 && regions == 1;
-    if (__ballot(need) != 0) sokoban_solve(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
+    if (__ballot(need) != 0) {
+      if constexpr (sizeof(M) == 4) sokoban_solve(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
+      else if (need && g.row == 0) atomicOr(p.err, 2);  // the solver supports W <= 32
+    }
     st[0] = n_player;
     st[1] = n_crate;
     st[2] = n_target;
@@ -514,25 +532,25 @@ struct EnvTargets {
 };
 
 // ------------------------------------------------------------------------------------------------ tile <-> planes
-template <int NB>
-__device__ inline int tile_at(const uint32_t *b, int x) {
+template <int NB, typename M>
+__device__ inline int tile_at(const M *b, int x) {
   int t = 0;
 #pragma unroll
-  for (int k = 0; k < NB; k++) t |= (int)((b[k] >> x) & 1u) << k;
+  for (int k = 0; k < NB; k++) t |= (int)((b[k] >> x) & M(1)) << k;
   return t;
 }
-template <int NB>
-__device__ inline void set_tile(uint32_t *b, int x, int t) {
+template <int NB, typename M>
+__device__ inline void set_tile(M *b, int x, int t) {
 #pragma unroll
-  for (int k = 0; k < NB; k++) b[k] = (b[k] & ~(1u << x)) | ((uint32_t)((t >> k) & 1) << x);
+  for (int k = 0; k < NB; k++) b[k] = (b[k] & ~(M(1) << x)) | ((M)((t >> k) & 1) << x);
 }
 
 // ------------------------------------------------------------------------------------------------ reset (RNG)
 // envs/pcgrl_env.py:158-188 + reps/representation.py:65-76 + helper.py:491-494, :527-536.
 // Every lane of the group replays the env's problem-RNG draws; the map draws of the representation RNG are
 // split by row with an LCG skip-ahead so the 16 lanes generate their rows concurrently.
-template <int PROB, int LPE>
-__device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, uint32_t *b, int *pos,
+template <int PROB, int LPE, typename M>
+__device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, int *pos,
                                       bool commit = true) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
@@ -571,7 +589,7 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
 #pragma unroll
       for (int t = 0; t < NT; t++) idx += cdf[t] <= u ? 1 : 0;  // searchsorted(cdf, u, side='right')
 #pragma unroll
-      for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((idx >> k) & 1) << x;
+      for (int k = 0; k < NB; k++) b[k] |= (M)((idx >> k) & 1) << x;
     }
   }
   if (commit && g.row == 0) {
@@ -632,8 +650,8 @@ __device__ inline uint4 oob_chunk_rt(int q) {
 // FAST: map 16x16 with a 32x32 window (the reference's default obs_window = 2 * map_shape): every map row is
 // visible, every map cell lands inside the window, each lane writes exactly one map row and one all-OOB row,
 // and every loop bound is a compile-time constant.
-template <int PROB, int LPE, bool FAST>
-__device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, bool active, const uint32_t *b, const int *pos,
+template <int PROB, int LPE, bool FAST, typename M>
+__device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
                                   uint8_t *lds) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
@@ -644,7 +662,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     uint8_t *row = lds + g.lane * lds_row_stride(row_bytes);
     for (int q = 0; q < chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
     if (active && g.row < H) {
-      for (int x = 0; x < W; x++) row[x * NT + tile_at<NB>(b, x)] = 1;
+      for (int x = 0; x < W; x++) row[x * NT + tile_at<NB, M>(b, x)] = 1;
       uint8_t *dst = p.obs + ((size_t)env * H + g.row) * row_bytes;
       for (int q = 0; q < chunks; q++) store_obs16(dst + q * 16, *(uint4 *)(row + q * 16));
     }
@@ -677,7 +695,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     for (int x = 0; x < FW; x++) {
       int o = (x - left) * C;  // always inside the window when OW = 2 * W
       row[o] = 0;
-      row[o + 1 + tile_at<NB>(b, x)] = 1;
+      row[o + 1 + tile_at<NB, M>(b, x)] = 1;
     }
   } else {
     for (int q = 0; q < CH; q++) {
@@ -689,7 +707,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
         int j = x - left;
         if (j >= 0 && j < OW) {
           row[j * C] = 0;
-          row[j * C + 1 + tile_at<NB>(b, x)] = 1;
+          row[j * C + 1 + tile_at<NB, M>(b, x)] = 1;
         }
       }
   }
@@ -719,16 +737,16 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
 
 // ------------------------------------------------------------------------------------------------ kernels
 constexpr int ROW_WORDS = 3;  // words per map row in HBM: tile bit-planes (1 or 3) [+ fars, best for binary]
-template <int N>
-__device__ inline void load_planes(const Params &p, int env, int row, bool ok, uint32_t *b) {
-  const uint32_t *pl = (const uint32_t *)p.planes;
+template <int N, typename M>
+__device__ inline void load_planes(const Params &p, int env, int row, bool ok, M *b) {
+  const M *pl = (const M *)p.planes;
   const int H = p.cfg.dims[0];
 #pragma unroll
-  for (int k = 0; k < N; k++) b[k] = ok ? pl[((size_t)env * ROW_WORDS + k) * H + row] : 0u;
+  for (int k = 0; k < N; k++) b[k] = ok ? pl[((size_t)env * ROW_WORDS + k) * H + row] : M(0);
 }
-template <int N>
-__device__ inline void store_planes(const Params &p, int env, int row, bool ok, const uint32_t *b) {
-  uint32_t *pl = (uint32_t *)p.planes;
+template <int N, typename M>
+__device__ inline void store_planes(const Params &p, int env, int row, bool ok, const M *b) {
+  M *pl = (M *)p.planes;
   const int H = p.cfg.dims[0];
   if (ok) {
 #pragma unroll
@@ -737,8 +755,8 @@ __device__ inline void store_planes(const Params &p, int env, int row, bool ok, 
 }
 
 // reps/*.update(): returns change flag (uniform over the group); edits the owning lane's planes, updates pos/n_step
-template <int PROB, int LPE>
-__device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool active, int action, uint32_t *b, int *pos,
+template <int PROB, int LPE, typename M>
+__device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool active, int action, M *b, int *pos,
                                   int &n_step, bool &bad_action) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
@@ -764,8 +782,8 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
   bool mine = tile >= 0 && g.row == r;
   bool ch = false;
   if (mine) {
-    ch = tile_at<NB>(b, c) != tile;
-    set_tile<NB>(b, c, tile);
+    ch = tile_at<NB, M>(b, c) != tile;
+    set_tile<NB, M>(b, c, tile);
   }
   bool change = g.gany(ch);
   if (active && !bad_action) {
@@ -793,7 +811,7 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
 //   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
 // The two never exchange data: the observation depends only on the post-action grid and position, not on the
 // statistics, so the BFS latency chain and the LDS/HBM-store chain overlap instead of adding up.
-template <int PROB, int LPE, bool FAST>
+template <int PROB, int LPE, typename M, bool FAST>
 __global__ __launch_bounds__(128) void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
@@ -807,14 +825,14 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   const int env = blockIdx.x * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
   const bool rowok = active && g.row < H;
-  const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
+  const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
   const int e = active ? env : 0;
 
-  uint32_t b[NW];
+  M b[NW];
   if (observer)
-    load_planes<NB>(p, e, g.row, rowok, b);
+    load_planes<NB, M>(p, e, g.row, rowok, b);
   else
-    load_planes<NW>(p, e, g.row, rowok, b);
+    load_planes<NW, M>(p, e, g.row, rowok, b);
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
@@ -822,20 +840,20 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   // both waves have read the old state before wave 0 may overwrite it
   if (p.obs != nullptr) __syncthreads();
   PHASE_MARK(0);  // loads + barrier
-  const uint32_t tile0_old = b[0];
+  const M tile0_old = b[0];
 
   // envs/pcgrl_env.py:267-342
   bool bad = false;
   iteration++;
-  bool change = rep_update<PROB, LPE>(g, p, active, action, b, pos, n_step, bad);
+  bool change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
   changes += change ? 1 : 0;
   bool done = iteration > p.cfg.max_iterations;
   if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
   const bool do_reset = active && done && p.auto_reset != 0;
 
   if (observer) {
-    if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE>(g, p, e, do_reset, b, pos, /*commit=*/false);
-    encode_obs<PROB, LPE, FAST>(g, p, e, active, b, pos, lds);
+    if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/false);
+    encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
     return;
   }
 
@@ -849,9 +867,9 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   if (__ballot(change) != 0) {
     if constexpr (PROB == PCGRL_PROB_BINARY) {
       // incremental: only the component(s) touching the edited cell are re-swept
-      const uint32_t x = change ? (tile0_old ^ b[0]) & colmask : 0u;
+      const M x = change ? (tile0_old ^ b[0]) & colmask : M(0);
       int reg = st[0], len = st[1];
-      uint32_t fars = b[1], best = b[2];
+      M fars = b[1], best = b[2];
       binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS);
       if (change) {
         st[0] = reg;
@@ -861,7 +879,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
       }
     } else {
       int32_t ns[NS];
-      compute_stats<PROB, LPE>(g, p, e, change, b, colmask, ns);
+      compute_stats<PROB, LPE, M>(g, p, e, change, b, colmask, ns);
       if (change) {
 #pragma unroll
         for (int k = 0; k < NS; k++) st[k] = ns[k];
@@ -894,9 +912,9 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
 #pragma unroll
       for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
     }
-    reset_from_rng<PROB, LPE>(g, p, e, do_reset, b, pos);
+    reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos);
     int32_t ns[NS];
-    compute_stats<PROB, LPE>(g, p, e, do_reset, b, colmask, ns);
+    compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
     if (do_reset) {
 #pragma unroll
       for (int k = 0; k < NS; k++) st[k] = ns[k];
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
     }
   }
   // write back state
-  if (change || do_reset) store_planes<NW>(p, e, g.row, rowok, b);
+  if (change || do_reset) store_planes<NW, M>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
     trg.write_ctrl_obs(p, e, st);
     trg.commit(p, e);
@@ -929,7 +947,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   PHASE_FLUSH();
 }
 
-template <int PROB, int LPE>
+template <int PROB, int LPE, typename M>
 __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -941,10 +959,10 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   const int e = inb ? env : 0;
   const bool active = inb && (p.mask == nullptr || p.mask[e] != 0);
   const bool rowok = active && g.row < H;
-  const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
+  const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;
   EnvState *S = &p.st[e];
-  uint32_t b[NW];
+  M b[NW];
   int pos[2] = {0, 0};
 #pragma unroll
   for (int k = 0; k < NW; k++) b[k] = 0;
@@ -954,7 +972,7 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
       for (int x = 0; x < W; x++) {
         int t = src[x];
 #pragma unroll
-        for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((t >> k) & 1) << x;
+        for (int k = 0; k < NB; k++) b[k] |= (M)((t >> k) & 1) << x;
       }
     }
     if (p.init_pos && p.cfg.representation != PCGRL_REP_WIDE) {
@@ -962,11 +980,11 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
       pos[1] = p.init_pos[(size_t)e * 3 + 1];
     }
   } else {
-    reset_from_rng<PROB, LPE>(g, p, e, active, b, pos);
+    reset_from_rng<PROB, LPE, M>(g, p, e, active, b, pos);
   }
   int32_t st[NS];
-  compute_stats<PROB, LPE>(g, p, e, active, b, colmask, st);
-  store_planes<NW>(p, e, g.row, rowok, b);
+  compute_stats<PROB, LPE, M>(g, p, e, active, b, colmask, st);
+  store_planes<NW, M>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
@@ -1011,7 +1029,7 @@ __global__ __launch_bounds__(64) void queue_targets_kernel(Params p, const doubl
   p.trg_flag[env] = 1;
 }
 
-template <int PROB, int LPE, bool FAST>
+template <int PROB, int LPE, typename M, bool FAST>
 __global__ __launch_bounds__(64) void observe_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, EPW = 64 / LPE;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1021,13 +1039,13 @@ __global__ __launch_bounds__(64) void observe_kernel(Params p) {
   const bool active = env < p.n_envs;
   const int e = active ? env : 0;
   const bool rowok = active && g.row < p.cfg.dims[0];
-  uint32_t b[NB];
-  load_planes<NB>(p, e, g.row, rowok, b);
+  M b[NB];
+  load_planes<NB, M>(p, e, g.row, rowok, b);
   int pos[2] = {p.st[e].pos[0], p.st[e].pos[1]};
-  encode_obs<PROB, LPE, FAST>(g, p, e, active, b, pos, lds);
+  encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
 }
 
-template <int PROB, int LPE>
+template <int PROB, int LPE, typename M>
 __global__ __launch_bounds__(64) void get_state_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   Grp<LPE> g;
@@ -1037,10 +1055,10 @@ __global__ __launch_bounds__(64) void get_state_kernel(Params p) {
   if (env >= p.n_envs) return;
   const EnvState *S = &p.st[env];
   if (p.out_grids && g.row < H) {
-    uint32_t b[NB];
-    load_planes<NB>(p, env, g.row, true, b);
+    M b[NB];
+    load_planes<NB, M>(p, env, g.row, true, b);
     uint8_t *dst = p.out_grids + ((size_t)env * H + g.row) * W;
-    for (int x = 0; x < W; x++) dst[x] = (uint8_t)tile_at<NB>(b, x);
+    for (int x = 0; x < W; x++) dst[x] = (uint8_t)tile_at<NB, M>(b, x);
   }
   if (g.row == 0) {
     if (p.out_pos) {
@@ -1075,7 +1093,7 @@ __global__ __launch_bounds__(64) void last_episode_kernel(Params p) {
 }
 
 // Problem.get_stats on caller-provided byte grids (no engine state)
-template <int PROB, int LPE>
+template <int PROB, int LPE, typename M>
 __global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   Grp<LPE> g;
@@ -1085,8 +1103,8 @@ __global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
   const bool active = env < p.n_envs;
   const int e = active ? env : 0;
   const bool rowok = active && g.row < H;
-  const uint32_t colmask = rowok ? (W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u)) : 0u;
-  uint32_t b[NB + ProbTraits<PROB>::NAUX];
+  const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
+  M b[NB + ProbTraits<PROB>::NAUX];
 #pragma unroll
   for (int k = 0; k < NB + ProbTraits<PROB>::NAUX; k++) b[k] = 0;
   if (rowok) {
@@ -1094,11 +1112,11 @@ __global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
     for (int x = 0; x < W; x++) {
       int t = src[x];
 #pragma unroll
-      for (int k = 0; k < NB; k++) b[k] |= (uint32_t)((t >> k) & 1) << x;
+      for (int k = 0; k < NB; k++) b[k] |= (M)((t >> k) & 1) << x;
     }
   }
   int32_t st[NS];
-  compute_stats<PROB, LPE>(g, p, e, active, b, colmask, st);
+  compute_stats<PROB, LPE, M>(g, p, e, active, b, colmask, st);
   if (active && g.row == 0)
     for (int k = 0; k < NS; k++) p.stats_out[(size_t)e * NS + k] = st[k];
 }

@@ -378,3 +378,17 @@ def test_gym_adapter_controllable_planes():
         obs, r, d, _, _ = env.step(int(z["action"][t]))
         assert abs(r - z["reward"][t]) <= 1e-9
         assert np.allclose(obs[0, 0, :4], z["ctrl"][t], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (32, 64), (48, 40), (20, 33)])
+def test_maps_wider_than_32_vs_oracle(shape):
+    """64-bit row masks (reference task configs binary_bigger / zelda_bigger are 64x64 with a 128x128 window);
+    change_percentage keeps episodes short so the RNG reset path is crossed several times."""
+    ow = (2 * shape[0], 128 if shape[1] > 32 else 64)
+    _rollout_vs_oracle("binary", "narrow", shape, 19, 400, full_every=57, obs_window=ow, change_percentage=0.01)
+    _rollout_vs_oracle("zelda", "turtle", shape, 11, 300, full_every=43, obs_window=ow, change_percentage=0.01)
+    _rollout_vs_oracle("binary", "turtle", shape, 7, 150, full_every=31, obs_window=ow, change_percentage=0.02)
+
+
+def test_binary_bigger_wide_vs_oracle():
+    _rollout_vs_oracle("binary", "wide", (64, 64), 5, 200, full_every=19, change_percentage=0.01)
