@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's)")
     ap.add_argument("--workload", default="binary-narrow", choices=sorted(ALGO_BYTES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-steps", type=int, default=0,
+                    help="launch the step kernel through a captured HIP graph of this many steps (0 = eager launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -85,11 +87,36 @@ def main():
     base, stride = actions.data_ptr(), N * 4
     step_raw = env.step_raw
 
-    def run(n):
-        for k in range(n):
+    def run_eager(n, first=0):
+        for k in range(first, first + n):
             rc = step_raw(base + (k % POOL) * stride, sptr)
             if rc:
                 raise RuntimeError(f"pcgrl_step rc={rc}")
+
+    # The launch-bound inner loop is captured once in a HIP graph of G consecutive steps (each node = one pcgrl_step
+    # launch with its own action row) and replayed; K steps = K // G replays + K % G eager launches.  G = 125 is
+    # coprime with the narrow scan period (256 cells), so every cell keeps receiving fresh random actions.
+    G = max(0, args.graph_steps)
+    graph = None
+    if G > 0:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                cap = torch.cuda.current_stream(dev).cuda_stream
+                for k in range(G):
+                    rc = step_raw(base + (k % POOL) * stride, cap)
+                    if rc:
+                        raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
+        stream.wait_stream(side)
+
+    def run(n):
+        if graph is None:
+            return run_eager(n)
+        for _ in range(n // G):
+            graph.replay()
+        run_eager(n % G, first=G)
 
     run(W)
     # warm the reporting path too (first use loads torch's reduction kernels), then start from clean accumulators
@@ -132,7 +159,8 @@ def main():
             "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, uniform random actions, auto-reset, "
                                    "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
-                       "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)"},
+                       "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)",
+                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(args.workload, N),
                          "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -79,8 +79,11 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or control_pcgrl_amd._lib.build()).  There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        override = os.environ.get("PCGRL_LIB")  # development: load another build of the same ABI (A/B timing)
+        L = C.CDLL(override or LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if override and not hasattr(L, name):
+                continue
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -53,12 +53,6 @@ struct Params {
   const JumpEntry *jump;  // [H+1]: skip by row*W draws; entry H = H*W draws
   int32_t *err;           // device error word
   void *soko;             // SokoPool* (sokoban solver workspace), else null
-  // controllable mode (cfg.n_ctrl > 0): per-env target intervals, [N][PCGRL_MAX_STATS][2] = (lo, hi)
-  double *trg;            // active targets (null in plain mode: cfg.trg_lo/hi apply to every env)
-  double *trg_pending;    // queued by pcgrl_queue_targets, applied at the env's next reset
-  int32_t *trg_flag;      // [N] 1 = pending targets waiting
-  double *reward64;       // per-call outputs of pcgrl_step_ex
-  float *ctrl_obs;
   // per-call I/O
   const int32_t *actions;
   uint8_t *obs;
@@ -77,6 +71,12 @@ struct Params {
   double *out_ep_return;
   int32_t *out_ep_len;
   int64_t *out_n_episodes;
+  // controllable mode (cfg.n_ctrl > 0): per-env target intervals, [N][PCGRL_MAX_STATS][2] = (lo, hi)
+  double *trg;            // active targets (null in plain mode: cfg.trg_lo/hi apply to every env)
+  double *trg_pending;    // queued by pcgrl_queue_targets, applied at the env's next reset
+  int32_t *trg_flag;      // [N] 1 = pending targets waiting
+  double *reward64;       // per-call outputs of pcgrl_step_ex
+  float *ctrl_obs;
 };
 
 }  // namespace pcgrl

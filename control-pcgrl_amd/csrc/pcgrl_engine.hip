@@ -217,12 +217,20 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
     case K_STEP:
       if constexpr (LPE == 16 && sizeof(M) == 4) {
         if (fast) {
-          hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true>), grid, dim3(128), lds, s, p);
+          if (p.trg || p.reward64)
+            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128), lds, s, p);
+          else
+            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128), lds, s, p);
           break;
         }
       }
-      if ((e = allow_lds(step_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false>), grid, dim3(128), lds, s, p);
+      if (p.trg || p.reward64) {
+        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, true>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, true>), grid, dim3(128), lds, s, p);
+      } else {
+        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, false>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128), lds, s, p);
+      }
       break;
     case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
     case K_OBSERVE:

@@ -462,6 +462,19 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
   }
 }
 
+// control_wrappers.py:318-345 get_loss against the config's static targets (plain mode: all operands are kernel arguments)
+template <int NS>
+__device__ inline double get_loss(const pcgrl_config &c, const int32_t *st) {
+  double loss = 0.0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    double v = (double)st[k];
+    double d = v < c.trg_lo[k] ? c.trg_lo[k] - v : (v > c.trg_hi[k] ? v - c.trg_hi[k] : 0.0);
+    loss += c.has_trg[k] ? (-d) * c.weights[k] : 0.0;
+  }
+  return loss;
+}
+
 // Target intervals of one env.  Plain mode: the config's static targets.  Controllable mode (control_wrappers.py:27-121):
 // per-env targets in HBM; targets queued by pcgrl_queue_targets replace the control metrics' targets at the env's next
 // reset (:174-178), which is when `take_pending` is set.
@@ -811,7 +824,7 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
 //   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
 // The two never exchange data: the observation depends only on the post-action grid and position, not on the
 // statistics, so the BFS latency chain and the LDS/HBM-store chain overlap instead of adding up.
-template <int PROB, int LPE, typename M, bool FAST>
+template <int PROB, int LPE, typename M, bool FAST, bool CTRL>
 __global__ __launch_bounds__(128) void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
@@ -888,16 +901,24 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   }
   PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
-  EnvTargets<NS> trg;
-  trg.load(p, e, false);
-  double loss = trg.loss(p.cfg, st);
+  // CTRL (controllable mode) is a compile-time variant so that the plain kernel carries none of its code
+  EnvTargets<CTRL ? NS : 1> trg;
+  double loss;
+  if constexpr (!CTRL) {
+    loss = get_loss<NS>(p.cfg, st);
+  } else {
+    trg.load(p, e, false);
+    loss = trg.loss(p.cfg, st);
+  }
   double rew = loss - last_loss;
   last_loss = loss;
   ep_return += rew;
   ep_len++;
   if (active && g.row == 0) {
     if (p.reward) p.reward[e] = (float)rew;
-    if (p.reward64) p.reward64[e] = rew;
+    if constexpr (CTRL) {
+      if (p.reward64) p.reward64[e] = rew;
+    }
     if (p.done) p.done[e] = done ? 1 : 0;
     if (p.stats_out) {
 #pragma unroll
@@ -923,15 +944,21 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
       n_step = 0;
       ep_len = 0;
       ep_return = 0.0;
-      trg.load(p, e, true);  // queued control targets take effect with the new episode
-      last_loss = trg.loss(p.cfg, st);
+      if constexpr (!CTRL) {
+        last_loss = get_loss<NS>(p.cfg, st);
+      } else {
+        trg.load(p, e, true);  // queued control targets take effect with the new episode
+        last_loss = trg.loss(p.cfg, st);
+      }
     }
   }
   // write back state
   if (change || do_reset) store_planes<NW, M>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
-    trg.write_ctrl_obs(p, e, st);
-    trg.commit(p, e);
+    if constexpr (CTRL) {
+      trg.write_ctrl_obs(p, e, st);
+      trg.commit(p, e);
+    }
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
     S->n_step = n_step;
