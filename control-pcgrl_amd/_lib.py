@@ -38,6 +38,8 @@ SYMBOLS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_queue_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_ctrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_refresh_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_obs_bytes": (C.c_int64, [C.c_void_p]),
     "pcgrl_obs_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 4), C.POINTER(C.c_int32)]),
@@ -59,7 +61,7 @@ def build(force=False, verbose=False):
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-falign-loops=32", "-fPIC", "-shared",
            "-o", LIB_PATH, os.path.join(CSRC, "pcgrl_engine.hip")]
     if verbose:
         print(" ".join(cmd))

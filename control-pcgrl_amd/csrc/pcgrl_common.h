@@ -60,6 +60,8 @@ struct Params {
   uint8_t *done;
   int32_t *stats_out;
   int32_t auto_reset;
+  int32_t update_only;   // pcgrl_update: representation update + observation only (no counters, stats, reward)
+  int32_t refresh_only;  // pcgrl_refresh_stats: recompute the stats of the current maps (reset kernel without a new map)
   const uint8_t *mask;
   const uint8_t *init_grids;
   const int32_t *init_pos;

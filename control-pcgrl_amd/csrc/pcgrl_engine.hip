@@ -433,6 +433,25 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   return PCGRL_OK;
 }
 
+int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void *stream) {
+  if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_update: bad arguments");
+  Params p = h->p;
+  p.actions = d_actions;
+  p.obs = d_obs;
+  p.update_only = 1;
+  HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_refresh_stats(pcgrl_handle h, int32_t *d_stats, void *stream) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_refresh_stats: null handle");
+  Params p = h->p;
+  p.refresh_only = 1;
+  p.stats_out = d_stats;
+  HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
 int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_trg_lo, const double *d_trg_hi, void *stream) {
   if (!h || !d_trg_lo || !d_trg_hi) return fail(PCGRL_EINVAL, "pcgrl_queue_targets: bad arguments");
   if (h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_queue_targets: the engine was created without control metrics");

@@ -857,11 +857,12 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
 
   // envs/pcgrl_env.py:267-342
   bool bad = false;
-  iteration++;
+  const bool upd_only = p.update_only != 0;  // evolution-driver pattern: rep.update() without PcgrlEnv.step()
+  iteration += upd_only ? 0 : 1;
   bool change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
-  changes += change ? 1 : 0;
-  bool done = iteration > p.cfg.max_iterations;
-  if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
+  changes += (change && !upd_only) ? 1 : 0;
+  bool done = !upd_only && iteration > p.cfg.max_iterations;
+  if (p.cfg.max_changes >= 0) done = done || (!upd_only && changes > p.cfg.max_changes);
   const bool do_reset = active && done && p.auto_reset != 0;
 
   if (observer) {
@@ -877,6 +878,15 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
   if (bad && g.row == 0 && active) atomicOr(p.err, 1);
   PHASE_MARK(1);  // action + second state loads
+  if (upd_only) {  // grid / position only; stats (and the binary fars/best masks) are rebuilt by pcgrl_refresh_stats
+    if (change) store_planes<NB, M>(p, e, g.row, rowok, b);
+    if (active && g.row == 0) {
+      S->pos[0] = pos[0];
+      S->pos[1] = pos[1];
+      S->n_step = n_step;
+    }
+    return;
+  }
   if (__ballot(change) != 0) {
     if constexpr (PROB == PCGRL_PROB_BINARY) {
       // incremental: only the component(s) touching the edited cell are re-swept
@@ -993,7 +1003,9 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   int pos[2] = {0, 0};
 #pragma unroll
   for (int k = 0; k < NW; k++) b[k] = 0;
-  if (p.init_grids) {  // inject: bytes -> planes (envs/pcgrl_ctrl_env.py:12-14 set_map)
+  if (p.refresh_only) {  // keep map, position and counters: only the statistics are recomputed from scratch
+    load_planes<NB, M>(p, e, g.row, rowok, b);
+  } else if (p.init_grids) {  // inject: bytes -> planes (envs/pcgrl_ctrl_env.py:12-14 set_map)
     if (rowok) {
       const uint8_t *src = p.init_grids + ((size_t)e * H + g.row) * W;
       for (int x = 0; x < W; x++) {
@@ -1012,6 +1024,19 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   int32_t st[NS];
   compute_stats<PROB, LPE, M>(g, p, e, active, b, colmask, st);
   store_planes<NW, M>(p, e, g.row, rowok, b);
+  if (p.refresh_only) {
+    if (active && g.row == 0) {
+      EnvTargets<NS> trg;
+      trg.load(p, e, false);
+      S->last_loss = trg.loss(p.cfg, st);
+#pragma unroll
+      for (int k = 0; k < NS; k++) {
+        S->stats[k] = st[k];
+        if (p.stats_out) p.stats_out[(size_t)e * NS + k] = st[k];
+      }
+    }
+    return;
+  }
   if (active && g.row == 0) {
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];

@@ -450,6 +450,20 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
 
   if constexpr (MODE == M3_RESET) {
     if (p.mask != nullptr && p.mask[env] == 0) return;
+    if (p.refresh_only) {  // statistics (and the path overlay) of the current map, nothing else
+      uint64_t air0 = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
+      m3_stats(L, c, air0, st, ovf PHASE_PASS);
+      if (ovf && c.lane == 0) atomicOr(p.err, 4);
+      for (int i = c.lane; i < c.nw; i += 64) gd[M3_MAXW + i] = L.over[i];
+      if (c.lane == 0) {
+        S->last_loss = trg.loss(p.cfg, st);
+        for (int k = 0; k < NS; k++) {
+          S->stats[k] = st[k];
+          if (p.stats_out) p.stats_out[(size_t)env * NS + k] = st[k];
+        }
+      }
+      return;
+    }
     if (p.init_grids) {
       for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
       const uint8_t *src = p.init_grids + (size_t)env * c.n_cells;
@@ -472,7 +486,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
     const int action = p.actions[env];
     const bool bad = action < 0 || action >= 2;
-    iteration++;
+    const bool upd_only = p.update_only != 0;
+    iteration += upd_only ? 0 : 1;
     bool change = false;
     if (!bad) {
       const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
@@ -486,6 +501,17 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       n_step++;
     } else if (c.lane == 0) {
       atomicOr(p.err, 1);
+    }
+    if (upd_only) {  // rep.update() only: map, position, observation (with the stale overlay)
+      m3_encode_obs(L, c, p, env, pos, true);
+      for (int i = c.lane; i < c.nw; i += 64) gd[i] = L.dirt[i];
+      if (c.lane == 0) {
+        S->pos[0] = pos[0];
+        S->pos[1] = pos[1];
+        S->pos[2] = pos[2];
+        S->n_step = n_step;
+      }
+      return;
     }
     changes += change ? 1 : 0;
     bool done = iteration > p.cfg.max_iterations;

@@ -228,6 +228,20 @@ class VecPcgrlEnv:
         return self._L.pcgrl_step(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
                                   self._ptrs[2], self._ptrs[3], stream)
 
+    # -- evolution-driver pattern (evo/evolve.py:1083-1120): rep.update() many times, get_stats() once ---------------
+    def update(self, actions, want_obs=True):
+        """rep.update(action) for every env (+ observation); counters / stats / reward are untouched."""
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self._L.pcgrl_update(self._h, actions.data_ptr(), self._ptrs[0] if want_obs else None, self._stream()),
+                   "pcgrl_update")
+        return self._obs if want_obs else None
+
+    def refresh_stats(self):
+        """Problem.get_stats() of the current maps; returns int32 [N, n_stats]."""
+        _lib.check(self._L.pcgrl_refresh_stats(self._h, self._ptrs[3], self._stream()), "pcgrl_refresh_stats")
+        return self._stats
+
     def observe(self):
         _lib.check(self._L.pcgrl_observe(self._h, self._ptrs[0], self._stream()), "pcgrl_observe")
         return self._obs

@@ -113,6 +113,15 @@ int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_t
 /* the control observation of the current state (after reset): float [N][2*n_ctrl] */
 int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream);
 
+/* Evolution-driver pattern (evo/evolve.py:1083-1120): the representation is updated directly, PcgrlEnv.step() is not
+ * involved and the statistics are only computed at the end.
+ *   pcgrl_update         rep.update(action) for every env + the observation (d_obs may be NULL); iteration / changes
+ *                        counters, stats, reward and done are not touched
+ *   pcgrl_refresh_stats  Problem.get_stats() of the current maps -> engine state (and d_stats int32 [N][n_stats] if
+ *                        non-NULL); also re-bases the loss so that later pcgrl_step rewards are consistent */
+int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void *stream);
+int pcgrl_refresh_stats(pcgrl_handle h, int32_t *d_stats, void *stream);
+
 int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream);
 int64_t pcgrl_obs_bytes(pcgrl_handle h); /* bytes per env: prod(obs_shape) */
 int pcgrl_obs_shape(pcgrl_handle h, int32_t shape_out[4], int32_t *ndim_out);

@@ -631,6 +631,26 @@ void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t
   }
 }
 
+void orc_update(orc_engine *e, const int32_t *actions, uint8_t *obs) {
+  int64_t osz = orc_obs_size(e);
+  for (int i = 0; i < e->n_envs; i++) {
+    env_t *v = &e->envs[i];
+    (void)rep_update(e, v, actions[i]);
+    if (obs) encode_obs(e, v, obs + (size_t)i * osz, 1);
+  }
+}
+
+void orc_refresh_stats(orc_engine *e, int32_t *stats) {
+  const orc_config *cfg = &e->cfg;
+  for (int i = 0; i < e->n_envs; i++) {
+    env_t *v = &e->envs[i];
+    get_stats(cfg, v->grid, v->stats, v->path_xyz, &v->path_len);
+    v->last_loss = get_loss(cfg, v, v->stats);
+    if (stats)
+      for (int k = 0; k < cfg->n_stats; k++) stats[(size_t)i * cfg->n_stats + k] = v->stats[k];
+  }
+}
+
 void orc_observe(orc_engine *e, uint8_t *obs) {
   int64_t osz = orc_obs_size(e);
   for (int i = 0; i < e->n_envs; i++) encode_obs(e, &e->envs[i], obs + (size_t)i * osz, 0);

@@ -65,6 +65,10 @@ void orc_reset(orc_engine *e, const uint8_t *mask, const uint8_t *init_grids, co
 void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t *obs, double *reward,
               uint8_t *done, int32_t *stats);
 
+/* evolution-driver pattern (evo/evolve.py:1083-1120): rep.update only, then get_stats once */
+void orc_update(orc_engine *e, const int32_t *actions, uint8_t *obs);
+void orc_refresh_stats(orc_engine *e, int32_t *stats);
+
 void orc_observe(orc_engine *e, uint8_t *obs);
 int64_t orc_obs_size(const orc_engine *e); /* bytes per env */
 

@@ -125,6 +125,8 @@ def lib():
         L.orc_stats_for_grids.argtypes = [C.POINTER(OrcConfig), C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_queue_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_get_ctrl_obs.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_refresh_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -232,6 +234,17 @@ class OracleVecEnv:
         if obs is not None:
             obs = obs.reshape((self.n,) + self.obs_shape)
         return obs, rew, done.astype(bool), stats
+
+    def update(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        obs = np.empty((self.n, self.obs_size), np.uint8)
+        lib().orc_update(self.h, a.ctypes.data, obs.ctypes.data)
+        return obs.reshape((self.n,) + self.obs_shape)
+
+    def refresh_stats(self):
+        stats = np.empty((self.n, self.n_stats), np.int32)
+        lib().orc_refresh_stats(self.h, stats.ctypes.data)
+        return stats
 
     def get_state(self):
         grids = np.empty((self.n, self.n_cells), np.uint8)

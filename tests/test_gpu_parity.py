@@ -392,3 +392,34 @@ def test_maps_wider_than_32_vs_oracle(shape):
 
 def test_binary_bigger_wide_vs_oracle():
     _rollout_vs_oracle("binary", "wide", (64, 64), 5, 200, full_every=19, change_percentage=0.01)
+
+
+@pytest.mark.parametrize("problem,rep,shape", [("binary", "narrow", (16, 16)), ("zelda", "turtle", (16, 16)),
+                                               ("sokoban", "wide", (16, 16)), ("minecraft_3D_maze", "narrow", (7, 7, 7))])
+def test_update_then_refresh_stats_vs_oracle(problem, rep, shape):
+    """evolution-driver pattern (evo/evolve.py:1083-1120): rep.update() K times without PcgrlEnv.step(), then
+    get_stats() once; afterwards normal steps (incl. the incremental binary statistics) must still agree."""
+    n = 150
+    seeds = 5 + np.arange(n)
+    env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=False)
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds)
+    env.reset(); orc.reset()
+    g = torch.Generator().manual_seed(3)
+    for t in range(60):
+        a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        obs = env.update(a.to(env.device))
+        oobs = orc.update(a.numpy())
+        if t % 13 == 0:
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+    st0 = env.get_state()
+    assert int(st0.iteration.max()) == 0 and int(st0.changes.max()) == 0  # counters untouched
+    assert np.array_equal(env.refresh_stats().cpu().numpy(), orc.refresh_stats())
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    for t in range(40):
+        a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a.to(env.device))
+        oobs, orew, odone, ostats = orc.step(a.numpy())
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy() - orew)) <= REW_TOL
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    env.check_errors()
