@@ -19,7 +19,7 @@ G = os.path.join(ROOT, "gpurun_out")
 
 def first(pattern):
     hits = glob.glob(os.path.join(G, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None  # gpurun merges into gpurun_out: newest run wins
 
 
 def short(name):
