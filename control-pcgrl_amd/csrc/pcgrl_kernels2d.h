@@ -170,6 +170,17 @@ struct Grp {
     if constexpr (LPE >= 64) v += (uint32_t)__shfl_xor((int)v, 32, 64);
     return v;
   }
+  // max over the group's lanes (result in every lane), same butterfly as gsum
+  __device__ inline uint32_t gmax(uint32_t v) const {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+    if constexpr (LPE >= 16) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+    if constexpr (LPE >= 32) v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+    if constexpr (LPE >= 64) v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+    return v;
+  }
+  __device__ inline uint32_t gmin(uint32_t v) const { return ~gmax(~v); }
   // this group's slice of an already computed wave ballot
   __device__ inline uint64_t gslice(uint64_t b) const {
     if constexpr (LPE == 64) return b;
@@ -216,8 +227,10 @@ __device__ inline int count_regions(const Grp<LPE> &g, M avail) {
     int fl = gb ? __builtin_ctzll(gb) : -1;
     M f = g.row == fl ? (remaining & (M(0) - remaining)) : M(0);
     f = hfill(f, remaining);
-    while (true) {
+    while (true) {  // two rounds per trip: one ballot + branch per two vertical steps
       M v = (g.from_above(f) | g.from_below(f)) & remaining & ~f;
+      f = hfill(f | v, remaining);
+      v = (g.from_above(f) | g.from_below(f)) & remaining & ~f;
       if (__ballot(v != 0) == 0) break;
       f = hfill(f | v, remaining);
     }
@@ -245,6 +258,49 @@ __device__ inline int count_regions(const Grp<LPE> &g, M avail) {
 // change re-runs the first sweep only inside the affected component(s); the second sweep runs from the new far cells
 // only, unless a component that attained the old maximum was touched (then from all far cells).
 template <int LPE, typename M>
+__device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
+  M f = hfill(seed & avail, avail);
+  while (true) {  // two rounds per trip
+    M v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
+    f = hfill(f | v, avail);
+    v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
+    if (__ballot(v != 0) == 0) break;
+    f = hfill(f | v, avail);
+  }
+  return f;
+}
+
+// Level-synchronous BFS of every group from `src` inside `avail`.  Per group: the number of levels (eccentricity of the
+// source set) and the last non-empty frontier.  The loop does SWEEP_UNROLL levels per trip and carries no cross-lane
+// state: every lane only remembers the deepest level at which IT received new cells and those cells; the group's depth
+// is a DPP max-reduction after the loop.  One ballot + branch per trip instead of per level shortens the dependent
+// chain that bounds the launch at small batches (a frontier that died stays empty, so testing the trip's last level
+// is enough).
+constexpr int SWEEP_UNROLL = 4;
+template <int LPE, typename M>
+__device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &last, M &visited) {
+  M front = src & avail;
+  M free_cells = avail & ~front;
+  M mynb = M(0);
+  int mylev = 0, lev = 0;
+  while (true) {
+#pragma unroll
+    for (int u = 0; u < SWEEP_UNROLL; u++) {
+      const M nb = expand(g, front) & free_cells;
+      free_cells ^= nb;
+      lev++;
+      mylev = nb ? lev : mylev;
+      mynb = nb ? nb : mynb;
+      front = nb;
+    }
+    if (__ballot(front != 0) == 0) break;
+  }
+  len = (int)g.gmax((uint32_t)mylev);
+  last = (len > 0 && mylev == len) ? mynb : M(0);
+  visited = avail & ~free_cells;
+}
+
+template <int LPE, typename M>
 __device__ inline M component_fars(const Grp<LPE> &g, M comps) {
   const M iso = comps & ~expand(g, comps);
   M remaining = comps & ~iso, fars = iso;
@@ -253,15 +309,10 @@ __device__ inline M component_fars(const Grp<LPE> &g, M comps) {
     if (__ballot(gb != 0) == 0) break;
     int fl = gb ? __builtin_ctzll(gb) : -1;
     M seed = g.row == fl ? (remaining & (M(0) - remaining)) : M(0);
-    M front = seed, vis = seed, last = seed;
-    while (true) {
-      M nb = expand(g, front) & remaining & ~vis;
-      uint64_t bb = __ballot(nb != 0);
-      if (bb == 0) break;
-      vis |= nb;
-      front = nb;
-      last = g.gslice(bb) ? nb : last;  // groups whose frontier died keep their last non-empty level
-    }
+    int depth;
+    M last, vis;
+    sweep(g, seed, remaining, depth, last, vis);
+    // non-isolated components always reach level 1, so `last` is empty only for groups without a seed
     fars |= first_rowmajor(g, last);
     remaining &= ~vis;
   }
@@ -270,30 +321,8 @@ __device__ inline M component_fars(const Grp<LPE> &g, M comps) {
 
 template <int LPE, typename M>
 __device__ inline void eccentricity(const Grp<LPE> &g, M src, M pass, int &len, M &last) {
-  M front = src, vis = src;
-  len = 0;
-  last = M(0);
-  while (true) {
-    M nb = expand(g, front) & pass & ~vis;
-    uint64_t bb = __ballot(nb != 0);
-    if (bb == 0) break;
-    const bool ga = g.gslice(bb) != 0;
-    vis |= nb;
-    front = nb;
-    len += ga;
-    last = ga ? nb : last;
-  }
-}
-
-template <int LPE, typename M>
-__device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
-  M f = hfill(seed & avail, avail);
-  while (true) {
-    M v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
-    if (__ballot(v != 0) == 0) break;
-    f = hfill(f | v, avail);
-  }
-  return f;
+  M vis;
+  sweep(g, src, pass, len, last, vis);
 }
 
 // from scratch (reset / stats_for_grids)
@@ -340,29 +369,31 @@ __device__ inline void binary_stats_update(const Grp<LPE> &g, M x, M p_old, M p_
 template <int LPE, typename M>
 __device__ inline void bfs_first_hit(const Grp<LPE> &g, M src, M avail, M targetA, M targetB,
                                      int &dA, int &dB) {
-  M front = src & avail, vis = front;
-  bool needA = g.gany(targetA != 0), needB = g.gany(targetB != 0);
-  dA = -1;
-  dB = -1;
-  int lev = 0;
+  constexpr uint32_t NONE = 0xFFFFu;
+  M front = src & avail;
+  M free_cells = avail & ~front;
+  const bool needA = g.gany(targetA != 0), needB = g.gany(targetB != 0);
+  uint32_t myA = NONE, myB = NONE;  // first level at which THIS lane's new cells meet the target
+  uint32_t lev = 0;
   while (true) {
-    M nb = expand(g, front) & avail & ~vis;
-    bool alive = g.gany(nb != 0) && (needA || needB);
-    if (__ballot(alive) == 0) break;
-    lev++;
-    nb = alive ? nb : M(0);
-    vis |= nb;
-    front = nb;
-    bool hitA = g.gany((nb & targetA) != 0), hitB = g.gany((nb & targetB) != 0);
-    if (needA && hitA) {
-      dA = lev;
-      needA = false;
+#pragma unroll
+    for (int u = 0; u < SWEEP_UNROLL; u++) {
+      const M nb = expand(g, front) & free_cells;
+      free_cells ^= nb;
+      lev++;
+      myA = ((nb & targetA) != 0 && myA == NONE) ? lev : myA;
+      myB = ((nb & targetB) != 0 && myB == NONE) ? lev : myB;
+      front = nb;
     }
-    if (needB && hitB) {
-      dB = lev;
-      needB = false;
-    }
+    // a group is finished when its frontier died or every target it looks for has been met
+    const bool alive = g.gany(front != 0);
+    const bool foundA = g.gany(myA != NONE), foundB = g.gany(myB != NONE);
+    const bool pending = alive && ((needA && !foundA) || (needB && !foundB));
+    if (__ballot(pending) == 0) break;
   }
+  const uint32_t a = g.gmin(myA), b = g.gmin(myB);
+  dA = (needA && a != NONE) ? (int)a : -1;
+  dB = (needB && b != NONE) ? (int)b : -1;
 }
 
 // ------------------------------------------------------------------------------------------------ per-problem stats
