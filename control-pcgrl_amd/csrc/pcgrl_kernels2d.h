@@ -276,7 +276,7 @@ __device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
 // is a DPP max-reduction after the loop.  One ballot + branch per trip instead of per level shortens the dependent
 // chain that bounds the launch at small batches (a frontier that died stays empty, so testing the trip's last level
 // is enough).
-constexpr int SWEEP_UNROLL = 4;
+constexpr int SWEEP_UNROLL = 6;
 template <int LPE, typename M>
 __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &last, M &visited) {
   M front = src & avail;
@@ -816,9 +816,10 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
       break;
     default: {  // wrappers.py:304-323 ActionMap + wide_rep.py:40-45: row = x = (a / NT) % W, col = y = a / (W*NT)
       bad_action = action < 0 || action >= H * W * NT;
-      tile = action % NT;
-      r = (action / NT) % W;
-      c = action / (W * NT);
+      tile = action % NT;  // NT is a compile-time constant
+      const int cell = action / NT;
+      c = (int)(((float)cell + 0.5f) * (1.0f / (float)W));
+      r = cell - c * W;
       break;
     }
   }
@@ -832,9 +833,11 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
   bool change = g.gany(ch);
   if (active && !bad_action) {
     if (p.cfg.representation == PCGRL_REP_NARROW) {  // Q1: position advances with the pre-increment index
-      int idx = n_step % (H * W);
-      pos[0] = idx / W;
-      pos[1] = idx % W;
+      // floor((x + 0.5) / d) in fp32 is exact for x < 2^20: avoids two ~40-instruction integer divisions
+      const int q = (int)(((float)n_step + 0.5f) * (1.0f / (float)(H * W)));
+      const int idx = n_step - q * (H * W);
+      pos[0] = (int)(((float)idx + 0.5f) * (1.0f / (float)W));
+      pos[1] = idx - pos[0] * W;
       n_step++;
     } else if (p.cfg.representation == PCGRL_REP_TURTLE) {
       if (action < 4) {  // _dirs = [(-1,0),(1,0),(0,-1),(0,1)] on (row, col), clamped
