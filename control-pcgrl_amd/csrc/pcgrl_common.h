@@ -44,7 +44,6 @@ struct Params {
   pcgrl_config cfg;
   int32_t n_envs;
   int32_t n_tiles;
-  int32_t n_bits;
   int32_t n_cells;
   int32_t obs_chunks;  // 16-byte chunks per observation row
   void *planes;

@@ -315,7 +315,6 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   p.cfg = *cfg;
   p.n_envs = n_envs;
   p.n_tiles = n_tiles_of(cfg->problem);
-  p.n_bits = p.n_tiles <= 2 ? 1 : 3;
   const bool is3d = cfg->problem == PCGRL_PROB_MC3DMAZE;
   p.n_cells = cfg->dims[0] * cfg->dims[1] * (is3d ? cfg->dims[2] : 1);
   p.obs_chunks = obs_chunks;
@@ -555,7 +554,6 @@ int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_g
   p.cfg = c;
   p.n_envs = n;
   p.n_tiles = n_tiles_of(c.problem);
-  p.n_bits = p.n_tiles <= 2 ? 1 : 3;
   p.n_cells = c.dims[0] * c.dims[1];
   p.init_grids = d_grids;
   p.stats_out = d_stats;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV outputs (gpurun_out/prof_*) into small tracked summaries under profiles/.
 
-  python tools/summarize_profiles.py r01
+  python tools/summarize_profiles.py r01 [outdir]
+(on the GPU box: outdir = gpurun_out/summary, then delete the raw traces -- gpurun only copies back 64 MiB)
 writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim top rows) and
 profiles/<tag>_summary.json (per-kernel durations, PMC counters per launch, derived HBM traffic).
 """
@@ -26,13 +27,15 @@ def short(name):
     return name.split("(")[0].replace("void ", "")[:60]
 
 
-def main(tag):
+def main(tag, outdir=None):
+    outdir = outdir or os.path.join(ROOT, "profiles")
+    os.makedirs(outdir, exist_ok=True)
     out = {"tag": tag, "source": "rocprofv3 on python3 bench.py (binary-narrow 16x16, 4096 envs, 1 MI355X)"}
     ks = first("prof_kt/**/*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
         keep = [r for r in rows if "pcgrl" in r["Name"]]
-        with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        with open(os.path.join(outdir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=rows[0].keys())
             w.writeheader()
             for r in keep:
@@ -74,10 +77,10 @@ def main(tag):
             "write_bytes_raw": wr, "write_calibration_factor": wcal, "fetch_bytes_raw": rd,
             "fetch_bytes_x2_correction": 2 * rd, "traffic_bytes": (wr * (wcal or 1.0)) + 2 * rd,
             "algorithmic_bytes": 4096 * 3348}
-    with open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w") as f:
+    with open(os.path.join(outdir, f"{tag}_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else None)
