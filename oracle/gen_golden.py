@@ -486,3 +486,92 @@ if __name__ == "__main__" and "control" in sys.argv[1:]:
     run_control_episode("zelda_turtle", ["nearest-enemy", "path-length"], 8)
     run_control_episode("sokoban_wide", ["crate", "sol-length"], 9)
     run_control_episode("binary_wide", ["path-length"], 10)
+
+
+# ------------------------------------------------------------------ representation wrappers
+EXT_CONFIGS = {
+    # name: (base config, static_prob, n_static_walls, act_window)
+    "binary_narrow_sp30": ("binary_narrow", 0.3, None, None),
+    "binary_turtle_sw3": ("binary_turtle", None, 3, None),
+    "zelda_narrow_sp10_sw3": ("zelda_narrow", 0.1, 3, None),
+    "zelda_turtle_sp50_sw7": ("zelda_turtle", 0.5, 7, None),
+    "sokoban_narrow_sp10_sw5": ("sokoban_narrow", 0.1, 5, None),
+    "binary_narrow_aw3x3": ("binary_narrow", None, None, [3, 3]),
+    "binary_narrow_aw4x4": ("binary_narrow", None, None, [4, 4]),
+    "binary_narrow_aw16x1": ("binary_narrow", None, None, [16, 1]),
+    "binary_narrow_aw16x16": ("binary_narrow", None, None, [16, 16]),
+    "zelda_narrow_aw2x2_sp10_sw3": ("zelda_narrow", 0.1, 3, [2, 2]),
+    "binary_narrow_aw4x4_sw5": ("binary_narrow", 0, 5, [4, 4]),
+}
+
+
+def run_ext_episode(name, seed, n_eps=4, n_steps=160):
+    """StaticTileRepresentation / MultiActionRepresentation (envs/reps/wrappers.py:234-376, :397-545) through
+    make_env(cfg): n_eps episodes of n_steps random actions, explicit reset() between them (the spare half of the
+    representation RNG's 32-bit buffer carries over between episodes, so several resets are needed to pin it)."""
+    base, sp, sw, aw = EXT_CONFIGS[name]
+    problem, rep, shape = CONFIGS[base]
+    cfg = ref_env.make_cfg(problem, rep, shape)
+    cfg.static_prob, cfg.n_static_walls, cfg.act_window = sp, sw, aw
+    cfg.static_tile_wrapper = sp is not None or sw is not None  # rl/utils.py:308
+    env = ref_env.make_reference_env(cfg, seed=seed)
+    core = env.unwrapped
+    sp_space = env.action_space
+    n_tiles = len(core._prob.get_tile_types())
+    A = int(np.prod(aw)) if aw is not None else 1
+    n_act = n_tiles if aw is not None else int(sp_space.n)
+    arng = np.random.default_rng(4000 + seed)
+    rec = dict(action=[], grid=[], pos=[], stats=[], reward=[], done=[], changes=[], obs_crc=[])
+    resets = dict(at=[], grid=[], pos=[], stats=[], static=[], obs=[], obs_crc=[])
+    full = {}
+    t = 0
+
+    def static_now():
+        r = core._rep
+        while not hasattr(r, "static_tiles") and hasattr(r, "rep"):
+            r = r.rep
+        if hasattr(r, "static_tiles"):
+            return np.asarray(r.static_tiles, np.uint8).copy()
+        return np.zeros(tuple(s + 2 for s in shape), np.uint8)
+
+    for ep in range(n_eps):
+        obs, _ = env.reset()
+        u = obs_u8(obs)
+        resets["at"].append(t); resets["grid"].append(core._rep.unwrapped._map.astype(np.uint8).ravel().copy())
+        resets["pos"].append(np.array(core._rep.unwrapped._pos, np.int64).copy())
+        resets["stats"].append(stats_vec(problem, core._rep_stats)); resets["static"].append(static_now().ravel())
+        resets["obs"].append(u.ravel().copy()); resets["obs_crc"].append(zlib.crc32(u.tobytes()))
+        for k in range(n_steps):
+            a = arng.integers(n_act, size=A)
+            obs, r, d, tr, info = env.step(a if aw is not None else int(a[0]))
+            u = obs_u8(obs)
+            rec["action"].append(a.astype(np.int32)); rec["grid"].append(core._rep.unwrapped._map.astype(np.uint8).ravel().copy())
+            rec["pos"].append(np.array(core._rep.unwrapped._pos, np.int64).copy())
+            rec["stats"].append(stats_vec(problem, core._rep_stats)); rec["reward"].append(float(r))
+            rec["done"].append(bool(d)); rec["changes"].append(int(info["changes"]))
+            rec["obs_crc"].append(zlib.crc32(u.tobytes()))
+            if k in (0, 1, 2, n_steps - 1):
+                full[t] = u.ravel().copy()
+            t += 1
+    keep = sorted(full)
+    out = dict(problem=problem, representation=rep, map_shape=np.array(shape), seed=seed,
+               static_prob=np.float64(-1 if sp is None else sp), n_static_walls=np.int32(-1 if sw is None else sw),
+               act_window=np.array(aw if aw is not None else [0, 0], np.int32), steps_per_episode=n_steps,
+               stat_keys=np.array(STAT_KEYS[problem]), obs_shape=np.array(u.shape),
+               action=np.array(rec["action"], np.int32), grid=np.array(rec["grid"], np.uint8),
+               pos=np.array(rec["pos"], np.int16), stats=np.array(rec["stats"], np.int32),
+               reward=np.array(rec["reward"], np.float64), done=np.array(rec["done"]),
+               changes=np.array(rec["changes"], np.int32), obs_crc=np.array(rec["obs_crc"], np.uint32),
+               obs_steps=np.array(keep, np.int32), obs_full=np.array([full[k] for k in keep], np.uint8),
+               reset_at=np.array(resets["at"], np.int32), reset_grid=np.array(resets["grid"], np.uint8),
+               reset_pos=np.array(resets["pos"], np.int16), reset_stats=np.array(resets["stats"], np.int32),
+               reset_static=np.array(resets["static"], np.uint8), reset_obs=np.array(resets["obs"], np.uint8),
+               reset_obs_crc=np.array(resets["obs_crc"], np.uint32))
+    path = os.path.join(OUT, f"ext_{name}_s{seed}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "T=", t, "ret=", sum(rec["reward"]), "changes", rec["changes"][-1])
+
+
+if __name__ == "__main__" and "ext" in sys.argv[1:]:
+    for i, name in enumerate(EXT_CONFIGS):
+        run_ext_episode(name, 21 + i)

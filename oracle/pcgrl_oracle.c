@@ -33,6 +33,8 @@ void orc_mc3d_stats(const uint8_t *grid, int Z, int Y, int X, int32_t *stats, in
 typedef unsigned __int128 u128;
 typedef struct {
   u128 state, inc;
+  int has32;      /* spare high half of the last 64-bit draw (pcg64_next32) */
+  uint32_t val32;
 } pcg64;
 
 #define PCG_MULT ((((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL)
@@ -84,6 +86,8 @@ static void pcg64_seed(pcg64 *r, uint64_t seed) {
   u128 initstate = ((u128)w[0] << 64) | w[1];
   u128 initseq = ((u128)w[2] << 64) | w[3];
   r->state = 0;
+  r->has32 = 0;
+  r->val32 = 0;
   r->inc = (initseq << 1) | 1;
   r->state = r->state * PCG_MULT + r->inc;
   r->state += initstate;
@@ -99,6 +103,37 @@ static inline uint64_t pcg64_next(pcg64 *r) {
 }
 
 static inline double pcg64_double(pcg64 *r) { return (double)(pcg64_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+
+/* numpy/random/src/pcg64/pcg64.h pcg64_next32: a 64-bit draw serves two 32-bit requests, low half first; the
+ * spare half survives any number of next64/next_double calls in between. */
+static inline uint32_t pcg64_next32(pcg64 *r) {
+  if (r->has32) {
+    r->has32 = 0;
+    return r->val32;
+  }
+  uint64_t n = pcg64_next(r);
+  r->has32 = 1;
+  r->val32 = (uint32_t)(n >> 32);
+  return (uint32_t)n;
+}
+
+/* Generator.integers(low, high) for a scalar int64 request whose range fits 32 bits: numpy/random/src/distributions/
+ * distributions.c random_bounded_uint64 -> buffered_bounded_lemire_uint32 (Lemire's nearly-divisionless rejection). */
+static int64_t pcg64_integers(pcg64 *r, int64_t low, int64_t high) {
+  uint32_t rng = (uint32_t)(high - 1 - low);
+  if (rng == 0) return low;
+  const uint32_t rng_excl = rng + 1;
+  uint64_t m = (uint64_t)pcg64_next32(r) * rng_excl;
+  uint32_t leftover = (uint32_t)m;
+  if (leftover < rng_excl) {
+    const uint32_t threshold = (uint32_t)(0u - rng_excl) % rng_excl;
+    while (leftover < threshold) {
+      m = (uint64_t)pcg64_next32(r) * rng_excl;
+      leftover = (uint32_t)m;
+    }
+  }
+  return low + (int64_t)(m >> 32);
+}
 
 void orc_rng_probe(uint64_t seed, int32_t n, uint64_t state_out[4], double *doubles_out) {
   pcg64 r;
@@ -132,6 +167,10 @@ typedef struct {
   /* 3-D maze: path overlay shown in the NEXT observation (minecraft_3D_maze_prob.py:84-93) */
   int16_t *path_xyz;
   int32_t path_len;
+  /* StaticTileRepresentation: static_tiles in the bordered shape, and the interior of rep._bordered_map, which lags
+   * behind rep._map between reset() (static walls are written into _map only, wrappers.py:309) and the first update */
+  uint8_t *static_b, *bord;
+  int32_t bord_stale;
 } env_t;
 
 struct orc_engine {
@@ -140,6 +179,8 @@ struct orc_engine {
   env_t *envs;
   uint8_t *grid_pool;
   int16_t *path_pool;
+  uint8_t *static_pool;
+  int32_t n_act; /* action entries per env: prod(act_window) or 1 */
 };
 
 static int n_tiles_of(int problem) {
@@ -376,8 +417,54 @@ static int ravel(const orc_config *cfg, const int32_t *pos) {
   return (pos[0] * cfg->dims[1] + pos[1]) * cfg->dims[2] + pos[2];
 }
 
+/* MultiActionRepresentation.update (reps/wrappers.py:466-524) around a narrow representation: the action is a
+ * row-major act_window patch of tile ids centred on _pos (inner pads floor/ceil((k-1)/2), :404-410); positions walk
+ * the row-major list of patch centres that keep the patch inside the map (get_act_coords :441-463). */
+static int multi_action_update(const orc_engine *e, env_t *v, const int32_t *act) {
+  const orc_config *cfg = &e->cfg;
+  const int ah = cfg->act_window[0], aw = cfg->act_window[1], W = cfg->dims[1];
+  const int l0 = (ah - 1) / 2, l1 = (aw - 1) / 2;
+  const int ny = cfg->dims[0] - ah + 1, nx = W - aw + 1;
+  int change = 0;
+  for (int a = 0; a < ah; a++)
+    for (int b = 0; b < aw; b++) {
+      int idx = (v->pos[0] - l0 + a) * W + (v->pos[1] - l1 + b);
+      uint8_t t = (uint8_t)act[a * aw + b];
+      change |= v->grid[idx] != t;
+      v->grid[idx] = t;
+    }
+  int k = v->n_step % (ny * nx); /* narrow_rep.py:137-138 get_pos_at_step with the pre-increment n_step */
+  v->pos[0] = l0 + k / nx;
+  v->pos[1] = l1 + k % nx;
+  v->n_step++;
+  return change;
+}
+
+static int base_update(const orc_engine *e, env_t *v, int action);
+
+/* rep.update() through the wrapper stack of wrap_rep (reps/wrappers.py:720-727): StaticTile(MultiAction(rep)). */
+static int rep_update(const orc_engine *e, env_t *v, const int32_t *act) {
+  const orc_config *cfg = &e->cfg;
+  int change = cfg->act_window[0] > 0 ? multi_action_update(e, v, act) : base_update(e, v, act[0]);
+  if (cfg->static_tiles) { /* StaticTileRepresentation.update :349-366 */
+    /* old_state = _bordered_map before the inner update; the inner update always re-syncs _bordered_map with _map */
+    const uint8_t *old = v->bord;
+    if (change > 0) {
+      const int H = cfg->dims[0], W = cfg->dims[1];
+      for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++)
+          if (v->static_b[(r + 1) * (W + 2) + c + 1]) v->grid[r * W + c] = old[r * W + c];
+      /* :362 compares old_state with the pre-revert array, so `change` stays True even if everything was undone */
+      change = 1;
+    }
+    memcpy(v->bord, v->grid, (size_t)e->n_cells);
+    v->bord_stale = 0;
+  }
+  return change;
+}
+
 /* returns change (0/1) */
-static int rep_update(const orc_engine *e, env_t *v, int action) {
+static int base_update(const orc_engine *e, env_t *v, int action) {
   const orc_config *cfg = &e->cfg;
   int change = 0;
   switch (cfg->representation) {
@@ -420,6 +507,43 @@ static int rep_update(const orc_engine *e, env_t *v, int action) {
     }
   }
   return change;
+}
+
+/* StaticTileRepresentation.reset (reps/wrappers.py:265-319), after the wrapped representation's reset.  All draws come
+ * from the representation RNG (unwrapped._random). */
+static void static_reset(const orc_engine *e, env_t *v, int injected) {
+  const orc_config *cfg = &e->cfg;
+  const int H = cfg->dims[0], W = cfg->dims[1], BW = W + 2, BH = H + 2;
+  memset(v->static_b, 0, (size_t)BH * BW);
+  memcpy(v->bord, v->grid, (size_t)e->n_cells); /* representation.py:65-76: _update_bordered_map at the end of reset */
+  v->bord_stale = 0;
+  if (injected) { /* engine extension (set_map): no draws, border only */
+  } else {
+    if (cfg->static_prob > 0) {
+      double ps = cfg->static_eval ? cfg->static_prob : pcg64_double(&v->rng_rep) * cfg->static_prob; /* :269-274 */
+      for (int i = 0; i < BH * BW; i++) v->static_b[i] = pcg64_double(&v->rng_rep) < ps;              /* :278 */
+    }
+    for (int n = 0; n < cfg->n_static_walls; n++) { /* :280-299 */
+      const int shape[2] = {H, W};
+      int wshape[2] = {1, 1}, wpos[2] = {0, 0};
+      int dim = (int)pcg64_integers(&v->rng_rep, 0, 2);
+      int wall_len = (int)pcg64_integers(&v->rng_rep, 1, shape[dim] - 1);
+      wshape[dim] = wall_len;
+      for (int d = 0; d < 2; d++) /* :292 draws from shape[dim] for the OTHER axis as well */
+        if (d != dim) wpos[d] = (int)pcg64_integers(&v->rng_rep, 0, shape[dim]);
+      wpos[dim] = (int)pcg64_integers(&v->rng_rep, 0, shape[dim] - wall_len);
+      wpos[0] += 1; /* :295 "shift to account for border" -- then used on the UNbordered _map too (:298) */
+      wpos[1] += 1;
+      for (int r = wpos[0]; r < wpos[0] + wshape[0]; r++)
+        for (int c = wpos[1]; c < wpos[1] + wshape[1]; c++) {
+          if (r < H && c < W) v->grid[r * W + c] = 1; /* _wall_tile = tiles[1] (probs/problem.py:41); slices clip */
+          if (r < BH && c < BW) v->static_b[r * BW + c] = 1;
+        }
+      v->bord_stale = 1;
+    }
+  }
+  for (int c = 0; c < BW; c++) v->static_b[c] = v->static_b[(BH - 1) * BW + c] = 1; /* :302-303 */
+  for (int r = 0; r < BH; r++) v->static_b[r * BW] = v->static_b[r * BW + BW - 1] = 1;
 }
 
 /* envs/pcgrl_env.py:158-188 reset + reps/representation.py:65-76 + helper.py:491-494, :527-536 +
@@ -467,6 +591,11 @@ static void env_reset(const orc_engine *e, env_t *v, const uint8_t *init_grid, c
       v->grid[i] = (uint8_t)idx;
     }
   }
+  if (cfg->act_window[0] > 0) { /* narrow_rep.py:41-51 with the wrapper's get_act_coords: first patch centre */
+    v->pos[0] = (cfg->act_window[0] - 1) / 2;
+    v->pos[1] = (cfg->act_window[1] - 1) / 2;
+  }
+  if (cfg->static_tiles) static_reset(e, v, init_grid != NULL);
   get_stats(cfg, v->grid, v->stats, v->path_xyz, &v->path_len);
   if (cfg->problem == ORC_PROB_MC3DMAZE) {
     /* the reset observation carries no path overlay: PcgrlEnv.reset() does not call
@@ -486,7 +615,7 @@ int64_t orc_obs_size(const orc_engine *e) {
   if (c->representation == ORC_REP_WIDE) return (int64_t)e->n_cells * e->n_tiles;
   int64_t n = 1;
   for (int d = 0; d < c->ndim; d++) n *= c->obs_window[d];
-  int chans = e->n_tiles + 1 + (c->problem == ORC_PROB_MC3DMAZE ? 1 : 0);
+  int chans = e->n_tiles + 1 + (c->problem == ORC_PROB_MC3DMAZE ? 1 : 0) + (c->static_tiles ? 1 : 0);
   return n * chans;
 }
 
@@ -501,13 +630,18 @@ static void encode_obs(const orc_engine *e, const env_t *v, uint8_t *out, int sh
     return;
   }
   if (c->ndim == 2) {
-    int oh = c->obs_window[0], ow = c->obs_window[1], C = e->n_tiles + 1;
+    int oh = c->obs_window[0], ow = c->obs_window[1], C = e->n_tiles + 1 + (c->static_tiles ? 1 : 0);
     for (int i = 0; i < oh; i++)
       for (int j = 0; j < ow; j++) {
         int r = v->pos[0] - oh / 2 + i, q = v->pos[1] - ow / 2 + j;
         int val = 0;
         if (r >= 0 && r < c->dims[0] && q >= 0 && q < c->dims[1]) val = v->grid[r * c->dims[1] + q] + 1;
         out[((size_t)i * ow + j) * C + val] = 1;
+        /* wrappers.py:452-461: the static_builds plane goes through the same Cropped wrapper, but it has the
+         * BORDERED shape while pos and pad are those of the map: the plane is read at bordered index (r, q), i.e. it
+         * is shifted by one cell against the map channels; zero outside the bordered array */
+        if (c->static_tiles && r >= 0 && r < c->dims[0] + 2 && q >= 0 && q < c->dims[1] + 2)
+          out[((size_t)i * ow + j) * C + e->n_tiles + 1] = v->static_b[r * (c->dims[1] + 2) + q];
       }
   } else {
     /* 3-D: the reference's image wrappers raise on this problem; this follows their
@@ -545,6 +679,9 @@ orc_engine *orc_create(const orc_config *cfg, int32_t n_envs) {
   e->n_cells = cfg->dims[0] * cfg->dims[1] * (cfg->ndim == 3 ? cfg->dims[2] : 1);
   e->n_tiles = n_tiles_of(cfg->problem);
   e->n_threads = 1;
+  e->n_act = cfg->act_window[0] > 0 ? cfg->act_window[0] * cfg->act_window[1] : 1;
+  size_t static_sz = (size_t)(cfg->dims[0] + 2) * (cfg->dims[1] + 2) + (size_t)e->n_cells;
+  e->static_pool = (uint8_t *)calloc((size_t)n_envs, static_sz);
   e->envs = (env_t *)calloc((size_t)n_envs, sizeof(env_t));
   e->grid_pool = (uint8_t *)calloc((size_t)n_envs, (size_t)e->n_cells);
   int path_cap = e->n_cells * 4 + 8;
@@ -552,6 +689,8 @@ orc_engine *orc_create(const orc_config *cfg, int32_t n_envs) {
   for (int i = 0; i < n_envs; i++) {
     e->envs[i].grid = e->grid_pool + (size_t)i * e->n_cells;
     e->envs[i].path_xyz = e->path_pool + (size_t)i * path_cap * 3;
+    e->envs[i].static_b = e->static_pool + (size_t)i * static_sz;
+    e->envs[i].bord = e->envs[i].static_b + (size_t)(cfg->dims[0] + 2) * (cfg->dims[1] + 2);
     pcg64_seed(&e->envs[i].rng_rep, (uint64_t)i);
     pcg64_seed(&e->envs[i].rng_prob, (uint64_t)i);
     memcpy(e->envs[i].trg_lo, cfg->trg_lo, sizeof(cfg->trg_lo));
@@ -565,6 +704,7 @@ void orc_destroy(orc_engine *e) {
   free(e->envs);
   free(e->grid_pool);
   free(e->path_pool);
+  free(e->static_pool);
   free(e);
 }
 
@@ -595,7 +735,7 @@ void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t
     env_t *v = &e->envs[i];
     /* envs/pcgrl_env.py:267-342 */
     v->iteration++;
-    int change = rep_update(e, v, actions[i]);
+    int change = rep_update(e, v, actions + (size_t)i * e->n_act);
     int show_path = 1;
     if (obs && cfg->problem == ORC_PROB_MC3DMAZE) {
       /* the 3-D observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 then :314-323),
@@ -635,7 +775,7 @@ void orc_update(orc_engine *e, const int32_t *actions, uint8_t *obs) {
   int64_t osz = orc_obs_size(e);
   for (int i = 0; i < e->n_envs; i++) {
     env_t *v = &e->envs[i];
-    (void)rep_update(e, v, actions[i]);
+    (void)rep_update(e, v, actions + (size_t)i * e->n_act);
     if (obs) encode_obs(e, v, obs + (size_t)i * osz, 1);
   }
 }
@@ -654,6 +794,11 @@ void orc_refresh_stats(orc_engine *e, int32_t *stats) {
 void orc_observe(orc_engine *e, uint8_t *obs) {
   int64_t osz = orc_obs_size(e);
   for (int i = 0; i < e->n_envs; i++) encode_obs(e, &e->envs[i], obs + (size_t)i * osz, 0);
+}
+
+void orc_get_static(orc_engine *e, uint8_t *out) {
+  size_t n = (size_t)(e->cfg.dims[0] + 2) * (e->cfg.dims[1] + 2);
+  for (int i = 0; i < e->n_envs; i++) memcpy(out + (size_t)i * n, e->envs[i].static_b, n);
 }
 
 void orc_get_state(orc_engine *e, uint8_t *grids, int32_t *pos, int32_t *counters, int32_t *stats,

@@ -46,6 +46,12 @@ typedef struct {
   int32_t n_ctrl;
   int32_t ctrl_idx[ORC_MAX_STATS];   /* stat index of each control metric, in cfg.controls order */
   double ctrl_range[ORC_MAX_STATS];  /* param_ranges[k] = |cond_bounds[k][1] - cond_bounds[k][0]|  (:70-73) */
+  /* representation wrappers (envs/reps/wrappers.py:725-727 wrap_rep) */
+  int32_t act_window[3];    /* cfg.act_window (MultiActionRepresentation :397-545, narrow only); {0,0,0} = None */
+  int32_t static_tiles;     /* cfg.static_tile_wrapper (StaticTileRepresentation :234-376, narrow / turtle) */
+  int32_t n_static_walls;   /* cfg.n_static_walls or 0 */
+  int32_t static_eval;      /* StaticTileRepresentation._eval_mode (:262-263) */
+  double static_prob;       /* cfg.static_prob or 0 */
 } orc_config;
 
 typedef struct orc_engine orc_engine;
@@ -60,7 +66,9 @@ void orc_seed(orc_engine *e, const uint64_t *seeds);
 /* reset(): mask NULL = all envs.  init_grids/init_pos non-NULL = inject (no RNG draw at all). */
 void orc_reset(orc_engine *e, const uint8_t *mask, const uint8_t *init_grids, const int32_t *init_pos);
 
-/* step(): outputs may be NULL.  obs is the uint8 one-hot observation AFTER an auto-reset, reward/done/
+/* With cfg.act_window set, every `actions` argument below is int32 [N][prod(act_window)] (MultiDiscrete, row-major
+ * patch); otherwise int32 [N].
+ * step(): outputs may be NULL.  obs is the uint8 one-hot observation AFTER an auto-reset, reward/done/
  * stats are those of the step itself (RLlib auto-reset convention). */
 void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t *obs, double *reward,
               uint8_t *done, int32_t *stats);
@@ -87,6 +95,9 @@ void orc_get_ctrl_obs(orc_engine *e, double *out);
 
 /* Stateless Problem.get_stats() on n grids. */
 void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out);
+
+/* StaticTileRepresentation.static_tiles per env: uint8 [N][(H+2)*(W+2)] (bordered shape, wrappers.py:267) */
+void orc_get_static(orc_engine *e, uint8_t *out);
 
 /* RNG known-answer hooks: state after seeding, and a stream of doubles. */
 void orc_rng_probe(uint64_t seed, int32_t n, uint64_t state_out[4], double *doubles_out);

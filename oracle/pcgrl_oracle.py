@@ -68,6 +68,8 @@ class OrcConfig(C.Structure):
         ("has_trg", C.c_int32 * 8), ("weights", C.c_double * 8), ("trg_lo", C.c_double * 8),
         ("trg_hi", C.c_double * 8), ("solver_power", C.c_int32),
         ("n_ctrl", C.c_int32), ("ctrl_idx", C.c_int32 * 8), ("ctrl_range", C.c_double * 8),
+        ("act_window", C.c_int32 * 3), ("static_tiles", C.c_int32), ("n_static_walls", C.c_int32),
+        ("static_eval", C.c_int32), ("static_prob", C.c_double),
     ]
 
 
@@ -127,13 +129,15 @@ def lib():
         L.orc_get_ctrl_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_refresh_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_static.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
 
 def make_config(problem, representation, map_shape, obs_window=None, weights=None, max_board_scans=3,
-                change_percentage=None, solver_power=10000, controls=None):
+                change_percentage=None, solver_power=10000, controls=None, act_window=None, static_prob=None,
+                n_static_walls=None, static_eval=False):
     map_shape = tuple(int(s) for s in map_shape)
     ndim = len(map_shape)
     if obs_window is None:
@@ -170,6 +174,17 @@ def make_config(problem, representation, map_shape, obs_window=None, weights=Non
     for i, k in enumerate(controls):  # control_wrappers.py:66-73
         cfg.ctrl_idx[i] = keys.index(k)
         cfg.ctrl_range[i] = abs(bounds[k][1] - bounds[k][0])
+    if act_window is not None:  # reps/wrappers.py:720-722
+        assert representation == "narrow" and ndim == 2, "the reference's MultiActionRepresentation only runs on narrow"
+        for d in range(ndim):
+            cfg.act_window[d] = int(act_window[d])
+    # rl/utils.py:308: static_tile_wrapper = static_prob is not None or n_static_walls is not None
+    if static_prob is not None or n_static_walls is not None:
+        assert representation in ("narrow", "turtle") and ndim == 2, "StaticTileRepresentation: narrow / turtle, 2-D"
+        cfg.static_tiles = 1
+        cfg.static_prob = float(static_prob or 0)        # reps/wrappers.py:240
+        cfg.n_static_walls = int(n_static_walls or 0)    # :242
+        cfg.static_eval = int(bool(static_eval))
     return cfg
 
 
@@ -199,7 +214,7 @@ class OracleVecEnv:
         if self.representation == "wide":
             return self.map_shape + (N_TILES[self.problem],)
         ow = tuple(int(self.cfg.obs_window[d]) for d in range(len(self.map_shape)))
-        extra = 1 if self.problem == "minecraft_3D_maze" else 0
+        extra = (1 if self.problem == "minecraft_3D_maze" else 0) + (1 if self.cfg.static_tiles else 0)
         return ow + (N_TILES[self.problem] + 1 + extra,)
 
     def seed(self, seeds):
@@ -245,6 +260,13 @@ class OracleVecEnv:
         stats = np.empty((self.n, self.n_stats), np.int32)
         lib().orc_refresh_stats(self.h, stats.ctypes.data)
         return stats
+
+    def static_tiles(self):
+        """StaticTileRepresentation.static_tiles, bordered shape [N, H+2, W+2]"""
+        h, w = self.map_shape
+        out = np.empty((self.n, h + 2, w + 2), np.uint8)
+        lib().orc_get_static(self.h, out.ctypes.data)
+        return out
 
     def get_state(self):
         grids = np.empty((self.n, self.n_cells), np.uint8)
