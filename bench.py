@@ -26,11 +26,16 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES = {"binary-narrow": 4 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               "zelda-turtle": 4 + 257 + 32 * 32 * 9 + (4 + 1 + 28 + 2),
               "sokoban-wide": 4 + 257 + 16 * 16 * 5 + (4 + 1 + 28 + 0),
-              "minecraft_3D_maze-narrow": 4 + 344 + 14 ** 3 * 4 + (4 + 1 + 12 + 3)}
+              "minecraft_3D_maze-narrow": 4 + 344 + 14 ** 3 * 4 + (4 + 1 + 12 + 3),
+              # SURVEY 8(f) N2 representation wrappers: + static mask read and one more obs channel / 9 action entries
+              "binary-narrow-static": 4 + 257 + 32 + 32 * 32 * 4 + (4 + 1 + 8 + 2),
+              "binary-narrow-patch3x3": 36 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2)}
 # BASELINE.json configs: (problem, representation, map_shape, envs per GPU)
 WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtle": ("zelda", "turtle", (16, 16), 4096),
              "sokoban-wide": ("sokoban", "wide", (16, 16), 2048),
-             "minecraft_3D_maze-narrow": ("minecraft_3D_maze", "narrow", (7, 7, 7), 1024)}
+             "minecraft_3D_maze-narrow": ("minecraft_3D_maze", "narrow", (7, 7, 7), 1024),
+             "binary-narrow-static": ("binary", "narrow", (16, 16), 4096, dict(static_prob=0.3, n_static_walls=3)),
+             "binary-narrow-patch3x3": ("binary", "narrow", (16, 16), 4096, dict(act_window=[3, 3]))}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -71,20 +76,21 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    problem, rep, shape, default_envs = WORKLOADS[args.workload]
+    problem, rep, shape, default_envs = WORKLOADS[args.workload][:4]
+    wkw = WORKLOADS[args.workload][4] if len(WORKLOADS[args.workload]) > 4 else {}
     N, K, W = (args.envs or default_envs), args.steps, args.warmup
     total_envs = N * world
     env = VecPcgrlEnv(problem, rep, shape, N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world),
-                      auto_reset=True)
+                      auto_reset=True, **wkw)
     env.reset()
     reducer = EpisodeStatsReducer(env.n_stats, dev)
     # synthetic input: uniform random actions, generated on device before the timed region (seed 1234 + rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     POOL = 1024
-    actions = torch.randint(0, env.num_actions, (POOL, N), generator=g, device=dev, dtype=torch.int32)
+    actions = torch.randint(0, env.num_actions, (POOL, N * env.action_entries), generator=g, device=dev, dtype=torch.int32)
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
-    base, stride = actions.data_ptr(), N * 4
+    base, stride = actions.data_ptr(), N * env.action_entries * 4
     step_raw = env.step_raw
 
     def run_eager(n, first=0):
@@ -168,7 +174,7 @@ def main():
             "episodes": ep,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -189,7 +195,7 @@ def profiled_traffic(workload, n_envs):
     return best
 
 
-def cpu_baseline(problem, rep, shape, n_envs, target_s):
+def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None):
     """The oracle (a C port of the reference's algorithm, OpenMP over envs) on the host cores of this box:
     same workload, bounded sample."""
     import numpy as np
@@ -209,7 +215,8 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s):
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
     def rate(threads, seconds):
-        orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads)
+        orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads,
+                              **(wkw or {}))
         orc.reset()
         for k in range(2):
             orc.step(acts[k], auto_reset=True)
@@ -226,7 +233,8 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s):
     rng = np.random.default_rng(1234)
     n_act = {"narrow": po.N_TILES[problem], "turtle": po.N_TILES[problem] + 4,
              "wide": int(np.prod(shape)) * po.N_TILES[problem]}[rep]
-    acts = rng.integers(0, n_act, size=(64, n_envs), dtype=np.int32)
+    entries = int(np.prod(wkw["act_window"])) if wkw and wkw.get("act_window") else 1
+    acts = rng.integers(0, n_act, size=(64, n_envs * entries), dtype=np.int32)
     # pick the thread count that this box actually rewards (short calibration), then time the sample
     cands = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)})
     best_threads, best_rate = 1, 0.0

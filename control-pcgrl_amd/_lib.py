@@ -23,6 +23,8 @@ class PcgrlConfig(C.Structure):
         ("trg_lo", C.c_double * PCGRL_MAX_STATS), ("trg_hi", C.c_double * PCGRL_MAX_STATS),
         ("solver_power", C.c_int32),
         ("n_ctrl", C.c_int32), ("ctrl_idx", C.c_int32 * PCGRL_MAX_STATS), ("ctrl_range", C.c_double * PCGRL_MAX_STATS),
+        ("act_window", C.c_int32 * 3), ("static_tiles", C.c_int32), ("n_static_walls", C.c_int32),
+        ("static_eval", C.c_int32), ("static_prob", C.c_double),
     ]
 
 
@@ -41,6 +43,8 @@ SYMBOLS = {
     "pcgrl_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_refresh_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_get_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_set_static": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
     "pcgrl_obs_bytes": (C.c_int64, [C.c_void_p]),
     "pcgrl_obs_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 4), C.POINTER(C.c_int32)]),
     "pcgrl_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),

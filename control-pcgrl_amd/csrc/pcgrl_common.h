@@ -7,6 +7,8 @@
 //                         its env with one coalesced 64-byte access per plane.
 //   st      EnvState[N]   128-byte record of per-env scalars (one cache line).
 //   rng     RngState[N]   two PCG64 streams (representation, problem), numpy-compatible.
+//   xplanes M[N][1+NB][H] only with static tiles / action patches: static mask + lagging bordered-map planes
+//   xstate  u32[N][4]     flags and the spare half of the representation RNG's last 64-bit draw (Generator.integers)
 #pragma once
 #include <stdint.h>
 
@@ -78,6 +80,13 @@ struct Params {
   int32_t *trg_flag;      // [N] 1 = pending targets waiting
   double *reward64;       // per-call outputs of pcgrl_step_ex
   float *ctrl_obs;
+  // representation wrappers (cfg.static_tiles / cfg.act_window), see "ext" in pcgrl_kernels2d.h
+  int32_t ext;              // 1 when static tiles or an action patch are configured (selects the general kernels)
+  int32_t n_act;            // action entries per env: prod(act_window) or 1
+  void *xplanes;            // M[N][1+NB][H]: static mask in map coordinates, then the lagging bordered-map tile planes
+  uint32_t *xstate;         // [N][4]: flags (bit 0: bordered map lags behind the map), rep-RNG spare 32 bits: has, value
+  const JumpEntry *jump_b;  // [H+3]: skip r*(W+2) draws (rows of the bordered static mask)
+  uint8_t *out_static;      // pcgrl_get_static output
 };
 
 }  // namespace pcgrl

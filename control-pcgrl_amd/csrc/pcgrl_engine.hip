@@ -123,6 +123,8 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   const int nt = n_tiles_of(c.problem);
   if (c.problem == PCGRL_PROB_MC3DMAZE) {
     if (c.ndim != 3) return fail(PCGRL_EINVAL, "minecraft_3D_maze needs ndim == 3");
+    if (c.static_tiles || c.act_window[0] != 0)
+      return fail(PCGRL_EUNSUPPORTED, "static tiles / act_window are only on the accelerated path for 2-D problems");
     if (c.representation != PCGRL_REP_NARROW)
       return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze: only the narrow representation is on the accelerated path");
     const int Z = c.dims[0], Y = c.dims[1], X = c.dims[2];
@@ -142,6 +144,21 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   }
   if (c.ndim != 2) return fail(PCGRL_EINVAL, "2-D problem needs ndim == 2");
   const int H = c.dims[0], W = c.dims[1];
+  if (c.act_window[0] != 0 || c.act_window[1] != 0) {  // reps/wrappers.py:397-545; turtle / wide raise in the reference
+    if (c.representation != PCGRL_REP_NARROW)
+      return fail(PCGRL_EUNSUPPORTED, "act_window: the reference's MultiActionRepresentation only runs on narrow");
+    if (c.act_window[0] < 1 || c.act_window[1] < 1 || c.act_window[0] > H || c.act_window[1] > W)
+      return fail(PCGRL_EINVAL, "act_window must fit inside map_shape");
+  }
+  if (c.static_tiles) {  // reps/wrappers.py:234-376; wide raises in the reference (update() got an unexpected 'pos')
+    if (c.representation == PCGRL_REP_WIDE)
+      return fail(PCGRL_EUNSUPPORTED, "static tiles: the reference's StaticTileRepresentation does not run on wide");
+    if (!(c.static_prob >= 0.0 && c.static_prob <= 1.0) || c.n_static_walls < 0)
+      return fail(PCGRL_EINVAL, "static_prob must be in [0, 1] and n_static_walls >= 0");
+    if (c.n_static_walls > 0 && (H < 3 || W < 3)) return fail(PCGRL_EINVAL, "static walls need a map of at least 3x3");
+  } else if (c.static_prob != 0.0 || c.n_static_walls != 0) {
+    return fail(PCGRL_EINVAL, "static_prob / n_static_walls need static_tiles = 1");
+  }
   if (H < 1 || W < 1 || H > 64 || W > 64) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 64");
   if (W > 32 && H <= 16) return fail(PCGRL_EUNSUPPORTED, "maps wider than 32 need more than 16 rows (64-bit row-mask kernels)");
   if (W > 32 && c.problem == PCGRL_PROB_SOKOBAN) return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32");
@@ -158,9 +175,9 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
     shape[2] = nt;
     ndim = 3;
   } else {
-    const int OH = c.obs_window[0], OW = c.obs_window[1], C = nt + 1;
+    const int OH = c.obs_window[0], OW = c.obs_window[1], C = nt + 1 + (c.static_tiles ? 1 : 0);
     if (OH < 1 || OW < 1) return fail(PCGRL_EINVAL, "obs_window must be positive");
-    if ((OW * C) % 16) return fail(PCGRL_EUNSUPPORTED, "obs_window[1] * (n_tiles+1) must be a multiple of 16 bytes");
+    if ((OW * C) % 16) return fail(PCGRL_EUNSUPPORTED, "obs_window[1] * channels must be a multiple of 16 bytes");
     obs_chunks = OW * C / 16;
     obs_bytes = (int64_t)OH * OW * C;
     shape[0] = OH;
@@ -211,7 +228,7 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
   dim3 grid((p.n_envs + epw - 1) / epw), block(64);
   // compile-time specialised observation path: 16x16 map, 32x32 window (reference default obs_window = 2*map)
   const bool fast = p.cfg.representation != PCGRL_REP_WIDE && p.cfg.dims[0] == 16 && p.cfg.dims[1] == 16 &&
-                    p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32;
+                    p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32 && !p.ext;
   hipError_t e = hipSuccess;
   switch (id) {
     case K_STEP:
@@ -318,7 +335,10 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   const bool is3d = cfg->problem == PCGRL_PROB_MC3DMAZE;
   p.n_cells = cfg->dims[0] * cfg->dims[1] * (is3d ? cfg->dims[2] : 1);
   p.obs_chunks = obs_chunks;
-  e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * 65;  // one padded observation row per lane + the OOB row
+  p.ext = (!is3d && (cfg->static_tiles || cfg->act_window[0] > 0)) ? 1 : 0;
+  p.n_act = (!is3d && cfg->act_window[0] > 0) ? cfg->act_window[0] * cfg->act_window[1] : 1;
+  // one padded observation row per lane + the OOB row (+ 2 rows per env of the wave with the static_builds plane)
+  e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * (65 + (cfg->static_tiles ? 16 : 0));
   e->cpl = is3d ? (p.n_cells + 63) / 64 : 0;
   const int H = cfg->dims[0], W = cfg->dims[1];
   auto dalloc = [&](void **ptr, size_t bytes) -> hipError_t {
@@ -350,6 +370,17 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   CREATE_CHK(dalloc((void **)&djt, jt.size() * sizeof(JumpEntry)));
   CREATE_CHK(hipMemcpy(djt, jt.data(), jt.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
   p.jump = djt;
+  if (p.ext) {
+    const size_t mbytes = W > 32 ? sizeof(uint64_t) : sizeof(uint32_t);
+    const int nb = p.n_tiles <= 2 ? 1 : 3;
+    CREATE_CHK(dalloc(&p.xplanes, (size_t)n_envs * (1 + nb) * H * mbytes));
+    CREATE_CHK(dalloc((void **)&p.xstate, (size_t)n_envs * 4 * sizeof(uint32_t)));
+    std::vector<JumpEntry> jb = make_jump_table(H + 2, W + 2);
+    JumpEntry *djb = nullptr;
+    CREATE_CHK(dalloc((void **)&djb, jb.size() * sizeof(JumpEntry)));
+    CREATE_CHK(hipMemcpy(djb, jb.data(), jb.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
+    p.jump_b = djb;
+  }
   if (cfg->problem == PCGRL_PROB_SOKOBAN) CREATE_CHK(sokoban_alloc(p, e->allocs));
   if (cfg->n_ctrl > 0) {  // controllable mode: per-env targets, initialised with the static ones
     std::vector<double> init((size_t)n_envs * PCGRL_MAX_STATS * 2, 0.0);
@@ -388,6 +419,8 @@ int pcgrl_seed(pcgrl_handle h, const uint64_t *seeds) {
   }
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(h->p.rng, r.data(), r.size() * sizeof(RngState), hipMemcpyHostToDevice));
+  // seeding a numpy bit generator drops the spare 32 bits of its last draw
+  if (h->p.xstate) HIPCHK(hipMemset(h->p.xstate, 0, (size_t)h->p.n_envs * 4 * sizeof(uint32_t)));
   return PCGRL_OK;
 }
 
@@ -481,6 +514,32 @@ int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream) {
   Params p = h->p;
   p.obs = d_obs;
   HIPCHK(launch(K_OBSERVE, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_get_static(pcgrl_handle h, uint8_t *d_static, void *stream) {
+  if (!h || !d_static) return fail(PCGRL_EINVAL, "pcgrl_get_static: bad arguments");
+  if (!h->p.cfg.static_tiles) return fail(PCGRL_EINVAL, "pcgrl_get_static: the engine was created without static tiles");
+  Params p = h->p;
+  p.out_static = d_static;
+  const int nb = p.n_tiles <= 2 ? 1 : 3;
+  if (p.cfg.dims[1] > 32)
+    hipLaunchKernelGGL((get_static_kernel<uint64_t>), dim3(p.n_envs), dim3(64), 0, (hipStream_t)stream, p, nb);
+  else
+    hipLaunchKernelGGL((get_static_kernel<uint32_t>), dim3(p.n_envs), dim3(64), 0, (hipStream_t)stream, p, nb);
+  HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls, int32_t eval_mode) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_set_static: null handle");
+  if (!h->p.cfg.static_tiles) return fail(PCGRL_EINVAL, "pcgrl_set_static: the engine was created without static tiles");
+  if (static_prob > 1.0) return fail(PCGRL_EINVAL, "pcgrl_set_static: static_prob must be <= 1");
+  if (n_static_walls > 0 && (h->p.cfg.dims[0] < 3 || h->p.cfg.dims[1] < 3))
+    return fail(PCGRL_EINVAL, "pcgrl_set_static: static walls need a map of at least 3x3");
+  if (static_prob >= 0.0) h->p.cfg.static_prob = static_prob;
+  if (n_static_walls >= 0) h->p.cfg.n_static_walls = n_static_walls;
+  h->p.cfg.static_eval = eval_mode ? 1 : 0;
   return PCGRL_OK;
 }
 

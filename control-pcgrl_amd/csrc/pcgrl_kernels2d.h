@@ -589,13 +589,126 @@ __device__ inline void set_tile(M *b, int x, int t) {
   for (int k = 0; k < NB; k++) b[k] = (b[k] & ~(M(1) << x)) | ((M)((t >> k) & 1) << x);
 }
 
+// ------------------------------------------------------------------------------------------------ ext: rep wrappers
+// StaticTileRepresentation / MultiActionRepresentation (envs/reps/wrappers.py:234-376, :397-545) are a run-time
+// option (p.ext) of the general (non-FAST) kernels.  Per-row extra state of one lane:
+template <int NB, typename M>
+struct ExtRow {
+  M prot;       // static_tiles[row+1][1..W]: the cells of this map row the agent cannot change
+  M stale[NB];  // tile planes of _bordered_map's interior while it lags behind _map (flags bit 0, see rep_update_ext)
+  uint32_t flags, has32, val32;  // has32/val32: spare half of the representation RNG's last 64-bit draw
+  __device__ inline void load(const Params &p, int env, int row, bool ok) {
+    const M *xp = (const M *)p.xplanes + (size_t)env * (1 + NB) * p.cfg.dims[0] + row;
+    const uint32_t *xs = p.xstate + (size_t)env * 4;
+    flags = xs[0];
+    has32 = xs[1];
+    val32 = xs[2];
+    prot = ok ? xp[0] : M(0);
+#pragma unroll
+    for (int k = 0; k < NB; k++) stale[k] = (ok && (flags & 1u)) ? xp[(size_t)(1 + k) * p.cfg.dims[0]] : M(0);
+  }
+  __device__ inline void store(const Params &p, int env, int row, bool ok, bool lead, bool planes) const {
+    if (planes && ok) {
+      M *xp = (M *)p.xplanes + (size_t)env * (1 + NB) * p.cfg.dims[0] + row;
+      xp[0] = prot;
+      if (flags & 1u) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) xp[(size_t)(1 + k) * p.cfg.dims[0]] = stale[k];
+      }
+    }
+    if (lead) {
+      uint32_t *xs = p.xstate + (size_t)env * 4;
+      xs[0] = flags;
+      xs[1] = has32;
+      xs[2] = val32;
+    }
+  }
+};
+
+// numpy/random/src/pcg64/pcg64.h pcg64_next32: one 64-bit draw serves two 32-bit requests, low half first
+__device__ inline uint32_t pcg_next32(Pcg &r, uint32_t &has32, uint32_t &val32) {
+  if (has32) {
+    has32 = 0;
+    return val32;
+  }
+  const uint64_t n = r.next();
+  has32 = 1;
+  val32 = (uint32_t)(n >> 32);
+  return (uint32_t)n;
+}
+// Generator.integers(low, high), scalar int64 request with a range below 2^32: numpy/random/src/distributions/
+// distributions.c random_bounded_uint64 -> buffered_bounded_lemire_uint32 (Lemire rejection on 32-bit draws)
+__device__ inline int pcg_integers(Pcg &r, uint32_t &has32, uint32_t &val32, int low, int high) {
+  const uint32_t rng = (uint32_t)(high - 1 - low);
+  if (rng == 0) return low;
+  const uint32_t ex = rng + 1;
+  uint64_t m = (uint64_t)pcg_next32(r, has32, val32) * ex;
+  uint32_t leftover = (uint32_t)m;
+  if (leftover < ex) {
+    const uint32_t threshold = (0u - ex) % ex;
+    while (leftover < threshold) {
+      m = (uint64_t)pcg_next32(r, has32, val32) * ex;
+      leftover = (uint32_t)m;
+    }
+  }
+  return low + (int)(m >> 32);
+}
+// bits [lo, hi) of a row mask, clipped to [0, W)  (numpy slices clip the same way)
+template <typename M>
+__device__ inline M bit_range(int lo, int hi, int W) {
+  lo = max(lo, 0);
+  hi = min(hi, W);
+  if (hi <= lo) return M(0);
+  const M upto_hi = hi >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << hi) - M(1));
+  return upto_hi & ~((M(1) << lo) - M(1));
+}
+
+// StaticTileRepresentation.reset (reps/wrappers.py:265-319) after the wrapped representation's reset; `rr` is the
+// representation RNG after the map draws.  Every lane replays the scalar draws; the (H+2)x(W+2) block of uniform
+// draws is split by bordered row with the LCG skip-ahead table p.jump_b.
+template <int NB, typename M>
+__device__ inline void static_reset(const Params &p, int row, M *b, Pcg &rr, ExtRow<NB, M> &X) {
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  X.prot = M(0);
+  X.flags = 0;
+  if (p.cfg.static_prob > 0.0) {
+    // :269-278: prob_static ~ U[0, static_prob) unless evaluating; static_tiles = random(bordered shape) < prob_static
+    const double ps = p.cfg.static_eval ? p.cfg.static_prob : rr.next_double() * p.cfg.static_prob;
+    Pcg blk = rr;
+    rr.jump(p.jump_b[H + 2]);
+    if (row < H) {
+      blk.jump(p.jump_b[row + 1]);
+      (void)blk.next();  // bordered column 0
+      for (int x = 0; x < W; x++) X.prot |= (M)(blk.next_double() < ps ? 1 : 0) << x;
+    }
+  }
+  for (int n = 0; n < p.cfg.n_static_walls; n++) {  // :280-299
+    const int dim = pcg_integers(rr, X.has32, X.val32, 0, 2);
+    const int size = dim == 0 ? H : W;  // :292 draws the other axis from shape[dim] as well
+    const int wall_len = pcg_integers(rr, X.has32, X.val32, 1, size - 1);
+    const int other = pcg_integers(rr, X.has32, X.val32, 0, size);
+    const int along = pcg_integers(rr, X.has32, X.val32, 0, size - wall_len);
+    // :295 the +1 border shift is applied to the slices of BOTH the bordered static mask and the unbordered map
+    const int r0 = (dim == 0 ? along : other) + 1, c0 = (dim == 0 ? other : along) + 1;
+    const int nr = dim == 0 ? wall_len : 1, nc = dim == 0 ? 1 : wall_len;
+    if (row >= r0 && row < r0 + nr && row < H) {  // _map[wall_slices] = _wall_tile (tile 1)
+      const M cm = bit_range<M>(c0, c0 + nc, W);
+      b[0] |= cm;
+#pragma unroll
+      for (int k = 1; k < NB; k++) b[k] &= ~cm;
+    }
+    if (row + 1 >= r0 && row + 1 < r0 + nr && row < H) X.prot |= bit_range<M>(c0 - 1, c0 - 1 + nc, W);
+    X.flags = 1;  // _bordered_map was synchronised before the walls were written: it lags until the first update
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ reset (RNG)
 // envs/pcgrl_env.py:158-188 + reps/representation.py:65-76 + helper.py:491-494, :527-536.
 // Every lane of the group replays the env's problem-RNG draws; the map draws of the representation RNG are
 // split by row with an LCG skip-ahead so the 16 lanes generate their rows concurrently.
 template <int PROB, int LPE, typename M>
 __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, int *pos,
-                                      bool commit = true) {
+                                      bool commit = true, ExtRow<ProbTraits<PROB>::NB, M> *X = nullptr) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   if (!active) return;
@@ -634,6 +747,17 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
       for (int t = 0; t < NT; t++) idx += cdf[t] <= u ? 1 : 0;  // searchsorted(cdf, u, side='right')
 #pragma unroll
       for (int k = 0; k < NB; k++) b[k] |= (M)((idx >> k) & 1) << x;
+    }
+  }
+  if (X != nullptr) {  // representation wrappers (p.ext)
+    if (p.cfg.act_window[0] > 0) {  // narrow_rep.py:41-51 with MultiActionRepresentation.get_act_coords: first centre
+      pos[0] = (p.cfg.act_window[0] - 1) / 2;
+      pos[1] = (p.cfg.act_window[1] - 1) / 2;
+    }
+    if (p.cfg.static_tiles) {
+#pragma unroll
+      for (int k = 0; k < NB; k++) X->stale[k] = g.row < H ? b[k] : M(0);  // representation.py:65-76, before the walls
+      static_reset<NB, M>(p, g.row, b, end, *X);
     }
   }
   if (commit && g.row == 0) {
@@ -853,6 +977,119 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
   return change;
 }
 
+// rep.update() through wrap_rep's stack StaticTile(MultiAction(rep)) (reps/wrappers.py:720-727).
+template <int PROB, int LPE, typename M>
+__device__ inline bool rep_update_ext(const Grp<LPE> &g, const Params &p, int env, bool active, int action, M *b, int *pos,
+                                      int &n_step, bool &bad_action, ExtRow<ProbTraits<PROB>::NB, M> &X) {
+  constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  // StaticTileRepresentation.update :349-366: old_state = _bordered_map before the inner update.  Its interior equals
+  // _map except right after a reset with static walls (flags bit 0), when it still holds the map without the walls.
+  M old[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) old[k] = (X.flags & 1u) ? X.stale[k] : b[k];
+  bool change;
+  if (p.cfg.act_window[0] > 0) {
+    // MultiActionRepresentation.update :466-524: the action is a row-major act_window patch of tile ids centred on _pos
+    // (inner pads floor / ceil((k-1)/2), :404-410); then _pos walks the row-major list of centres that keep the patch
+    // inside the map (get_act_coords :441-463) with the pre-increment n_step (narrow_rep.py:137-138)
+    const int ah = p.cfg.act_window[0], aw = p.cfg.act_window[1];
+    const int l0 = (ah - 1) / 2, l1 = (aw - 1) / 2;
+    const int a_row = g.row - (pos[0] - l0), left = pos[1] - l1;
+    const bool mine = active && a_row >= 0 && a_row < ah;
+    const int32_t *src = p.actions + (size_t)env * p.n_act + (mine ? a_row * aw : 0);
+    bool badl = false;
+    if (mine)
+      for (int j = 0; j < aw; j++) badl = badl || src[j] < 0 || src[j] >= NT;
+    bad_action = g.gany(badl);
+    bool ch = false;
+    if (mine && !bad_action)
+      for (int j = 0; j < aw; j++) {
+        const int t = src[j];
+        ch = ch || tile_at<NB, M>(b, left + j) != t;
+        set_tile<NB, M>(b, left + j, t);
+      }
+    change = g.gany(ch);
+    if (active && !bad_action) {
+      const int nx = W - aw + 1, n = (H - ah + 1) * nx;
+      const int k = n_step % n;
+      pos[0] = l0 + k / nx;
+      pos[1] = l1 + k % nx;
+      n_step++;
+    }
+  } else {
+    change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad_action);
+  }
+  if (p.cfg.static_tiles && active && !bad_action) {
+    if (change) {  // :357-362 undo the builds on static cells; `change` stays true even if everything was undone
+#pragma unroll
+      for (int k = 0; k < NB; k++) b[k] = (b[k] & ~X.prot) | (old[k] & X.prot);
+    }
+    X.flags &= ~1u;  // every representation's update ends with _update_bordered_map()
+  }
+  return change;
+}
+
+// Observation with the static_builds plane (wrappers.py:452-461): C = NT + 2 channels.  The plane goes through the same
+// Cropped wrapper as the map but has the BORDERED shape while pos and pad are the map's, so observation pixel (i, j)
+// shows map[r][q] and static_tiles[r][q] with the same (r, q) = (pos - window/2 + (i, j)): the plane is shifted by one
+// cell against the map channels, and rows H, H+1 / columns W, W+1 carry static bits where the map is out of bounds.
+template <int NB, typename M>
+__device__ inline void build_obs_row_static(uint8_t *row, const Params &p, int C, int r, int left, const M *b, M prot_above) {
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1], OW = p.cfg.obs_window[1];
+  for (int q = 0; q < p.obs_chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < OW; j++) {
+    const int q = left + j;
+    uint8_t *px = row + j * C;
+    if (r < H && q >= 0 && q < W)
+      px[1 + tile_at<NB, M>(b, q)] = 1;
+    else
+      px[0] = 1;
+    if (r <= H + 1 && q >= 0 && q <= W + 1) {
+      const bool ring = r == 0 || r == H + 1 || q == 0 || q == W + 1;
+      px[C - 1] = ring ? 1 : (uint8_t)((prot_above >> (ring ? 0 : q - 1)) & M(1));
+    }
+  }
+}
+
+template <int PROB, int LPE, typename M>
+__device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
+                                         M prot, uint8_t *lds) {
+  constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
+  if (p.obs == nullptr) return;
+  const int H = p.cfg.dims[0], OH = p.cfg.obs_window[0], OW = p.cfg.obs_window[1];
+  const int C = NT + 2, CH = p.obs_chunks, RB = OW * C, STRIDE = RB + 16;
+  const int top = pos[0] - OH / 2, left = pos[1] - OW / 2;
+  // LDS rows: 0..63 one per lane (bordered row index = map row index), 64 the all-out-of-bounds row,
+  // 65 + 2*group + {0, 1}: bordered rows H and H+1 of the group's env
+  uint8_t *oob_row = lds + 64 * STRIDE;
+  uint8_t *xrows = lds + (65 + 2 * (g.lane / LPE)) * STRIDE;
+  M above = g.from_above(prot);  // static_tiles row r interior = protection of map row r-1
+  M last = prot;
+  if constexpr (sizeof(M) == 8)
+    last = (M)g.gbcast((uint32_t)prot, H - 1) | ((M)g.gbcast((uint32_t)((uint64_t)prot >> 32), H - 1) << 32);
+  else
+    last = (M)g.gbcast((uint32_t)prot, H - 1);
+  M none[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) none[k] = M(0);
+  if (g.row < H) build_obs_row_static<NB, M>(lds + g.lane * STRIDE, p, C, g.row, left, b, above);
+  if (g.row < 2) build_obs_row_static<NB, M>(xrows + g.row * STRIDE, p, C, H + g.row, left, none, last);
+  if (g.lane == 0) build_obs_row_static<NB, M>(oob_row, p, C, H + 2, 0, none, M(0));
+  if (active) {
+    uint8_t *base = p.obs + (size_t)env * OH * RB;
+    const int total = OH * CH;
+    for (int k = g.row; k < total; k += LPE) {
+      const int i = k / CH, q = k - i * CH;
+      const int m = i + top;
+      const uint8_t *src = (unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE
+                           : (m == H || m == H + 1) ? xrows + (m - H) * STRIDE
+                                                    : oob_row;
+      store_obs16(base + (size_t)k * 16, *(const uint4 *)(src + q * 16));
+    }
+  }
+}
+
 // One workgroup = two specialised wavefronts over the same 64/LPE envs:
 //   wave 0 "simulate": action -> stats -> reward/done -> auto-reset -> state write-back
 //   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
@@ -880,6 +1117,13 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
     load_planes<NB, M>(p, e, g.row, rowok, b);
   else
     load_planes<NW, M>(p, e, g.row, rowok, b);
+  // representation wrappers (static tiles / action patch): run-time option of the general kernels only
+  ExtRow<NB, M> X;
+  bool ext = false;
+  if constexpr (!FAST) {
+    ext = p.ext != 0;
+    if (ext) X.load(p, e, g.row, rowok);
+  }
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
@@ -893,15 +1137,23 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   bool bad = false;
   const bool upd_only = p.update_only != 0;  // evolution-driver pattern: rep.update() without PcgrlEnv.step()
   iteration += upd_only ? 0 : 1;
-  bool change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
+  bool change;
+  if (ext)
+    change = rep_update_ext<PROB, LPE, M>(g, p, e, active, action, b, pos, n_step, bad, X);
+  else
+    change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
   changes += (change && !upd_only) ? 1 : 0;
   bool done = !upd_only && iteration > p.cfg.max_iterations;
   if (p.cfg.max_changes >= 0) done = done || (!upd_only && changes > p.cfg.max_changes);
   const bool do_reset = active && done && p.auto_reset != 0;
 
   if (observer) {
-    if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/false);
-    encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
+    if (__ballot(do_reset) != 0)
+      reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/false, ext ? &X : nullptr);
+    if (ext && p.cfg.static_tiles)
+      encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds);
+    else
+      encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
     return;
   }
 
@@ -914,6 +1166,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   PHASE_MARK(1);  // action + second state loads
   if (upd_only) {  // grid / position only; stats (and the binary fars/best masks) are rebuilt by pcgrl_refresh_stats
     if (change) store_planes<NB, M>(p, e, g.row, rowok, b);
+    if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, false);
     if (active && g.row == 0) {
       S->pos[0] = pos[0];
       S->pos[1] = pos[1];
@@ -922,7 +1175,14 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
     return;
   }
   if (__ballot(change) != 0) {
-    if constexpr (PROB == PCGRL_PROB_BINARY) {
+    if (PROB != PCGRL_PROB_BINARY || ext) {  // (ext: several cells may change at once -> no incremental update)
+      int32_t ns[NS];
+      compute_stats<PROB, LPE, M>(g, p, e, change, b, colmask, ns);
+      if (change) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) st[k] = ns[k];
+      }
+    } else if constexpr (PROB == PCGRL_PROB_BINARY) {
       // incremental: only the component(s) touching the edited cell are re-swept
       const M x = change ? (tile0_old ^ b[0]) & colmask : M(0);
       int reg = st[0], len = st[1];
@@ -933,13 +1193,6 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
         st[1] = len;
         b[1] = fars;
         b[2] = best;
-      }
-    } else {
-      int32_t ns[NS];
-      compute_stats<PROB, LPE, M>(g, p, e, change, b, colmask, ns);
-      if (change) {
-#pragma unroll
-        for (int k = 0; k < NS; k++) st[k] = ns[k];
       }
     }
   }
@@ -977,7 +1230,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
 #pragma unroll
       for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
     }
-    reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos);
+    reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/true, ext ? &X : nullptr);
     int32_t ns[NS];
     compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
     if (do_reset) {
@@ -998,6 +1251,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   }
   // write back state
   if (change || do_reset) store_planes<NW, M>(p, e, g.row, rowok, b);
+  if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, do_reset);
   if (active && g.row == 0) {
     if constexpr (CTRL) {
       trg.write_ctrl_obs(p, e, st);
@@ -1037,6 +1291,9 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   int pos[2] = {0, 0};
 #pragma unroll
   for (int k = 0; k < NW; k++) b[k] = 0;
+  ExtRow<NB, M> X;
+  const bool ext = p.ext != 0;
+  if (ext) X.load(p, e, g.row, rowok);
   if (p.refresh_only) {  // keep map, position and counters: only the statistics are recomputed from scratch
     load_planes<NB, M>(p, e, g.row, rowok, b);
   } else if (p.init_grids) {  // inject: bytes -> planes (envs/pcgrl_ctrl_env.py:12-14 set_map)
@@ -1048,16 +1305,23 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
         for (int k = 0; k < NB; k++) b[k] |= (M)((t >> k) & 1) << x;
       }
     }
+    if (ext) {  // injected maps carry no static tiles (border ring only) and draw nothing
+      X.prot = M(0);
+      X.flags = 0;
+      pos[0] = p.cfg.act_window[0] > 0 ? (p.cfg.act_window[0] - 1) / 2 : 0;
+      pos[1] = p.cfg.act_window[0] > 0 ? (p.cfg.act_window[1] - 1) / 2 : 0;
+    }
     if (p.init_pos && p.cfg.representation != PCGRL_REP_WIDE) {
       pos[0] = p.init_pos[(size_t)e * 3 + 0];
       pos[1] = p.init_pos[(size_t)e * 3 + 1];
     }
   } else {
-    reset_from_rng<PROB, LPE, M>(g, p, e, active, b, pos);
+    reset_from_rng<PROB, LPE, M>(g, p, e, active, b, pos, /*commit=*/true, ext ? &X : nullptr);
   }
   int32_t st[NS];
   compute_stats<PROB, LPE, M>(g, p, e, active, b, colmask, st);
   store_planes<NW, M>(p, e, g.row, rowok, b);
+  if (ext && !p.refresh_only) X.store(p, e, g.row, rowok, active && g.row == 0, true);
   if (p.refresh_only) {
     if (active && g.row == 0) {
       EnvTargets<NS> trg;
@@ -1128,7 +1392,29 @@ __global__ __launch_bounds__(64) void observe_kernel(Params p) {
   M b[NB];
   load_planes<NB, M>(p, e, g.row, rowok, b);
   int pos[2] = {p.st[e].pos[0], p.st[e].pos[1]};
+  if constexpr (!FAST) {
+    if (p.ext && p.cfg.static_tiles) {
+      ExtRow<NB, M> X;
+      X.load(p, e, g.row, rowok);
+      encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds);
+      return;
+    }
+  }
   encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
+}
+
+// pcgrl_get_static: static mask in the reference's bordered layout, uint8 [N][(H+2)*(W+2)]
+template <typename M>
+__global__ __launch_bounds__(64) void get_static_kernel(Params p, int nb) {
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1], BW = W + 2;
+  const int env = blockIdx.x;
+  const M *xp = (const M *)p.xplanes + (size_t)env * (1 + nb) * H;
+  uint8_t *dst = p.out_static + (size_t)env * (H + 2) * BW;
+  for (int i = threadIdx.x; i < (H + 2) * BW; i += 64) {
+    const int r = i / BW, c = i - r * BW;
+    const bool ring = r == 0 || r == H + 1 || c == 0 || c == W + 1;
+    dst[i] = ring ? 1 : (uint8_t)((xp[r - 1] >> (c - 1)) & M(1));
+  }
 }
 
 template <int PROB, int LPE, typename M>

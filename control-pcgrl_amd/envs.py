@@ -15,7 +15,7 @@ from .vec_env import VecPcgrlEnv, _cfg_get, make_vec_env
 try:  # use the real spaces when gymnasium is installed, else shape/bounds holders with the same attributes
     from gymnasium import spaces as _spaces
 
-    Box, Discrete = _spaces.Box, _spaces.Discrete
+    Box, Discrete, MultiDiscrete = _spaces.Box, _spaces.Discrete, _spaces.MultiDiscrete
 except Exception:  # pragma: no cover - gymnasium is not in the build image
 
     class Box:
@@ -35,6 +35,17 @@ except Exception:  # pragma: no cover - gymnasium is not in the build image
         def __repr__(self):
             return f"Discrete({self.n})"
 
+    class MultiDiscrete:
+        def __init__(self, nvec):
+            self.nvec = np.asarray(nvec, dtype=np.int64)
+            self.shape, self.dtype = self.nvec.shape, np.dtype(np.int64)
+
+        def sample(self):
+            return (np.random.random(self.nvec.shape) * self.nvec).astype(np.int64)
+
+        def __repr__(self):
+            return f"MultiDiscrete({self.nvec.tolist()})"
+
 
 class PcgrlGymEnv:
     """One env with the reference's API on top of the batched engine."""
@@ -51,7 +62,10 @@ class PcgrlGymEnv:
         self._n_ctrl_planes = 2 * len(v.controls)
         shape = v.obs_shape[:-1] + (v.obs_shape[-1] + self._n_ctrl_planes,)
         self.observation_space = Box(low=0, high=1, shape=shape, dtype=np.float32)
-        self.action_space = Discrete(v.num_actions)  # narrow_rep.py:65-68, turtle_rep.py:70-71, wrappers.py:297
+        if v.act_window:  # envs/reps/wrappers.py:434-439: one tile id per cell of the action patch
+            self.action_space = MultiDiscrete([v.spec.n_tiles] * v.action_entries)
+        else:
+            self.action_space = Discrete(v.num_actions)  # narrow_rep.py:65-68, turtle_rep.py:70-71, wrappers.py:297
         self.static_trgs = dict(v.spec.static_trgs)
         self.metric_trgs = self.static_trgs
         self.cond_bounds = dict(v.spec.cond_bounds)
@@ -97,11 +111,17 @@ class PcgrlGymEnv:
         return self._with_ctrl_planes(obs, info), {}
 
     def step(self, action):
-        a = int(action)
-        if not 0 <= a < self.action_space.n:
-            # the reference raises IndexError from numpy indexing on an out-of-range action
-            raise IndexError(f"action {a} outside Discrete({self.action_space.n})")
-        act = torch.tensor([a], dtype=torch.int32, device=self._vec.device)
+        if self._vec.act_window:
+            a = np.asarray(action, dtype=np.int64).reshape(-1)  # :478 action.reshape(self.action_size)
+            if a.size != self._vec.action_entries or (a < 0).any() or (a >= self._vec.spec.n_tiles).any():
+                raise IndexError(f"action {a.tolist()} outside {self.action_space}")
+            act = torch.tensor(a.reshape(1, -1), dtype=torch.int32, device=self._vec.device)
+        else:
+            a = int(action)
+            if not 0 <= a < self.action_space.n:
+                # the reference raises IndexError from numpy indexing on an out-of-range action
+                raise IndexError(f"action {a} outside Discrete({self.action_space.n})")
+            act = torch.tensor([a], dtype=torch.int32, device=self._vec.device)
         obs, rew, done, trunc, info = self._vec.step(act)
         stats = info["stats"][0].cpu()
         self._rep_stats = self._stats_dict(stats)
@@ -113,6 +133,20 @@ class PcgrlGymEnv:
                         max_iterations=int(self._vec.cfg.max_iterations),
                         max_changes=None if self._vec.cfg.max_changes < 0 else int(self._vec.cfg.max_changes))
         return self._with_ctrl_planes(obs, info), float(rew[0].item()), d, d, out_info
+
+    # StaticTileRepresentation setters, reached in the reference as env.unwrapped._rep.set_* (rl/evaluate.py:128-129)
+    def set_static_prob(self, static_prob):
+        self._vec.set_static(static_prob=static_prob)
+
+    def set_n_static_walls(self, n_static_walls):
+        self._vec.set_static(n_static_walls=n_static_walls)
+
+    def set_eval_mode(self, eval_mode):
+        self._vec.set_static(eval_mode=eval_mode)
+
+    @property
+    def _rep(self):
+        return self
 
     def get_map(self):
         return self._vec.get_state().grids[0].cpu().numpy()

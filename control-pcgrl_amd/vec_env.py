@@ -25,7 +25,8 @@ def _cfg_get(cfg, path, default=None):
 
 
 def build_config(problem, representation, map_shape, obs_window=None, weights=None, max_board_scans=3,
-                 change_percentage=None, solver_power=10000, static_trgs=None, controls=None):
+                 change_percentage=None, solver_power=10000, static_trgs=None, controls=None, act_window=None,
+                 static_prob=None, n_static_walls=None, static_eval=False):
     """cfg fields -> pcgrl_config (include/pcgrl_amd.h)."""
     if representation not in REPRESENTATIONS:
         raise ValueError(f"Unknown representation: {representation}")  # rl/envs.py:65
@@ -68,6 +69,17 @@ def build_config(problem, representation, map_shape, obs_window=None, weights=No
             raise ValueError(f"control metric '{k}' is not a metric of problem '{problem}'")
         c.ctrl_idx[i] = spec.stat_keys.index(k)
         c.ctrl_range[i] = abs(spec.cond_bounds[k][1] - spec.cond_bounds[k][0])
+    if act_window is not None:  # envs/reps/wrappers.py:720-722 MultiActionRepresentation
+        if len(act_window) != ndim or ndim != 2:
+            raise ValueError("act_window must have one entry per map dimension (2-D problems)")
+        for d in range(ndim):
+            c.act_window[d] = int(act_window[d])
+    # rl/utils.py:308: static_tile_wrapper = static_prob is not None or n_static_walls is not None
+    if static_prob is not None or n_static_walls is not None:
+        c.static_tiles = 1
+        c.static_prob = float(static_prob or 0)      # envs/reps/wrappers.py:240
+        c.n_static_walls = int(n_static_walls or 0)  # :242
+        c.static_eval = int(bool(static_eval))
     return c, spec, obs_window
 
 
@@ -84,7 +96,8 @@ class VecPcgrlEnv:
 
     def __init__(self, problem, representation, map_shape, num_envs, device="cuda:0", obs_window=None, weights=None,
                  max_board_scans=3, change_percentage=None, seeds=None, auto_reset=True, solver_power=10000,
-                 static_trgs=None, controls=None, reward_dtype=torch.float32):
+                 static_trgs=None, controls=None, reward_dtype=torch.float32, act_window=None, static_prob=None,
+                 n_static_walls=None, static_eval=False):
         if not torch.cuda.is_available():
             raise RuntimeError("VecPcgrlEnv needs a GPU (ROCm device); there is no CPU fallback in the product path")
         self.device = torch.device(device)
@@ -94,8 +107,10 @@ class VecPcgrlEnv:
         self.auto_reset = bool(auto_reset)
         self.cfg, self.spec, self.obs_window = build_config(
             problem, representation, map_shape, obs_window, weights, max_board_scans, change_percentage, solver_power,
-            static_trgs, controls)
+            static_trgs, controls, act_window, static_prob, n_static_walls, static_eval)
         self.controls = list(controls or [])
+        self.act_window = None if act_window is None else tuple(int(a) for a in act_window)
+        self.static_tiles = bool(self.cfg.static_tiles)
         self.stat_keys = list(self.spec.stat_keys)
         self.n_stats = len(self.stat_keys)
         self.n_cells = int(np.prod(self.map_shape))
@@ -112,6 +127,8 @@ class VecPcgrlEnv:
         n_act = {"narrow": self.spec.n_tiles, "turtle": self.spec.n_tiles + 4,
                  "wide": self.n_cells * self.spec.n_tiles}[representation]
         self.num_actions = n_act
+        # with an action patch the action is MultiDiscrete([n_tiles] * prod(act_window)): int32 [N, action_entries]
+        self.action_entries = int(np.prod(self.act_window)) if self.act_window else 1
         N, dev = self.num_envs, self.device
         self._obs = torch.empty((N,) + self.obs_shape, dtype=torch.uint8, device=dev)
         self._reward = torch.empty(N, dtype=torch.float32, device=dev)
@@ -170,7 +187,12 @@ class VecPcgrlEnv:
             return self._obs, {"ctrl_obs": self._ctrl_obs}
         return self._obs, {}
 
+    def _check_action_shape(self, actions):
+        if actions.numel() != self.num_envs * self.action_entries:
+            raise ValueError(f"actions must hold {self.num_envs} x {self.action_entries} entries, got {tuple(actions.shape)}")
+
     def step(self, actions):
+        self._check_action_shape(actions)
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         if self._ex:
@@ -231,6 +253,7 @@ class VecPcgrlEnv:
     # -- evolution-driver pattern (evo/evolve.py:1083-1120): rep.update() many times, get_stats() once ---------------
     def update(self, actions, want_obs=True):
         """rep.update(action) for every env (+ observation); counters / stats / reward are untouched."""
+        self._check_action_shape(actions)
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         _lib.check(self._L.pcgrl_update(self._h, actions.data_ptr(), self._ptrs[0] if want_obs else None, self._stream()),
@@ -245,6 +268,25 @@ class VecPcgrlEnv:
     def observe(self):
         _lib.check(self._L.pcgrl_observe(self._h, self._ptrs[0], self._stream()), "pcgrl_observe")
         return self._obs
+
+    # -- static tiles (envs/reps/wrappers.py:234-376) ---------------------------------------------------------------
+    def get_static(self):
+        """StaticTileRepresentation.static_tiles, uint8 [N, H+2, W+2] (bordered layout, border ring = 1)."""
+        if not self.static_tiles:
+            raise ValueError("this env was built without static tiles")
+        h, w = self.map_shape
+        out = torch.empty((self.num_envs, h + 2, w + 2), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.pcgrl_get_static(self._h, out.data_ptr(), self._stream()), "pcgrl_get_static")
+        return out
+
+    def set_static(self, static_prob=None, n_static_walls=None, eval_mode=None):
+        """set_static_prob / set_n_static_walls / set_eval_mode (:256-263; rl/evaluate.py:128-129); next reset on."""
+        if eval_mode is not None:
+            self._static_eval = bool(eval_mode)
+        _lib.check(self._L.pcgrl_set_static(self._h, -1.0 if static_prob is None else float(static_prob),
+                                            -1 if n_static_walls is None else int(n_static_walls),
+                                            int(getattr(self, "_static_eval", bool(self.cfg.static_eval)))),
+                   "pcgrl_set_static")
 
     def check_errors(self):
         """Synchronises; raises ValueError if a kernel saw an action outside the action space."""
@@ -293,8 +335,6 @@ def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
     object (attributes or dict keys): task.problem, task.map_shape, task.obs_window, task.weights,
     representation, max_board_scans, change_percentage."""
     unsupported = {
-        "act_window": _cfg_get(cfg, "act_window"),
-        "static_prob": _cfg_get(cfg, "static_prob"), "n_static_walls": _cfg_get(cfg, "n_static_walls"),
         "n_aux_tiles": _cfg_get(cfg, "n_aux_tiles", 0) or None,
         "show_agents": _cfg_get(cfg, "show_agents", False) or None,
         "multiagent.n_agents": _cfg_get(cfg, "multiagent.n_agents", 0) or None,
@@ -308,4 +348,6 @@ def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
         obs_window=_cfg_get(cfg, "task.obs_window"), weights=_cfg_get(cfg, "task.weights"),
         max_board_scans=_cfg_get(cfg, "max_board_scans", 3), change_percentage=_cfg_get(cfg, "change_percentage"),
         seeds=seeds, auto_reset=auto_reset, controls=_cfg_get(cfg, "controls"),
-        reward_dtype=torch.float64 if _cfg_get(cfg, "controls") else torch.float32)
+        reward_dtype=torch.float64 if _cfg_get(cfg, "controls") else torch.float32,
+        act_window=_cfg_get(cfg, "act_window"), static_prob=_cfg_get(cfg, "static_prob"),
+        n_static_walls=_cfg_get(cfg, "n_static_walls"))

@@ -72,6 +72,12 @@ typedef struct {
   int32_t n_ctrl;                       /* len(cfg.controls), 0 = plain mode */
   int32_t ctrl_idx[PCGRL_MAX_STATS];    /* stat column of each control metric, in cfg.controls order */
   double ctrl_range[PCGRL_MAX_STATS];   /* param_ranges[k] = |cond_bounds[k][1] - cond_bounds[k][0]| (:70-73) */
+  /* representation wrappers (envs/reps/wrappers.py:720-727 wrap_rep), 2-D problems only */
+  int32_t act_window[3];  /* cfg.act_window: MultiActionRepresentation (:397-545), narrow only; {0,0,0} = None */
+  int32_t static_tiles;   /* cfg.static_tile_wrapper: StaticTileRepresentation (:234-376), narrow / turtle */
+  int32_t n_static_walls; /* cfg.n_static_walls or 0 */
+  int32_t static_eval;    /* StaticTileRepresentation._eval_mode (:262-263): static_prob is used as is */
+  double static_prob;     /* cfg.static_prob or 0: upper bound of the per-episode static-tile probability (:269-278) */
 } pcgrl_config;
 
 typedef struct pcgrl_engine *pcgrl_handle;
@@ -88,7 +94,9 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
                 void *stream);
 
 /* One env step for all N envs.  Any output pointer may be NULL.
- *   d_actions int32 [N]      d_obs uint8 [N][obs_bytes]   d_reward float [N]
+ *   d_actions int32 [N], or int32 [N][prod(act_window)] when cfg.act_window is set (the reference's MultiDiscrete
+ *             action: a row-major patch of tile ids, reps/wrappers.py:475-478) -- also for pcgrl_step_ex / pcgrl_update
+ *   d_obs uint8 [N][obs_bytes]   d_reward float [N]
  *   d_done uint8 [N]         d_stats int32 [N][n_stats]
  * auto_reset != 0: an env whose episode ended is reset inside the same launch; reward/done/stats are
  * those of the finished step, the observation is the first one of the new episode (RLlib convention),
@@ -131,6 +139,13 @@ int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d
                     double *d_last_loss, double *d_ep_return, void *stream);
 int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_len, int32_t *d_final_stats,
                            int64_t *d_n_episodes, void *stream);
+
+/* StaticTileRepresentation.static_tiles (reps/wrappers.py:267-303): d_static uint8 [N][(H+2)*(W+2)], the reference's
+ * bordered layout (entry (r+1, c+1) protects map cell (r, c); the border ring is always 1).  Requires cfg.static_tiles. */
+int pcgrl_get_static(pcgrl_handle h, uint8_t *d_static, void *stream);
+/* set_static_prob / set_n_static_walls / set_eval_mode (:256-263; used by rl/evaluate.py:128-129): take effect at each
+ * env's next reset.  n_static_walls < 0 or static_prob < 0 leave that value unchanged. */
+int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls, int32_t eval_mode);
 
 /* Stateless Problem.get_stats on n maps: d_grids uint8 [n][cells] -> d_stats int32 [n][n_stats]. */
 int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_grids, int32_t *d_stats,

@@ -796,6 +796,13 @@ void orc_observe(orc_engine *e, uint8_t *obs) {
   for (int i = 0; i < e->n_envs; i++) encode_obs(e, &e->envs[i], obs + (size_t)i * osz, 0);
 }
 
+/* set_static_prob / set_n_static_walls / set_eval_mode (reps/wrappers.py:256-263); negative = unchanged */
+void orc_set_static(orc_engine *e, double static_prob, int32_t n_static_walls, int32_t eval_mode) {
+  if (static_prob >= 0) e->cfg.static_prob = static_prob;
+  if (n_static_walls >= 0) e->cfg.n_static_walls = n_static_walls;
+  e->cfg.static_eval = eval_mode ? 1 : 0;
+}
+
 void orc_get_static(orc_engine *e, uint8_t *out) {
   size_t n = (size_t)(e->cfg.dims[0] + 2) * (e->cfg.dims[1] + 2);
   for (int i = 0; i < e->n_envs; i++) memcpy(out + (size_t)i * n, e->envs[i].static_b, n);

@@ -98,6 +98,7 @@ void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids,
 
 /* StaticTileRepresentation.static_tiles per env: uint8 [N][(H+2)*(W+2)] (bordered shape, wrappers.py:267) */
 void orc_get_static(orc_engine *e, uint8_t *out);
+void orc_set_static(orc_engine *e, double static_prob, int32_t n_static_walls, int32_t eval_mode);
 
 /* RNG known-answer hooks: state after seeding, and a stream of doubles. */
 void orc_rng_probe(uint64_t seed, int32_t n, uint64_t state_out[4], double *doubles_out);

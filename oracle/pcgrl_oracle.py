@@ -130,6 +130,7 @@ def lib():
         L.orc_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_refresh_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_static.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_static.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_int32]
         L.orc_rng_probe.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -260,6 +261,10 @@ class OracleVecEnv:
         stats = np.empty((self.n, self.n_stats), np.int32)
         lib().orc_refresh_stats(self.h, stats.ctypes.data)
         return stats
+
+    def set_static(self, static_prob=None, n_static_walls=None, eval_mode=False):
+        lib().orc_set_static(self.h, -1.0 if static_prob is None else float(static_prob),
+                             -1 if n_static_walls is None else int(n_static_walls), int(bool(eval_mode)))
 
     def static_tiles(self):
         """StaticTileRepresentation.static_tiles, bordered shape [N, H+2, W+2]"""

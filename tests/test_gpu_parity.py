@@ -88,7 +88,8 @@ def _rollout_vs_oracle(problem, rep, shape, n_envs, n_steps, seed0=100, full_eve
     g = torch.Generator(device="cpu").manual_seed(seed0)
     n_done = 0
     for t in range(n_steps):
-        a = torch.randint(0, env.num_actions, (n_envs,), generator=g, dtype=torch.int32)
+        a = torch.randint(0, env.num_actions, (n_envs, env.action_entries) if env.action_entries > 1 else (n_envs,),
+                          generator=g, dtype=torch.int32)
         obs, rew, done, _, info = env.step(a.to(env.device))
         want_obs = (t % full_every == 0) or t == n_steps - 1
         oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want_obs)
@@ -105,6 +106,8 @@ def _rollout_vs_oracle(problem, rep, shape, n_envs, n_steps, seed0=100, full_eve
             assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"])
             assert np.array_equal(st.changes.cpu().numpy(), ost["changes"])
             assert np.allclose(st.ep_return.cpu().numpy(), ost["ep_return"], atol=REW_TOL)
+            if env.static_tiles:
+                assert np.array_equal(env.get_static().cpu().numpy(), orc.static_tiles()), f"static mask @ {t}"
     le, ole = env.last_episode(), orc.last_episode()
     assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"])
     assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"])
@@ -423,3 +426,137 @@ def test_update_then_refresh_stats_vs_oracle(problem, rep, shape):
         assert np.max(np.abs(rew.cpu().numpy() - orew)) <= REW_TOL
     assert np.array_equal(obs.cpu().numpy(), oobs)
     env.check_errors()
+
+
+# ---------------------------------------------------------------- representation wrappers
+EXT = sorted(glob.glob(os.path.join(GOLDEN, "ext_*.npz")))
+
+
+def _ext_kwargs(z):
+    kw = {}
+    if float(z["static_prob"]) >= 0:
+        kw["static_prob"] = float(z["static_prob"])
+    if int(z["n_static_walls"]) >= 0:
+        kw["n_static_walls"] = int(z["n_static_walls"])
+    if int(z["act_window"][0]) > 0:
+        kw["act_window"] = [int(a) for a in z["act_window"]]
+    return kw
+
+
+@pytest.mark.parametrize("path", EXT, ids=[os.path.basename(p)[4:-4] for p in EXT])
+def test_golden_rep_wrapper_episode_replay(path):
+    """StaticTileRepresentation / MultiActionRepresentation traces of the reference (4 episodes x 160 steps each):
+    maps, static masks, positions, stats, rewards, change counters and observations, bit for bit."""
+    z = np.load(path)
+    problem, rep = str(z["problem"]), str(z["representation"])
+    shape = tuple(int(s) for s in z["map_shape"])
+    env = _vec(problem, rep, shape, 1, seeds=[int(z["seed"])], auto_reset=False, **_ext_kwargs(z))
+    assert tuple(env.obs_shape) == tuple(int(x) for x in z["obs_shape"])
+    n = int(z["steps_per_episode"])
+    full = {int(t): o for t, o in zip(z["obs_steps"], z["obs_full"])}
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    for ep, t0 in enumerate(z["reset_at"]):
+        obs, _ = env.reset()
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["reset_grid"][ep]), f"reset {ep}: map"
+        assert np.array_equal(st.pos[0, :2].cpu().numpy(), z["reset_pos"][ep])
+        assert np.array_equal(st.stats[0].cpu().numpy(), z["reset_stats"][ep])
+        if env.static_tiles:
+            assert np.array_equal(env.get_static()[0].cpu().numpy().ravel(), z["reset_static"][ep]), f"reset {ep}: static"
+        assert np.array_equal(obs[0].cpu().numpy().ravel(), z["reset_obs"][ep]), f"reset {ep}: obs"
+        for t in range(int(t0), int(t0) + n):
+            obs, rew, done, _, info = env.step(acts[t:t + 1])
+            st = env.get_state()
+            assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["grid"][t]), f"map @ {t}"
+            assert np.array_equal(st.pos[0, :2].cpu().numpy(), z["pos"][t]), f"pos @ {t}"
+            assert np.array_equal(info["stats"][0].cpu().numpy(), z["stats"][t]), f"stats @ {t}"
+            assert abs(float(rew[0]) - z["reward"][t]) <= REW_TOL, f"reward @ {t}"
+            assert bool(done[0]) == bool(z["done"][t])
+            assert int(st.changes[0]) == int(z["changes"][t]), f"changes @ {t}"
+            o = obs[0].cpu().numpy()
+            assert zlib.crc32(o.tobytes()) == int(z["obs_crc"][t]), f"obs @ {t}"
+            if t in full:
+                assert np.array_equal(o.ravel(), full[t])
+    env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep,shape,n_envs,n_steps,kw", [
+    ("binary", "narrow", (16, 16), 512, 1000, dict(static_prob=0.3, n_static_walls=3)),
+    ("zelda", "turtle", (16, 16), 256, 900, dict(static_prob=0.1, n_static_walls=5)),
+    ("sokoban", "narrow", (16, 16), 64, 300, dict(n_static_walls=7)),
+    ("binary", "narrow", (16, 16), 512, 900, dict(act_window=[3, 3])),
+    ("binary", "narrow", (16, 16), 128, 300, dict(act_window=[16, 1])),
+    ("zelda", "narrow", (16, 16), 256, 900, dict(act_window=[2, 2], static_prob=0.1, n_static_walls=3)),
+    ("binary", "narrow", (12, 20), 64, 800, dict(static_prob=0.2, n_static_walls=5, obs_window=(24, 32))),
+    ("binary", "turtle", (8, 8), 100, 300, dict(static_prob=0.5, n_static_walls=2, obs_window=(16, 16))),
+    ("zelda", "narrow", (40, 48), 16, 300, dict(act_window=[5, 3], static_prob=0.2, n_static_walls=6, obs_window=(80, 96))),
+    ("binary", "turtle", (64, 64), 8, 300, dict(static_prob=0.3, n_static_walls=7, obs_window=(32, 32))),
+])
+def test_rep_wrappers_batch_vs_oracle(problem, rep, shape, n_envs, n_steps, kw):
+    """static tiles / action patches with auto-reset over whole episodes, all row-mask widths and lane groupings"""
+    _rollout_vs_oracle(problem, rep, shape, n_envs, n_steps, full_every=41, **kw)
+
+
+def test_static_setters_and_eval_mode_vs_oracle():
+    """set_static_prob / set_n_static_walls / set_eval_mode (reps/wrappers.py:256-263) take effect at the next reset"""
+    n = 64
+    kw = dict(static_prob=0.1, n_static_walls=1)
+    env = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=False, **kw)
+    orc = po.OracleVecEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), **kw)
+    for sp, sw, ev in [(None, None, False), (0.7, 5, True), (0.0, 3, False), (0.4, 0, True)]:
+        env.set_static(static_prob=sp, n_static_walls=sw, eval_mode=ev)
+        orc.set_static(static_prob=sp, n_static_walls=sw, eval_mode=ev)
+        obs, _ = env.reset()
+        assert np.array_equal(obs.cpu().numpy(), orc.reset())
+        assert np.array_equal(env.get_static().cpu().numpy(), orc.static_tiles())
+        a = torch.randint(0, 2, (n,), dtype=torch.int32)
+        for _ in range(5):
+            obs, rew, done, _, info = env.step(a.to(env.device))
+            oobs, orew, odone, ostats = orc.step(a.numpy())
+            assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(info["stats"].cpu().numpy(), ostats)
+
+
+def test_rep_wrappers_update_and_injected_maps_vs_oracle():
+    n = 48
+    kw = dict(act_window=[4, 4], static_prob=0.3, n_static_walls=4)
+    env = _vec("zelda", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=False, **kw)
+    orc = po.OracleVecEnv("zelda", "narrow", (16, 16), n, seeds=np.arange(n), **kw)
+    assert np.array_equal(env.reset()[0].cpu().numpy(), orc.reset())
+    g = torch.Generator().manual_seed(1)
+    for t in range(30):  # evolution pattern: rep.update() only, then get_stats once
+        a = torch.randint(0, 8, (n, 16), generator=g, dtype=torch.int32)
+        assert np.array_equal(env.update(a.to(env.device)).cpu().numpy(), orc.update(a.numpy())), f"update obs @ {t}"
+    assert np.array_equal(env.refresh_stats().cpu().numpy(), orc.refresh_stats())
+    grids = np.random.default_rng(2).integers(0, 8, size=(n, 16, 16), dtype=np.uint8)
+    assert np.array_equal(env.reset(init_grids=grids)[0].cpu().numpy(), orc.reset(init_grids=grids))
+    a = torch.randint(0, 8, (n, 16), generator=g, dtype=torch.int32)
+    obs, rew, done, _, info = env.step(a.to(env.device))
+    oobs, orew, odone, ostats = orc.step(a.numpy())
+    assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(info["stats"].cpu().numpy(), ostats)
+    bad = a.clone()
+    bad[3, 5] = 8
+    before = env.get_state().grids.clone()
+    env.step(bad.to(env.device))
+    with pytest.raises(ValueError):
+        env.check_errors()
+    assert torch.equal(before[3], env.get_state().grids[3])  # a patch with a bad entry edits nothing
+
+
+def test_gym_adapter_action_patch_and_static_tiles():
+    from types import SimpleNamespace as NS
+    from control_pcgrl_amd import make_env
+    z = np.load(os.path.join(GOLDEN, "ext_zelda_narrow_aw2x2_sp10_sw3_s30.npz"))
+    cfg = NS(representation="narrow", max_board_scans=3, change_percentage=None, controls=None, act_window=[2, 2],
+             static_prob=0.1, n_static_walls=3,
+             task=NS(problem="zelda", map_shape=(16, 16), obs_window=(32, 32), weights=None), multiagent=NS(n_agents=0))
+    env = make_env(cfg)
+    env.unwrapped.seed(int(z["seed"]))
+    obs, _ = env.reset()
+    assert obs.shape == (32, 32, 10) and tuple(env.action_space.nvec) == (8, 8, 8, 8)
+    assert np.array_equal(obs.astype(np.uint8).ravel(), z["reset_obs"][0])
+    for t in range(40):
+        obs, r, d, tr, info = env.step(z["action"][t])
+        assert r == z["reward"][t] and info["changes"] == z["changes"][t]
+        assert zlib.crc32(obs.astype(np.uint8).tobytes()) == int(z["obs_crc"][t])
+    with pytest.raises(IndexError):
+        env.step([0, 1, 8, 0])
