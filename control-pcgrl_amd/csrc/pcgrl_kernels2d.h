@@ -56,6 +56,30 @@ namespace pcgrl {
   } while (0)
 #endif
 
+// Development aid: -DPCGRL_WAVE_TRACE records, per workgroup, the 100 MHz wall-clock stamps of the simulate wave
+// (start, end) and of the observe wave (start, stores issued, stores acknowledged) of the LAST launch into p.err[64..]
+// (read back by tools/wave_trace.py).  Not compiled into the shipped library.
+#ifdef PCGRL_WAVE_TRACE
+#define TRACE_DECL() const unsigned long long _tr0 = wall_clock64()
+#define TRACE_PUT(slot, v)                                                                          \
+  do {                                                                                              \
+    if ((threadIdx.x & 63) == 0) ((unsigned long long *)(p.err + 64))[(size_t)blockIdx.x * 8 + (slot)] = (v); \
+  } while (0)
+#define TRACE_NOW() wall_clock64()
+#define TRACE_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define TRACE_DECL() \
+  do {               \
+  } while (0)
+#define TRACE_PUT(slot, v) \
+  do {                     \
+  } while (0)
+#define TRACE_NOW() 0
+#define TRACE_DRAIN() \
+  do {                \
+  } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ PCG64
 struct U128 {
   uint64_t hi, lo;
@@ -1105,6 +1129,7 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   const bool observer = threadIdx.x >= 64;  // wave-uniform
   if (observer && p.obs == nullptr) return;  // (no barrier below is reached by wave 0 in that case either)
   PHASE_DECL();
+  TRACE_DECL();
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   const int env = blockIdx.x * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
@@ -1154,6 +1179,10 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
       encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds);
     else
       encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
+    TRACE_PUT(2, _tr0);
+    TRACE_PUT(3, TRACE_NOW());
+    TRACE_DRAIN();
+    TRACE_PUT(4, TRACE_NOW());
     return;
   }
 
@@ -1270,6 +1299,8 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   }
   PHASE_MARK(6);  // loss, outputs, write-back
   PHASE_FLUSH();
+  TRACE_PUT(0, _tr0);
+  TRACE_PUT(1, TRACE_NOW());
 }
 
 template <int PROB, int LPE, typename M>

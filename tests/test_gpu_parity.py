@@ -209,6 +209,20 @@ def test_other_map_shapes_vs_oracle(shape):
     _rollout_vs_oracle("zelda", "turtle", shape, 21, 200, full_every=29, obs_window=ow)
 
 
+@pytest.mark.parametrize("shape,ow", [((1, 16), (2, 32)), ((2, 2), (4, 16)), ((3, 3), (6, 16)), ((1, 1), (2, 16)),
+                                      ((64, 1), (16, 16)), ((4, 64), (8, 64))])
+def test_degenerate_map_shapes_vs_oracle(shape, ow):
+    """single-row / single-column / single-cell maps: empty frontiers, one-lane groups, W = 1 and W = 64 masks"""
+    if shape[1] > 32 and shape[0] <= 16:
+        with pytest.raises(NotImplementedError):
+            _vec("binary", "narrow", shape, 4, obs_window=ow)
+        return
+    _rollout_vs_oracle("binary", "narrow", shape, 19, 3 * shape[0] * shape[1] + 30, full_every=3, obs_window=ow)
+    if shape[0] * shape[1] >= 9:  # smaller maps have empty zelda target ranges (the reference fails on them too)
+        _rollout_vs_oracle("zelda", "turtle", shape, 19, 60, full_every=3, obs_window=ow)
+    _rollout_vs_oracle("sokoban", "narrow", shape, 19, 60, full_every=3, obs_window=ow)
+
+
 def test_small_obs_window_and_change_percentage():
     _rollout_vs_oracle("binary", "narrow", (16, 16), 64, 200, obs_window=(8, 16), change_percentage=0.2, full_every=7)
     _rollout_vs_oracle("zelda", "turtle", (16, 16), 64, 200, obs_window=(16, 16), full_every=7)
