@@ -301,13 +301,23 @@ __device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
 // chain that bounds the launch at small batches (a frontier that died stays empty, so testing the trip's last level
 // is enough).
 constexpr int SWEEP_UNROLL = 6;
+#ifndef SWEEP_TRACKED_TRIPS
+#define SWEEP_TRACKED_TRIPS 1
+#endif
+// Level-synchronous BFS from `src` inside `avail`: len = number of levels, last = the cells of the final level,
+// visited = everything reached.  SWEEP_UNROLL levels per loop trip (one ballot per trip).  The per-lane bookkeeping of
+// "my last non-empty level and its cells" costs 4-5 of the 12 instructions of a level, and it only matters for the
+// final level, so after the first SWEEP_TRACKED_TRIPS trips (which cover the many short sweeps) the loop runs without
+// it, remembering per group the state at the end of its last trip with a live frontier; that one trip is then replayed
+// with the bookkeeping.  The launch time is set by the env with the longest path, i.e. by exactly these long sweeps.
 template <int LPE, typename M>
 __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &last, M &visited) {
   M front = src & avail;
   M free_cells = avail & ~front;
   M mynb = M(0);
   int mylev = 0, lev = 0;
-  while (true) {
+  bool more = true;
+  for (int trip = 0; trip < SWEEP_TRACKED_TRIPS && more; trip++) {
 #pragma unroll
     for (int u = 0; u < SWEEP_UNROLL; u++) {
       const M nb = expand(g, front) & free_cells;
@@ -317,7 +327,40 @@ __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &las
       mynb = nb ? nb : mynb;
       front = nb;
     }
-    if (__ballot(front != 0) == 0) break;
+    more = __ballot(front != 0) != 0;
+  }
+  if (more) {
+    M s_front = front, s_free = free_cells;
+    int s_lev = lev;
+    while (true) {
+#pragma unroll
+      for (int u = 0; u < SWEEP_UNROLL; u++) {
+        const M nb = expand(g, front) & free_cells;
+        free_cells ^= nb;
+        front = nb;
+      }
+      lev += SWEEP_UNROLL;
+      const uint64_t bal = __ballot(front != 0);
+      const bool alive = g.gslice(bal) != 0;
+      s_front = alive ? front : s_front;
+      s_free = alive ? free_cells : s_free;
+      s_lev = alive ? lev : s_lev;
+      if (bal == 0) break;
+    }
+    // replay each group's last live trip with the bookkeeping (s_front are the cells of level s_lev)
+    M f = s_front, fr = s_free;
+    int l = s_lev;
+    mylev = f ? l : mylev;
+    mynb = f ? f : mynb;
+#pragma unroll
+    for (int u = 0; u < SWEEP_UNROLL; u++) {
+      const M nb = expand(g, f) & fr;
+      fr ^= nb;
+      l++;
+      mylev = nb ? l : mylev;
+      mynb = nb ? nb : mynb;
+      f = nb;
+    }
   }
   len = (int)g.gmax((uint32_t)mylev);
   last = (len > 0 && mylev == len) ? mynb : M(0);
