@@ -574,3 +574,29 @@ def test_gym_adapter_action_patch_and_static_tiles():
         assert zlib.crc32(obs.astype(np.uint8).tobytes()) == int(z["obs_crc"][t])
     with pytest.raises(IndexError):
         env.step([0, 1, 8, 0])
+
+
+@pytest.mark.parametrize("problem,rep,n_envs", [("binary", "narrow", 65536), ("zelda", "turtle", 32768)])
+def test_full_size_properties_beyond_oracle_sizes(problem, rep, n_envs):
+    """Size-independent properties at batch sizes the CPU oracle does not finish in seconds: the incrementally
+    maintained statistics equal a from-scratch evaluation of the same maps (pcgrl_stats_for_grids), refresh_stats is
+    idempotent, observe() reproduces the observation returned by step(), rewards telescope to the loss difference."""
+    env = _vec(problem, rep, (16, 16), n_envs, seeds=7 + np.arange(n_envs), auto_reset=False)
+    env.reset()
+    loss0 = env.get_state().last_loss.clone()
+    g = torch.Generator(device=env.device).manual_seed(3)
+    ret = torch.zeros(n_envs, dtype=torch.float64, device=env.device)
+    for t in range(300):
+        a = torch.randint(0, env.num_actions, (n_envs,), generator=g, device=env.device, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a)
+        ret += rew.double()
+    st = env.get_state()
+    scratch = env.stats_for_grids(st.grids)
+    assert torch.equal(scratch, info["stats"]) and torch.equal(scratch, st.stats)
+    assert torch.equal(ret, st.ep_return) and torch.allclose(st.last_loss - loss0, ret, atol=1e-9)
+    step_obs = obs.clone()
+    assert torch.equal(env.observe(), step_obs)
+    stats_before = st.stats.clone()
+    assert torch.equal(env.refresh_stats(), stats_before) and torch.equal(env.refresh_stats(), stats_before)
+    assert torch.equal(env.get_state().last_loss, st.last_loss)
+    env.check_errors()
