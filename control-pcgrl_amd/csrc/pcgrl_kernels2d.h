@@ -1047,9 +1047,14 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
 // rep.update() through wrap_rep's stack StaticTile(MultiAction(rep)) (reps/wrappers.py:720-727).
 template <int PROB, int LPE, typename M>
 __device__ inline bool rep_update_ext(const Grp<LPE> &g, const Params &p, int env, bool active, int action, M *b, int *pos,
-                                      int &n_step, bool &bad_action, ExtRow<ProbTraits<PROB>::NB, M> &X) {
+                                      int &n_step, bool &bad_action, ExtRow<ProbTraits<PROB>::NB, M> &X,
+                                      bool &map_changed, bool &multi) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  M pre[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) pre[k] = b[k];
+  const bool was_stale = (X.flags & 1u) != 0;
   // StaticTileRepresentation.update :349-366: old_state = _bordered_map before the inner update.  Its interior equals
   // _map except right after a reset with static walls (flags bit 0), when it still holds the map without the walls.
   M old[NB];
@@ -1094,6 +1099,12 @@ __device__ inline bool rep_update_ext(const Grp<LPE> &g, const Params &p, int en
     }
     X.flags &= ~1u;  // every representation's update ends with _update_bordered_map()
   }
+  // for the statistics: did the map really change (an undone build leaves it as it was), and in more than one cell?
+  M diff = M(0);
+#pragma unroll
+  for (int k = 0; k < NB; k++) diff |= pre[k] ^ b[k];
+  map_changed = g.gany(diff != 0);
+  multi = p.cfg.act_window[0] > 0 || was_stale;
   return change;
 }
 
@@ -1205,11 +1216,13 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   bool bad = false;
   const bool upd_only = p.update_only != 0;  // evolution-driver pattern: rep.update() without PcgrlEnv.step()
   iteration += upd_only ? 0 : 1;
-  bool change;
-  if (ext)
-    change = rep_update_ext<PROB, LPE, M>(g, p, e, active, action, b, pos, n_step, bad, X);
-  else
+  bool change, map_changed, multi = false;
+  if (ext) {
+    change = rep_update_ext<PROB, LPE, M>(g, p, e, active, action, b, pos, n_step, bad, X, map_changed, multi);
+  } else {
     change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
+    map_changed = change;
+  }
   changes += (change && !upd_only) ? 1 : 0;
   bool done = !upd_only && iteration > p.cfg.max_iterations;
   if (p.cfg.max_changes >= 0) done = done || (!upd_only && changes > p.cfg.max_changes);
@@ -1246,21 +1259,26 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
     }
     return;
   }
-  if (__ballot(change) != 0) {
-    if (PROB != PCGRL_PROB_BINARY || ext) {  // (ext: several cells may change at once -> no incremental update)
-      int32_t ns[NS];
-      compute_stats<PROB, LPE, M>(g, p, e, change, b, colmask, ns);
-      if (change) {
+  // the statistics can only move if the map did (with static tiles a build may have been undone: change without edit)
+  const bool restat = change && map_changed;
+  const bool full = PROB != PCGRL_PROB_BINARY ? restat : (restat && multi);  // binary: one-cell edits go incremental
+  if (__ballot(full) != 0) {
+    int32_t ns[NS];
+    compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns);
+    if (full) {
 #pragma unroll
-        for (int k = 0; k < NS; k++) st[k] = ns[k];
-      }
-    } else if constexpr (PROB == PCGRL_PROB_BINARY) {
+      for (int k = 0; k < NS; k++) st[k] = ns[k];
+    }
+  }
+  if constexpr (PROB == PCGRL_PROB_BINARY) {
+    const bool inc = restat && !multi;
+    if (__ballot(inc) != 0) {
       // incremental: only the component(s) touching the edited cell are re-swept
-      const M x = change ? (tile0_old ^ b[0]) & colmask : M(0);
+      const M x = inc ? (tile0_old ^ b[0]) & colmask : M(0);
       int reg = st[0], len = st[1];
       M fars = b[1], best = b[2];
       binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS);
-      if (change) {
+      if (inc) {
         st[0] = reg;
         st[1] = len;
         b[1] = fars;
