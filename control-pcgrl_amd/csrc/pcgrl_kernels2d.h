@@ -492,8 +492,32 @@ template <int LPE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
 
+// cells that count for calc_num_regions: zelda everything but solid and door (zelda_ctrl_prob.py:104), sokoban
+// everything but solid (sokoban_prob.py:166)
+template <int PROB, typename M>
+__device__ inline M region_cells(const M *b, M cm) {
+  const M solid = b[0] & ~b[1] & ~b[2];
+  if constexpr (PROB == PCGRL_PROB_ZELDA) return cm & ~(solid | (~b[0] & ~b[1] & b[2]));
+  return cm & ~solid;
+}
+
+// Region count after editing the single cell `x` (one bit in one lane; 0 for groups that keep their count).  If the
+// cell's membership flips, let U be the component of x in the map where x counts: on the other side of the edit U - x
+// falls into `pieces` components (0..4), so the count moves by +-(pieces - 1).  One flood and at most four fills instead
+// of one fill per region of the whole map.
+template <int LPE, typename M>
+__device__ inline int regions_update(const Grp<LPE> &g, M x, M w_old, M w_new, int regions_old) {
+  const bool flip = g.gany((x & (w_old ^ w_new)) != 0);
+  const bool became = g.gany((x & w_new & ~w_old) != 0);
+  const M U = flood(g, flip ? x : M(0), became ? w_new : w_old);
+  const int pieces = count_regions(g, U & ~x);
+  return flip ? (became ? regions_old - pieces + 1 : regions_old - 1 + pieces) : regions_old;
+}
+
+// regions_known >= 0: the caller already has the region count (incremental update in the step kernel)
 template <int PROB, int LPE, typename M>
-__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, M colmask, int32_t *st) {
+__device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, M colmask, int32_t *st,
+                                     int regions_known = -1) {
   if constexpr (PROB == PCGRL_PROB_BINARY) {
     // binary_prob.py:152-158: regions and path-length over "empty" (tile 0); b[1], b[2] receive fars / best
     M pass = active ? (~b[0] & colmask) : M(0);
@@ -519,7 +543,15 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     st[1] = n_key;
     st[2] = n_door;
     st[3] = n_enemy;
-    st[4] = count_regions(g, walk);
+    {
+      const bool need_cr = active && regions_known < 0;
+      int r = regions_known;
+      if (__ballot(need_cr) != 0) {
+        const int cr = count_regions(g, need_cr ? walk : M(0));
+        r = need_cr ? cr : r;
+      }
+      st[4] = r;
+    }
     int nearest = 0, plen = 0;
     bool one_player = n_player == 1;
     bool want_enemy = one_player && n_enemy > 0;
@@ -542,7 +574,14 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     M crate = b[0] & b[1] & ~b[2] & cm, target = ~b[0] & ~b[1] & b[2] & cm;
     uint32_t c01 = g.gsum((uint32_t)popc_m(player) | ((uint32_t)popc_m(crate) << 16));
     int n_player = c01 & 0xFFFF, n_crate = c01 >> 16, n_target = (int)g.gsum((uint32_t)popc_m(target));
-    int regions = count_regions(g, cm & ~solid);
+    int regions = regions_known;
+    {
+      const bool need_cr = active && regions_known < 0;
+      if (__ballot(need_cr) != 0) {
+        const int cr = count_regions(g, need_cr ? (cm & ~solid) : M(0));
+        regions = need_cr ? cr : regions;
+      }
+    }
     int dist_win = p.cfg.dims[0] * p.cfg.dims[1] * (p.cfg.dims[0] + p.cfg.dims[1]);
     int sol_len = 0;
     bool need = active && n_player == 1 && n_crate == n_target && n_crate > 0 && regions == 1;
@@ -1211,6 +1250,9 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   if (p.obs != nullptr) __syncthreads();
   PHASE_MARK(0);  // loads + barrier
   const M tile0_old = b[0];
+  M pre[NB];  // pre-update tile planes (zelda / sokoban: incremental region count)
+#pragma unroll
+  for (int k = 0; k < NB; k++) pre[k] = b[k];
 
   // envs/pcgrl_env.py:267-342
   bool bad = false;
@@ -1264,7 +1306,21 @@ __global__ __launch_bounds__(128) void step_kernel(Params p) {
   const bool full = PROB != PCGRL_PROB_BINARY ? restat : (restat && multi);  // binary: one-cell edits go incremental
   if (__ballot(full) != 0) {
     int32_t ns[NS];
-    compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns);
+    int regions_known = -1;
+    if constexpr (PROB != PCGRL_PROB_BINARY) {
+      // one-cell edit: the region count moves only around that cell
+      constexpr int RI = PROB == PCGRL_PROB_ZELDA ? 4 : 3;
+      const bool one = full && !multi;
+      if (__ballot(one) != 0) {
+        M x = M(0);
+#pragma unroll
+        for (int k = 0; k < NB; k++) x |= pre[k] ^ b[k];
+        x = one ? (x & colmask) : M(0);
+        const int r = regions_update(g, x, region_cells<PROB, M>(pre, colmask), region_cells<PROB, M>(b, colmask), st[RI]);
+        regions_known = one ? r : -1;
+      }
+    }
+    compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns, regions_known);
     if (full) {
 #pragma unroll
       for (int k = 0; k < NS; k++) st[k] = ns[k];
