@@ -48,8 +48,14 @@ def main(tag, outdir=None):
         rows = [r for r in csv.DictReader(open(kt)) if "step_kernel" in r["Kernel_Name"]]
         gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
         r0 = rows[0]
+        durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+        periods = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["Start_Timestamp"]) for i in range(len(rows) - 1)]
+        q = lambda f: durs[min(len(durs) - 1, int(f * len(durs)))]
         out["step_kernel_launch"] = {"grid": int(r0["Grid_Size_X"]), "workgroup": int(r0["Workgroup_Size_X"]),
-                                     "median_gap_between_launches_ns": statistics.median(gaps)}
+                                     "median_gap_between_launches_ns": statistics.median(gaps),
+                                     "duration_ns": {"p10": q(0.1), "median": q(0.5), "p90": q(0.9), "p99": q(0.99),
+                                                     "mean": statistics.mean(durs)},
+                                     "median_start_to_start_ns": statistics.median(periods)}
     counters = defaultdict(dict)
     for d in ("prof_fetch", "prof_write", "prof_sq"):
         f = first(f"{d}/**/*counter_collection.csv")
