@@ -283,15 +283,36 @@ __device__ inline int count_regions(const Grp<LPE> &g, M avail) {
 // only, unless a component that attained the old maximum was touched (then from all far cells).
 template <int LPE, typename M>
 __device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
-  M f = hfill(seed & avail, avail);
-  while (true) {  // two rounds per trip
-    M v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
-    f = hfill(f | v, avail);
-    v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
-    if (__ballot(v != 0) == 0) break;
-    f = hfill(f | v, avail);
+  if constexpr (LPE <= 16) {
+    // small maps: plain frontier expansion, 8 levels per trip (7 instructions per level, no run fill)
+    M front = seed & avail, free_cells = avail & ~front;
+    while (true) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const M nb = expand(g, front) & free_cells;
+        free_cells ^= nb;
+        front = nb;
+      }
+      if (__ballot(front != 0) == 0) break;
+    }
+    return avail & ~free_cells;
+  } else {
+    // larger maps: O(1) horizontal run fill + one vertical step per round (corridors cost one round per row, not one
+    // level per cell), four rounds per trip
+    M f = hfill(seed & avail, avail);
+    while (true) {
+      M v;
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
+        f = hfill(f | v, avail);
+      }
+      v = (g.from_above(f) | g.from_below(f)) & avail & ~f;
+      if (__ballot(v != 0) == 0) break;
+      f = hfill(f | v, avail);
+    }
+    return f;
   }
-  return f;
 }
 
 // Level-synchronous BFS of every group from `src` inside `avail`.  Per group: the number of levels (eccentricity of the
