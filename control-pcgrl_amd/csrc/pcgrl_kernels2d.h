@@ -322,6 +322,9 @@ __device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
 // chain that bounds the launch at small batches (a frontier that died stays empty, so testing the trip's last level
 // is enough).
 constexpr int SWEEP_UNROLL = 6;
+#ifndef SWEEP_UNTRACKED_UNROLL
+#define SWEEP_UNTRACKED_UNROLL 6
+#endif
 #ifndef SWEEP_TRACKED_TRIPS
 #define SWEEP_TRACKED_TRIPS 1
 #endif
@@ -355,12 +358,12 @@ __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &las
     int s_lev = lev;
     while (true) {
 #pragma unroll
-      for (int u = 0; u < SWEEP_UNROLL; u++) {
+      for (int u = 0; u < SWEEP_UNTRACKED_UNROLL; u++) {
         const M nb = expand(g, front) & free_cells;
         free_cells ^= nb;
         front = nb;
       }
-      lev += SWEEP_UNROLL;
+      lev += SWEEP_UNTRACKED_UNROLL;
       const uint64_t bal = __ballot(front != 0);
       const bool alive = g.gslice(bal) != 0;
       s_front = alive ? front : s_front;
@@ -374,7 +377,7 @@ __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &las
     mylev = f ? l : mylev;
     mynb = f ? f : mynb;
 #pragma unroll
-    for (int u = 0; u < SWEEP_UNROLL; u++) {
+    for (int u = 0; u < SWEEP_UNTRACKED_UNROLL; u++) {
       const M nb = expand(g, f) & fr;
       fr ^= nb;
       l++;
