@@ -83,6 +83,7 @@ struct Params {
   // representation wrappers (cfg.static_tiles / cfg.act_window), see "ext" in pcgrl_kernels2d.h
   int32_t ext;              // 1 when static tiles or an action patch are configured (selects the general kernels)
   int32_t n_act;            // action entries per env: prod(act_window) or 1
+  int32_t lds_pair_bytes;   // LDS bytes of one (simulate, observe) wave pair of the step kernel
   void *xplanes;            // M[N][1+NB][H]: static mask in map coordinates, then the lagging bordered-map tile planes
   uint32_t *xstate;         // [N][4]: flags (bit 0: bordered map lags behind the map), rep-RNG spare 32 bits: has, value
   const JumpEntry *jump_b;  // [H+3]: skip r*(W+2) draws (rows of the bordered static mask)

@@ -234,7 +234,18 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
     case K_STEP:
       if constexpr (LPE == 16 && sizeof(M) == 4) {
         if (fast) {
-          if (p.trg || p.reward64)
+          const bool ctrl = p.trg || p.reward64;
+#if !defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_WAVE_TRACE)  // (the development counters are indexed by workgroup)
+          if constexpr (PROB == PCGRL_PROB_BINARY) {  // two wave pairs per workgroup
+            const dim3 g2((grid.x + 1) / 2);
+            if (ctrl)
+              hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true, 2>), g2, dim3(256), 2 * lds, s, p);
+            else
+              hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false, 2>), g2, dim3(256), 2 * lds, s, p);
+            break;
+          }
+#endif
+          if (ctrl)
             hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128), lds, s, p);
           else
             hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128), lds, s, p);
@@ -339,6 +350,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   p.n_act = (!is3d && cfg->act_window[0] > 0) ? cfg->act_window[0] * cfg->act_window[1] : 1;
   // one padded observation row per lane + the OOB row (+ 2 rows per env of the wave with the static_builds plane)
   e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * (65 + (cfg->static_tiles ? 16 : 0));
+  p.lds_pair_bytes = (int32_t)e->lds_bytes;
   e->cpl = is3d ? (p.n_cells + 63) / 64 : 0;
   const int H = cfg->dims[0], W = cfg->dims[1];
   auto dalloc = [&](void **ptr, size_t bytes) -> hipError_t {

@@ -1236,19 +1236,24 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
 //   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
 // The two never exchange data: the observation depends only on the post-action grid and position, not on the
 // statistics, so the BFS latency chain and the LDS/HBM-store chain overlap instead of adding up.
-template <int PROB, int LPE, typename M, bool FAST, bool CTRL>
-__global__ __launch_bounds__(128) void step_kernel(Params p) {
+// PAIRS (simulate, observe) wave pairs share a workgroup: 2 for the binary 16x16 kernel (512 instead of 1 024
+// workgroups to dispatch at 4096 envs: 6.65 -> 6.57 us per launch; 4 pairs are slower, 7.7 us; zelda, whose launch is
+// bound by its observation stores, is faster with 1).
+template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
+__global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
   Grp<LPE> g;
   g.init();
-  const bool observer = threadIdx.x >= 64;  // wave-uniform
+  const int wave = (int)(threadIdx.x >> 6), pair = wave >> 1;
+  const bool observer = (wave & 1) != 0;  // wave-uniform
+  uint8_t *lds = lds_all + (size_t)pair * p.lds_pair_bytes;
   if (observer && p.obs == nullptr) return;  // (no barrier below is reached by wave 0 in that case either)
   PHASE_DECL();
   TRACE_DECL();
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
-  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  const int env = (blockIdx.x * PAIRS + pair) * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
   const bool rowok = active && g.row < H;
   const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
