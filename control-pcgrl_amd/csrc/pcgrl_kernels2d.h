@@ -455,6 +455,33 @@ __device__ inline void binary_stats_update(const Grp<LPE> &g, M x, M p_old, M p_
   }
 }
 
+// The same after editing SEVERAL cells X at once (action patches, the static-tile revert after a reset).  A component
+// that neither contains nor touches a cell of X is the same set of cells before and after, so its far cell stands:
+// drop the far cells of the old components that meet N[X] = X + neighbours, re-sweep the new components that meet N[X].
+template <int LPE, typename M>
+__device__ inline void binary_stats_update_multi(const Grp<LPE> &g, M X, M p_old, M p_new, int &regions, int &path_len,
+                                                 M &fars, M &best) {
+  const M nx = X | expand(g, X);
+  const M t_old = flood(g, nx & p_old, p_old);
+  const M k_new = flood(g, nx & p_new, p_new);
+  const bool hit = g.gany((best & t_old) != 0);
+  const M newfars = component_fars(g, k_new);
+  fars = (fars & ~t_old) | newfars;
+  const bool changed = g.gany(X != 0);
+  int l;
+  M b;
+  eccentricity(g, hit ? fars : newfars, p_new, l, b);
+  if (changed) {
+    regions = (int)g.gsum((uint32_t)popc_m(fars));
+    if (hit || l > path_len) {
+      path_len = l;
+      best = b;
+    }
+  } else {
+    (void)g.gsum(0u);
+  }
+}
+
 // helper.py:225-240 run_dijkstra from a single source, reduced to "distance to the first target cell":
 // level k >= 1 at which the frontier first meets targetA / targetB, or -1 if the frontier dies first.
 template <int LPE, typename M>
@@ -1193,6 +1220,30 @@ __device__ inline void build_obs_row_static(uint8_t *row, const Params &p, int C
   }
 }
 
+// the same for two tile types: C = 4, so a pixel is one dword (byte 0 out of bounds, byte 1 + tile, byte 3 static) and
+// the row is assembled in registers, four pixels per 16-byte LDS store
+template <typename M>
+__device__ inline void build_obs_row_static4(uint8_t *row, const Params &p, int r, int left, M tiles, M prot_above) {
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1], OW = p.cfg.obs_window[1];
+  const bool maprow = r < H, srow = r <= H + 1, ring_row = r == 0 || r == H + 1;
+  for (int j0 = 0; j0 < OW; j0 += 4) {
+    uint32_t w[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int q = left + j0 + t;
+      const bool inmap = maprow && (unsigned)q < (unsigned)W;
+      const uint32_t tile = (uint32_t)((tiles >> (inmap ? q : 0)) & M(1));
+      uint32_t v = inmap ? (0x100u << (8 * tile)) : 1u;
+      if (srow && (unsigned)q <= (unsigned)(W + 1)) {
+        const bool ring = ring_row || q == 0 || q == W + 1;
+        v |= (ring ? 1u : (uint32_t)((prot_above >> (ring ? 0 : q - 1)) & M(1))) << 24;
+      }
+      w[t] = v;
+    }
+    *(uint4 *)(row + j0 * 4) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 template <int PROB, int LPE, typename M>
 __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
                                          M prot, uint8_t *lds) {
@@ -1214,14 +1265,21 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
   M none[NB];
 #pragma unroll
   for (int k = 0; k < NB; k++) none[k] = M(0);
-  if (g.row < H) build_obs_row_static<NB, M>(lds + g.lane * STRIDE, p, C, g.row, left, b, above);
-  if (g.row < 2) build_obs_row_static<NB, M>(xrows + g.row * STRIDE, p, C, H + g.row, left, none, last);
-  if (g.lane == 0) build_obs_row_static<NB, M>(oob_row, p, C, H + 2, 0, none, M(0));
+  if constexpr (NT == 2) {
+    if (g.row < H) build_obs_row_static4<M>(lds + g.lane * STRIDE, p, g.row, left, b[0], above);
+    if (g.row < 2) build_obs_row_static4<M>(xrows + g.row * STRIDE, p, H + g.row, left, M(0), last);
+    if (g.lane == 0) build_obs_row_static4<M>(oob_row, p, H + 2, 0, M(0), M(0));
+  } else {
+    if (g.row < H) build_obs_row_static<NB, M>(lds + g.lane * STRIDE, p, C, g.row, left, b, above);
+    if (g.row < 2) build_obs_row_static<NB, M>(xrows + g.row * STRIDE, p, C, H + g.row, left, none, last);
+    if (g.lane == 0) build_obs_row_static<NB, M>(oob_row, p, C, H + 2, 0, none, M(0));
+  }
   if (active) {
     uint8_t *base = p.obs + (size_t)env * OH * RB;
     const int total = OH * CH;
+    const float inv_ch = 1.0f / (float)CH;  // floor((k + 0.5) / CH) is exact in fp32 for k < 2^20
     for (int k = g.row; k < total; k += LPE) {
-      const int i = k / CH, q = k - i * CH;
+      const int i = (int)(((float)k + 0.5f) * inv_ch), q = k - i * CH;
       const int m = i + top;
       const uint8_t *src = (unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE
                            : (m == H || m == H + 1) ? xrows + (m - H) * STRIDE
@@ -1332,7 +1390,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   }
   // the statistics can only move if the map did (with static tiles a build may have been undone: change without edit)
   const bool restat = change && map_changed;
-  const bool full = PROB != PCGRL_PROB_BINARY ? restat : (restat && multi);  // binary: one-cell edits go incremental
+  const bool full = PROB != PCGRL_PROB_BINARY && restat;  // binary: always incremental around the edited cell(s)
   if (__ballot(full) != 0) {
     int32_t ns[NS];
     int regions_known = -1;
@@ -1368,6 +1426,21 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
         st[1] = len;
         b[1] = fars;
         b[2] = best;
+      }
+    }
+    if constexpr (!FAST) {  // several cells at once: only with the representation wrappers
+      const bool many = restat && multi;
+      if (__ballot(many) != 0) {
+        const M X = many ? (tile0_old ^ b[0]) & colmask : M(0);
+        int reg = st[0], len = st[1];
+        M fars = b[1], best = b[2];
+        binary_stats_update_multi(g, X, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
+        if (many) {
+          st[0] = reg;
+          st[1] = len;
+          b[1] = fars;
+          b[2] = best;
+        }
       }
     }
   }

@@ -32,14 +32,21 @@ def main():
     ap.add_argument("--envs", default="4096,16384,65536")
     ap.add_argument("--iters", type=int, default=3000)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--static", action="store_true", help="static tiles (p <= 0.3, 3 walls)")
+    ap.add_argument("--patch", default="", help="action patch, e.g. 3x3")
     args = ap.parse_args()
     problem, rep = args.workload.split("-")
     dev = torch.device("cuda:0")
     for n in [int(x) for x in args.envs.split(",")]:
-        env = VecPcgrlEnv(problem, rep, (16, 16), n, device=dev, seeds=np.arange(n), auto_reset=True)
+        kw = {}
+        if args.static:
+            kw.update(static_prob=0.3, n_static_walls=3)
+        if args.patch:
+            kw.update(act_window=[int(x) for x in args.patch.split("x")])
+        env = VecPcgrlEnv(problem, rep, (16, 16), n, device=dev, seeds=np.arange(n), auto_reset=True, **kw)
         env.reset()
         g = torch.Generator(device=dev).manual_seed(1)
-        pool = torch.randint(0, env.num_actions, (1021, n), generator=g, device=dev, dtype=torch.int32)
+        pool = torch.randint(0, env.num_actions, (1021, n * env.action_entries), generator=g, device=dev, dtype=torch.int32)
         stream = torch.cuda.current_stream(dev)
         sp = stream.cuda_stream
         L, h = env._L, env._h
