@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=0,
                     help="launch the step kernel through a captured HIP graph of this many steps (0 = eager launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--rollout-steps", type=int, default=64,
+                    help="also time the open-loop rollout kernel (pcgrl_rollout) with this many steps per launch and "
+                         "report it as `open_loop_rollout`; 0 = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -153,6 +156,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary figure: the same K steps through pcgrl_rollout (G steps per launch, every observation written), the
+    # engine's counterpart of the reference's random-action profiling loop (profile_env.py:124-142).  Never `value`.
+    rollout = None
+    G = args.rollout_steps
+    if G > 0 and problem != "minecraft_3D_maze" and not wkw and POOL >= G:
+        R = max(1, K // G)
+        obs_r = torch.empty((G, N) + env.obs_shape, dtype=torch.uint8, device=dev)
+        rew_r = torch.empty((G, N), dtype=torch.float32, device=dev)
+        done_r = torch.empty((G, N), dtype=torch.uint8, device=dev)
+        stats_r = torch.empty((G, N, env.n_stats), dtype=torch.int32, device=dev)
+
+        def run_rollouts(n):
+            for i in range(n):
+                rc = env._L.pcgrl_rollout(env._h, base + ((i * G) % (POOL - G + 1)) * stride, G, 1, obs_r.data_ptr(), 0,
+                                          rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
+                if rc:
+                    raise RuntimeError(f"pcgrl_rollout rc={rc}")
+
+        run_rollouts(max(1, R // 10))
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run_rollouts(R)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        el_r = time.perf_counter() - t1
+        env.check_errors()
+        if world > 1:
+            t = torch.tensor([el_r], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_r = float(t.item())
+        us = el_r / (R * G) * 1e6
+        rollout = {"value": total_envs * R * G / el_r, "unit": "env-steps/s", "steps_per_launch": G, "launches": R,
+                   "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                   "note": "open-loop action sequences only (actions known in advance); all per-step outputs written"}
+
     if rank == 0:
         value = total_envs * K / elapsed
         bytes_per_launch = ALGO_BYTES[args.workload] * N
@@ -173,6 +215,8 @@ def main():
                          "avg_launch_us": kernel_ms * 1e3},
             "episodes": ep,
         }
+        if rollout is not None:
+            out["open_loop_rollout"] = rollout
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw)
         print(json.dumps(out), flush=True)

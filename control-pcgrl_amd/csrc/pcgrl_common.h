@@ -88,6 +88,10 @@ struct Params {
   uint32_t *xstate;         // [N][4]: flags (bit 0: bordered map lags behind the map), rep-RNG spare 32 bits: has, value
   const JumpEntry *jump_b;  // [H+3]: skip r*(W+2) draws (rows of the bordered static mask)
   uint8_t *out_static;      // pcgrl_get_static output
+  // pcgrl_rollout: several steps per launch
+  int32_t n_steps;          // steps per launch; actions / reward / done / stats are [n_steps][N]...
+  int32_t obs_last_only;    // 0: obs is [n_steps][N][obs_env_bytes]; else only the last step's observation [N][...]
+  int64_t obs_env_bytes;    // observation bytes per env
 };
 
 }  // namespace pcgrl

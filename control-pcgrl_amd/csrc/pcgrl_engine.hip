@@ -213,7 +213,7 @@ static std::vector<JumpEntry> make_jump_table(int H, int W, int last = -1) {
 }
 
 // ---------------------------------------------------------------------------------------------- dispatch
-enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS };
+enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS, K_ROLLOUT };
 
 // LDS above the 64 KiB default needs an explicit opt-in per kernel (64x64 zelda rows are 1152 B x 65 = 74 KiB)
 template <typename K>
@@ -260,6 +260,16 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
         hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128), lds, s, p);
       }
       break;
+    case K_ROLLOUT:
+      if constexpr (LPE == 16 && sizeof(M) == 4) {
+        if (fast) {
+          hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true>), grid, dim3(128), lds, s, p);
+          break;
+        }
+      }
+      if ((e = allow_lds(rollout_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, false>), grid, dim3(128), lds, s, p);
+      break;
     case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
     case K_OBSERVE:
       if constexpr (LPE == 16 && sizeof(M) == 4) {
@@ -305,6 +315,7 @@ static hipError_t launch3d(KernelId id, const Params &p, int cpl, hipStream_t s)
     case K_LAST_EPISODE:
       hipLaunchKernelGGL((last_episode_kernel<PCGRL_PROB_MC3DMAZE, 64>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
       break;
+    case K_ROLLOUT: return hipErrorNotSupported;
   }
   return hipGetLastError();
 }
@@ -474,6 +485,25 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   p.stats_out = d_stats;
   p.ctrl_obs = d_ctrl_obs;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
+                  int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream) {
+  if (!h || !d_actions || n_steps < 1) return fail(PCGRL_EINVAL, "pcgrl_rollout: bad arguments");
+  if (h->p.cfg.problem == PCGRL_PROB_MC3DMAZE || h->p.ext || h->p.cfg.n_ctrl > 0)
+    return fail(PCGRL_EUNSUPPORTED, "pcgrl_rollout: 2-D problems in plain mode only (no controls, no representation wrappers)");
+  Params p = h->p;
+  p.actions = d_actions;
+  p.n_steps = n_steps;
+  p.auto_reset = auto_reset;
+  p.obs = d_obs;
+  p.obs_last_only = obs_last_only;
+  p.obs_env_bytes = h->obs_bytes;
+  p.reward = d_reward;
+  p.done = d_done;
+  p.stats_out = d_stats;
+  HIPCHK(launch(K_ROLLOUT, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
 

@@ -865,13 +865,19 @@ __device__ inline void static_reset(const Params &p, int row, M *b, Pcg &rr, Ext
 // split by row with an LCG skip-ahead so the 16 lanes generate their rows concurrently.
 template <int PROB, int LPE, typename M>
 __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, int *pos,
-                                      bool commit = true, ExtRow<ProbTraits<PROB>::NB, M> *X = nullptr) {
+                                      bool commit = true, ExtRow<ProbTraits<PROB>::NB, M> *X = nullptr,
+                                      Pcg *reg_prob = nullptr, Pcg *reg_rep = nullptr) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   if (!active) return;
   Pcg rp, rr;
-  rp.load(p.rng[env].prob);
-  rr.load(p.rng[env].rep);
+  if (reg_prob != nullptr) {  // rollout kernel: the streams live in registers across steps
+    rp = *reg_prob;
+    rr = *reg_rep;
+  } else {
+    rp.load(p.rng[env].prob);
+    rr.load(p.rng[env].rep);
+  }
   double cdf[NT], total = 0.0;
 #pragma unroll
   for (int t = 0; t < NT; t++) cdf[t] = rp.next_double();
@@ -917,7 +923,10 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
       static_reset<NB, M>(p, g.row, b, end, *X);
     }
   }
-  if (commit && g.row == 0) {
+  if (reg_prob != nullptr) {
+    *reg_prob = rp;
+    *reg_rep = end;
+  } else if (commit && g.row == 0) {
     end.store(p.rng[env].rep);
     rp.store(p.rng[env].prob);
   }
@@ -977,10 +986,11 @@ __device__ inline uint4 oob_chunk_rt(int q) {
 // and every loop bound is a compile-time constant.
 template <int PROB, int LPE, bool FAST, typename M>
 __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
-                                  uint8_t *lds) {
+                                  uint8_t *lds, uint8_t *obs_base = nullptr) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   if (p.obs == nullptr) return;
+  if (obs_base == nullptr) obs_base = p.obs;
   if (p.cfg.representation == PCGRL_REP_WIDE) {
     // wrappers.py:502-526: plain one-hot of the map, (H, W, NT), no out-of-bounds channel
     const int row_bytes = W * NT, chunks = row_bytes >> 4;
@@ -988,7 +998,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     for (int q = 0; q < chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
     if (active && g.row < H) {
       for (int x = 0; x < W; x++) row[x * NT + tile_at<NB, M>(b, x)] = 1;
-      uint8_t *dst = p.obs + ((size_t)env * H + g.row) * row_bytes;
+      uint8_t *dst = obs_base + ((size_t)env * H + g.row) * row_bytes;
       for (int q = 0; q < chunks; q++) store_obs16(dst + q * 16, *(uint4 *)(row + q * 16));
     }
     return;
@@ -1037,7 +1047,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
       }
   }
   if (active) {
-    uint8_t *base = p.obs + (size_t)env * OH * RB;
+    uint8_t *base = obs_base + (size_t)env * OH * RB;
     const int total = OH * CH;
     if constexpr (FAST) {
       constexpr int FCH = FOW * C / 16;
@@ -1520,6 +1530,167 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   PHASE_FLUSH();
   TRACE_PUT(0, _tr0);
   TRACE_PUT(1, TRACE_NOW());
+}
+
+// Open-loop rollout: p.n_steps consecutive steps of every env in ONE launch (pcgrl_rollout).  Same two specialised waves
+// as step_kernel; the whole env state, including the two RNG streams, stays in registers between steps, so there is no
+// per-step kernel boundary, no per-step state traffic, and waves advance independently (a launch no longer waits for
+// its slowest env at every step).  Plain mode only (no control targets, no representation wrappers).
+template <int PROB, int LPE, typename M, bool FAST>
+__global__ __launch_bounds__(128) void rollout_kernel(Params p) {
+  constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
+  constexpr int NW = NB + ProbTraits<PROB>::NAUX;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  Grp<LPE> g;
+  g.init();
+  const bool observer = threadIdx.x >= 64;  // wave-uniform
+  if (observer && p.obs == nullptr) return;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int env = blockIdx.x * EPW + (g.lane / LPE);
+  const bool active = env < p.n_envs;
+  const bool rowok = active && g.row < H;
+  const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
+  const int e = active ? env : 0;
+  const size_t N = (size_t)p.n_envs;
+  const int K = p.n_steps;
+
+  M b[NW];
+  if (observer)
+    load_planes<NB, M>(p, e, g.row, rowok, b);
+  else
+    load_planes<NW, M>(p, e, g.row, rowok, b);
+  EnvState *S = &p.st[e];
+  int pos[2] = {S->pos[0], S->pos[1]};
+  int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
+  int ep_len = S->ep_len;
+  double last_loss = S->last_loss, ep_return = S->ep_return;
+  int32_t st[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+  Pcg rp, rr;
+  rp.load(p.rng[e].prob);
+  rr.load(p.rng[e].rep);
+  int action = active ? p.actions[e] : 0;
+  if (p.obs != nullptr) __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
+  bool any_change = false, any_reset = false, bad_any = false;
+
+  for (int k = 0; k < K; k++) {
+    // the next step's action is requested now and consumed one iteration later
+    const int next_action = (k + 1 < K && active) ? p.actions[(size_t)(k + 1) * N + e] : 0;
+    const M tile0_old = b[0];
+    M pre[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) pre[i] = b[i];
+    bool bad = false;
+    iteration++;
+    const bool change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
+    changes += change ? 1 : 0;
+    bool done = iteration > p.cfg.max_iterations;
+    if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
+    const bool do_reset = active && done && p.auto_reset != 0;
+    bad_any = bad_any || bad;
+
+    if (observer) {
+      if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, false, nullptr, &rp, &rr);
+      if (!p.obs_last_only || k == K - 1)
+        encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds,
+                                       p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes));
+    } else {
+      const bool full = PROB != PCGRL_PROB_BINARY && change;
+      if (__ballot(full) != 0) {
+        int32_t ns[NS];
+        int regions_known = -1;
+        if constexpr (PROB != PCGRL_PROB_BINARY) {
+          constexpr int RI = PROB == PCGRL_PROB_ZELDA ? 4 : 3;
+          M x = M(0);
+#pragma unroll
+          for (int i = 0; i < NB; i++) x |= pre[i] ^ b[i];
+          x = full ? (x & colmask) : M(0);
+          const int r = regions_update(g, x, region_cells<PROB, M>(pre, colmask), region_cells<PROB, M>(b, colmask), st[RI]);
+          regions_known = full ? r : -1;
+        }
+        compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns, regions_known);
+        if (full) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) st[i] = ns[i];
+        }
+      }
+      if constexpr (PROB == PCGRL_PROB_BINARY) {
+        if (__ballot(change) != 0) {
+          const M x = change ? (tile0_old ^ b[0]) & colmask : M(0);
+          int reg = st[0], len = st[1];
+          M fars = b[1], best = b[2];
+          binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
+          if (change) {
+            st[0] = reg;
+            st[1] = len;
+            b[1] = fars;
+            b[2] = best;
+          }
+        }
+      }
+      const double loss = get_loss<NS>(p.cfg, st);
+      const double rew = loss - last_loss;
+      last_loss = loss;
+      ep_return += rew;
+      ep_len++;
+      if (active && g.row == 0) {
+        const size_t o = (size_t)k * N + (size_t)e;
+        if (p.reward) p.reward[o] = (float)rew;
+        if (p.done) p.done[o] = done ? 1 : 0;
+        if (p.stats_out) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
+        }
+      }
+      if (__ballot(do_reset) != 0) {
+        if (do_reset && g.row == 0) {
+          S->last_ep_return = ep_return;
+          S->last_ep_len = ep_len;
+          S->n_episodes += 1;
+#pragma unroll
+          for (int i = 0; i < NS; i++) S->final_stats[i] = st[i];
+        }
+        reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, true, nullptr, &rp, &rr);
+        int32_t ns[NS];
+        compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
+        if (do_reset) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) st[i] = ns[i];
+          ep_len = 0;
+          ep_return = 0.0;
+          last_loss = get_loss<NS>(p.cfg, st);
+        }
+      }
+      any_change = any_change || change;
+      any_reset = any_reset || do_reset;
+    }
+    if (do_reset) {  // both waves restart their replay of the representation from the new episode
+      iteration = 0;
+      changes = 0;
+      n_step = 0;
+    }
+    action = next_action;
+  }
+  if (observer) return;
+  if (bad_any && g.row == 0 && active) atomicOr(p.err, 1);
+  if (any_change || any_reset) store_planes<NW, M>(p, e, g.row, rowok, b);
+  if (active && g.row == 0) {
+    S->pos[0] = pos[0];
+    S->pos[1] = pos[1];
+    S->n_step = n_step;
+    S->iteration = iteration;
+    S->changes = changes;
+    S->ep_len = ep_len;
+    S->last_loss = last_loss;
+    S->ep_return = ep_return;
+#pragma unroll
+    for (int i = 0; i < NS; i++) S->stats[i] = st[i];
+    if (any_reset) {
+      rr.store(p.rng[e].rep);
+      rp.store(p.rng[e].prob);
+    }
+  }
 }
 
 template <int PROB, int LPE, typename M>

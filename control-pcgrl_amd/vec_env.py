@@ -250,6 +250,29 @@ class VecPcgrlEnv:
         return self._L.pcgrl_step(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
                                   self._ptrs[2], self._ptrs[3], stream)
 
+    def rollout(self, actions, want_obs="all"):
+        """Open-loop rollout: `actions` int32 [K, N]; K steps in one launch (pcgrl_rollout).  Returns
+        (obs, reward [K, N], done [K, N], stats [K, N, n_stats]); obs is [K, N, ...] for want_obs="all", [N, ...]
+        (after the last step) for "last", None for "none".  Fresh tensors, not the env's step buffers."""
+        K = int(actions.shape[0])
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if actions.numel() != K * self.num_envs:
+            raise ValueError(f"actions must be [K, {self.num_envs}]")
+        N, dev = self.num_envs, self.device
+        obs = None
+        if want_obs == "all":
+            obs = torch.empty((K, N) + self.obs_shape, dtype=torch.uint8, device=dev)
+        elif want_obs == "last":
+            obs = torch.empty((N,) + self.obs_shape, dtype=torch.uint8, device=dev)
+        rew = torch.empty((K, N), dtype=torch.float32, device=dev)
+        done = torch.empty((K, N), dtype=torch.uint8, device=dev)
+        stats = torch.empty((K, N, self.n_stats), dtype=torch.int32, device=dev)
+        _lib.check(self._L.pcgrl_rollout(self._h, actions.data_ptr(), K, 1 if self.auto_reset else 0,
+                                         obs.data_ptr() if obs is not None else None, 1 if want_obs == "last" else 0,
+                                         rew.data_ptr(), done.data_ptr(), stats.data_ptr(), self._stream()), "pcgrl_rollout")
+        return obs, rew, done.view(torch.bool), stats
+
     # -- evolution-driver pattern (evo/evolve.py:1083-1120): rep.update() many times, get_stats() once ---------------
     def update(self, actions, want_obs=True):
         """rep.update(action) for every env (+ observation); counters / stats / reward are untouched."""

@@ -112,6 +112,16 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
 int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                   double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream);
 
+/* Open-loop rollout: n_steps consecutive pcgrl_step()s of every env in ONE launch, for action sequences that do not
+ * depend on the observations (random-action rollouts as in the reference's own env tests, replays, evaluation of stored
+ * action sequences).  Results are identical to n_steps calls of pcgrl_step; there is no kernel boundary between steps.
+ *   d_actions int32 [n_steps][N]          d_reward float [n_steps][N]      d_done uint8 [n_steps][N]
+ *   d_stats   int32 [n_steps][N][n_stats] d_obs uint8 [n_steps][N][obs_bytes], or [N][obs_bytes] (the observation
+ *             after the last step only) when obs_last_only != 0.  Any output pointer may be NULL.
+ * 2-D problems in plain mode (no cfg.controls, no representation wrappers). */
+int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
+                  int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
+
 /* ControlWrapper.set_trgs (control_wrappers.py:168-172): queue per-env targets; they replace the env's targets at its
  * next reset (explicit or automatic), exactly like the reference's _ctrl_trg_queue (:174-178).
  * d_trg_lo / d_trg_hi: double [N][n_stats], inclusive interval per stat (lo == hi for a scalar target); only the

@@ -600,3 +600,47 @@ def test_full_size_properties_beyond_oracle_sizes(problem, rep, n_envs):
     assert torch.equal(env.refresh_stats(), stats_before) and torch.equal(env.refresh_stats(), stats_before)
     assert torch.equal(env.get_state().last_loss, st.last_loss)
     env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep,shape,n_envs,K", [("binary", "narrow", (16, 16), 512, 900), ("zelda", "turtle", (16, 16), 256, 850),
+                                                        ("sokoban", "wide", (16, 16), 64, 120), ("binary", "turtle", (12, 20), 37, 300),
+                                                        ("zelda", "narrow", (40, 48), 9, 100)])
+def test_rollout_kernel_equals_stepwise_and_oracle(problem, rep, shape, n_envs, K):
+    """pcgrl_rollout (K steps in one launch, state in registers, auto-reset inside) == K x pcgrl_step == oracle"""
+    kw = {} if shape == (16, 16) else dict(obs_window=(2 * shape[0], 32 if shape[1] <= 16 else 96))
+    seeds = 11 + np.arange(n_envs)
+    a = torch.randint(0, _vec(problem, rep, shape, 1, **kw).num_actions, (K, n_envs), dtype=torch.int32,
+                      generator=torch.Generator().manual_seed(5))
+    env = _vec(problem, rep, shape, n_envs, seeds=seeds, auto_reset=True, **kw)
+    env.reset()
+    chunks = [(0, 7), (7, K - 40), (K - 40, K)]  # several launches: state carried through memory in between
+    obs_all, rew, done, stats = [], [], [], []
+    for lo, hi in chunks:
+        o, r, d, s = env.rollout(a[lo:hi].to(env.device), want_obs="all")
+        obs_all.append(o); rew.append(r); done.append(d); stats.append(s)
+    obs_all, rew, done, stats = (torch.cat(x) for x in (obs_all, rew, done, stats))
+    orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=seeds, threads=8, **kw)
+    orc.reset()
+    for t in range(K):
+        oobs, orew, odone, ostats = orc.step(a[t].numpy(), auto_reset=True, want_obs=(t % 37 == 0 or t == K - 1))
+        assert np.array_equal(stats[t].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew[t].cpu().numpy().astype(np.float64) - orew)) <= REW_TOL, f"reward @ {t}"
+        assert np.array_equal(done[t].cpu().numpy(), odone), f"done @ {t}"
+        if oobs is not None:
+            assert np.array_equal(obs_all[t].cpu().numpy(), oobs), f"obs @ {t}"
+    st, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(st.grids.cpu().numpy().reshape(n_envs, -1), ost["grids"])
+    assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"]) and np.array_equal(st.changes.cpu().numpy(), ost["changes"])
+    le, ole = env.last_episode(), orc.last_episode()
+    assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]) and np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"])
+    # and the step-wise path continues from the rollout's state (RNG streams included)
+    for t in range(3):
+        act = torch.randint(0, env.num_actions, (n_envs,), dtype=torch.int32, generator=torch.Generator().manual_seed(t))
+        obs, r, d, _, info = env.step(act.to(env.device))
+        oobs, orew, odone, ostats = orc.step(act.numpy(), auto_reset=True)
+        assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(info["stats"].cpu().numpy(), ostats)
+    o_last, _, _, _ = env.rollout(a[:5].to(env.device), want_obs="last")
+    for t in range(5):
+        oobs, _, _, _ = orc.step(a[t].numpy(), auto_reset=True)
+    assert np.array_equal(o_last.cpu().numpy(), oobs)
+    env.check_errors()
