@@ -18,6 +18,9 @@
  *   pcgrl_get_state                env.unwrapped._rep._map / _rep._pos / _iteration / _changes / _rep_stats
  *                                  (read by rl/callbacks.py:91-117)
  *   pcgrl_get_last_episode         rl/callbacks.py:91-117 StatsCallbacks.on_episode_end (final stats, return)
+ *   pcgrl_rollout                  the random-action rollout loop of profile_env.py:124-142 / train_reward_model.py:43-45
+ *                                  (K x PcgrlEnv.step with actions that do not depend on the observations)
+ *   pcgrl_get_static / _set_static envs/reps/wrappers.py:234-376 StaticTileRepresentation.static_tiles, set_static_prob ...
  *   pcgrl_stats_for_grids          envs/probs/problem.py:128 Problem.get_stats(map) as called directly by
  *                                  evo/evolve.py:1083-1120
  *
