@@ -160,7 +160,7 @@ def main():
     # engine's counterpart of the reference's random-action profiling loop (profile_env.py:124-142).  Never `value`.
     rollout = None
     G = args.rollout_steps
-    if G > 0 and problem != "minecraft_3D_maze" and not wkw and POOL >= G:
+    if G > 0 and not wkw and POOL >= G:
         R = max(1, K // G)
         obs_r = torch.empty((G, N) + env.obs_shape, dtype=torch.uint8, device=dev)
         rew_r = torch.empty((G, N), dtype=torch.float32, device=dev)

@@ -315,7 +315,7 @@ static hipError_t launch3d(KernelId id, const Params &p, int cpl, hipStream_t s)
     case K_LAST_EPISODE:
       hipLaunchKernelGGL((last_episode_kernel<PCGRL_PROB_MC3DMAZE, 64>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
       break;
-    case K_ROLLOUT: return hipErrorNotSupported;
+    case K_ROLLOUT: hipLaunchKernelGGL((m3_kernel<M3_ROLLOUT>), grid, block, 0, s, p, cpl); break;
   }
   return hipGetLastError();
 }
@@ -491,8 +491,8 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream) {
   if (!h || !d_actions || n_steps < 1) return fail(PCGRL_EINVAL, "pcgrl_rollout: bad arguments");
-  if (h->p.cfg.problem == PCGRL_PROB_MC3DMAZE || h->p.ext || h->p.cfg.n_ctrl > 0)
-    return fail(PCGRL_EUNSUPPORTED, "pcgrl_rollout: 2-D problems in plain mode only (no controls, no representation wrappers)");
+  if (h->p.ext || h->p.cfg.n_ctrl > 0)
+    return fail(PCGRL_EUNSUPPORTED, "pcgrl_rollout: plain mode only (no controls, no representation wrappers)");
   Params p = h->p;
   p.actions = d_actions;
   p.n_steps = n_steps;

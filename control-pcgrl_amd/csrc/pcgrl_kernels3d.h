@@ -302,11 +302,13 @@ __device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t 
 }
 
 // observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay
-__device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Params &p, int env, const int *pos, bool show_path) {
+__device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Params &p, int env, const int *pos, bool show_path,
+                                     uint8_t *obs_base = nullptr) {
   if (p.obs == nullptr) return;
+  if (obs_base == nullptr) obs_base = p.obs;
   const int o0 = p.cfg.obs_window[0], o1 = p.cfg.obs_window[1], o2 = p.cfg.obs_window[2];
   const int total = o0 * o1 * o2, chunks = total >> 2;
-  uint4 *dst = (uint4 *)(p.obs + (size_t)env * total * 4);
+  uint4 *dst = (uint4 *)(obs_base + (size_t)env * total * 4);
   const int t0 = pos[0] - o0 / 2, t1 = pos[1] - o1 / 2, t2 = pos[2] - o2 / 2;
   const int o12 = o1 * o2;
   const float inv12 = 1.0f / (float)o12, inv2 = 1.0f / (float)o2;
@@ -343,6 +345,7 @@ __device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Param
 // reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order)
 __device__ inline void m3_reset_rng(M3Lds &L, const M3Ctx &c, const Params &p, int env, int cpl) {
   Pcg rp, rr;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // rollout kernel: the state stored by lane 0 at the previous reset of this wave
   rp.load(p.rng[env].prob);
   rr.load(p.rng[env].rep);
   double p0 = rp.next_double(), p1 = rp.next_double();
@@ -373,9 +376,11 @@ __device__ inline void m3_reset_rng(M3Lds &L, const M3Ctx &c, const Params &p, i
     end.store(p.rng[env].rep);
     rp.store(p.rng[env].prob);
   }
+  __atomic_thread_fence(__ATOMIC_RELEASE);
 }
 
-enum M3Mode { M3_STEP = 0, M3_RESET = 1, M3_OBSERVE = 2, M3_STATS_FOR_GRIDS = 3, M3_GET_STATE = 4 };
+// M3_ROLLOUT: pcgrl_rollout, p.n_steps steps per launch with the env state in LDS / registers (see rollout_kernel)
+enum M3Mode { M3_STEP = 0, M3_RESET = 1, M3_OBSERVE = 2, M3_STATS_FOR_GRIDS = 3, M3_GET_STATE = 4, M3_ROLLOUT = 5 };
 
 template <int MODE>
 __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
@@ -483,8 +488,15 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     trg.load(p, env, true);
     last_loss = trg.loss(p.cfg, st);
   } else {
+   const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;
+   const size_t N = (size_t)p.n_envs;
+   for (int k = 0; k < K; k++) {
+    const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
+    uint8_t *obs_k = p.obs == nullptr ? nullptr
+                     : (MODE == M3_ROLLOUT && !p.obs_last_only ? p.obs + (size_t)k * N * (size_t)p.obs_env_bytes : p.obs);
+    const bool want_obs = MODE != M3_ROLLOUT || !p.obs_last_only || k == K - 1;
     // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
-    const int action = p.actions[env];
+    const int action = p.actions[o];
     const bool bad = action < 0 || action >= 2;
     const bool upd_only = p.update_only != 0;
     iteration += upd_only ? 0 : 1;
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
     // the previous stats update on the already edited map
     PHASE_MARK(0);  // loads + action
-    if (!do_reset) m3_encode_obs(L, c, p, env, pos, true);
+    if (!do_reset && want_obs) m3_encode_obs(L, c, p, env, pos, true, obs_k);
     PHASE_MARK(1);  // observation
     if (change) {
       uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
@@ -532,11 +544,11 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     ep_return += rew;
     ep_len++;
     if (c.lane == 0) {
-      if (p.reward) p.reward[env] = (float)rew;
-      if (p.reward64) p.reward64[env] = rew;
-      if (p.done) p.done[env] = done ? 1 : 0;
+      if (p.reward) p.reward[o] = (float)rew;
+      if (p.reward64) p.reward64[o] = rew;
+      if (p.done) p.done[o] = done ? 1 : 0;
       if (p.stats_out)
-        for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
+        for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
     }
     if (do_reset) {
       if (c.lane == 0) {
@@ -553,8 +565,9 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       ep_return = 0.0;
       trg.load(p, env, true);
       last_loss = trg.loss(p.cfg, st);
-      m3_encode_obs(L, c, p, env, pos, false);
+      if (want_obs) m3_encode_obs(L, c, p, env, pos, false, obs_k);
     }
+   }
   }
   if (ovf && c.lane == 0) atomicOr(p.err, 4);
   // write back

@@ -121,7 +121,7 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
  *   d_actions int32 [n_steps][N]          d_reward float [n_steps][N]      d_done uint8 [n_steps][N]
  *   d_stats   int32 [n_steps][N][n_stats] d_obs uint8 [n_steps][N][obs_bytes], or [N][obs_bytes] (the observation
  *             after the last step only) when obs_last_only != 0.  Any output pointer may be NULL.
- * 2-D problems in plain mode (no cfg.controls, no representation wrappers). */
+ * Plain mode only (no cfg.controls, no representation wrappers). */
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
 

@@ -644,3 +644,27 @@ def test_rollout_kernel_equals_stepwise_and_oracle(problem, rep, shape, n_envs, 
         oobs, _, _, _ = orc.step(a[t].numpy(), auto_reset=True)
     assert np.array_equal(o_last.cpu().numpy(), oobs)
     env.check_errors()
+
+
+def test_rollout_kernel_3d_equals_oracle():
+    n, K, shape = 96, 1100, (7, 7, 7)  # episode length 1031: auto-resets inside the launch
+    seeds = 3 + np.arange(n)
+    a = torch.randint(0, 2, (K, n), dtype=torch.int32, generator=torch.Generator().manual_seed(9))
+    env = _vec("minecraft_3D_maze", "narrow", shape, n, seeds=seeds, auto_reset=True)
+    env.reset()
+    parts = [env.rollout(a[lo:hi].to(env.device), want_obs="all") for lo, hi in [(0, 3), (3, K)]]
+    obs_all, rew, done, stats = (torch.cat([p[i] for p in parts]) for i in range(4))
+    orc = po.OracleVecEnv("minecraft_3D_maze", "narrow", shape, n, seeds=seeds, threads=8)
+    orc.reset()
+    for t in range(K):
+        oobs, orew, odone, ostats = orc.step(a[t].numpy(), auto_reset=True, want_obs=(t % 29 == 0 or t == K - 1 or 1028 <= t <= 1034))
+        assert np.array_equal(stats[t].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew[t].cpu().numpy().astype(np.float64) - orew)) <= REW_TOL and np.array_equal(done[t].cpu().numpy(), odone)
+        if oobs is not None:
+            assert np.array_equal(obs_all[t].cpu().numpy(), oobs), f"obs @ {t}"
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    act = torch.ones(n, dtype=torch.int32)
+    obs, r, d, _, info = env.step(act.to(env.device))
+    oobs, orew, odone, ostats = orc.step(act.numpy(), auto_reset=True)
+    assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(info["stats"].cpu().numpy(), ostats)
+    env.check_errors()
