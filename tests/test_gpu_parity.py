@@ -668,3 +668,20 @@ def test_rollout_kernel_3d_equals_oracle():
     oobs, orew, odone, ostats = orc.step(act.numpy(), auto_reset=True)
     assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(info["stats"].cpu().numpy(), ostats)
     env.check_errors()
+
+
+def test_rollout_kernel_without_auto_reset_and_with_change_budget():
+    n, K = 128, 90
+    kw = dict(change_percentage=0.1)
+    a = torch.randint(0, 12, (K, n), dtype=torch.int32, generator=torch.Generator().manual_seed(2))
+    env = _vec("zelda", "turtle", (16, 16), n, seeds=np.arange(n), auto_reset=False, **kw)
+    orc = po.OracleVecEnv("zelda", "turtle", (16, 16), n, seeds=np.arange(n), **kw)
+    env.reset(); orc.reset()
+    obs, rew, done, stats = env.rollout(a.to(env.device), want_obs="last")
+    for t in range(K):
+        oobs, orew, odone, ostats = orc.step(a[t].numpy(), auto_reset=False)
+        assert np.array_equal(stats[t].cpu().numpy(), ostats) and np.array_equal(done[t].cpu().numpy(), odone), f"@ {t}"
+        assert np.max(np.abs(rew[t].cpu().numpy().astype(np.float64) - orew)) <= REW_TOL
+    assert done[-1].any() and not done[0].any()  # the change budget ended some episodes; without auto-reset they stay done
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    assert np.array_equal(env.get_state().changes.cpu().numpy(), orc.get_state()["changes"])
