@@ -575,3 +575,65 @@ def run_ext_episode(name, seed, n_eps=4, n_steps=160):
 if __name__ == "__main__" and "ext" in sys.argv[1:]:
     for i, name in enumerate(EXT_CONFIGS):
         run_ext_episode(name, 21 + i)
+
+
+# ------------------------------------------------------------------ the reference's own 3-D known-answer maps
+def gen_stats_mc3d_test3d():
+    """test3D.py:23-1070 holds the reference's hand-built maps for helper_3D.calc_longest_path / calc_num_regions
+    (walk, stairs, jumps, head-room cases).  Its expected values are stale at this commit, so the maps
+    are re-answered here by the current code; the upstream expectations are stored next to them for the record.
+    The map literals are read with `ast` (importing test3D.py would run its module-level environment code)."""
+    import ast
+    from control_pcgrl.envs import helper_3D
+    maps = []
+    # second source: control_pcgrl/envs/probs/minecraft/test_paths.py:14-416 (hand-crafted levels for the same path
+    # search: a staircase built with numpy slices, raw list maps and dict maps)
+    for fname, tag in (("test3D.py", "test3D"), ("control_pcgrl/envs/probs/minecraft/test_paths.py", "test_paths")):
+        src = open(os.path.join("/root/reference", fname)).read()
+        ns = {"np": np}
+        for node in ast.parse(src).body:
+            if not isinstance(node, ast.Assign):
+                continue
+            t = node.targets[0]
+            base = t.value if isinstance(t, ast.Subscript) else t
+            if isinstance(base, ast.Name) and base.id == "staircase":  # np.ones + slice assignments: evaluate as written
+                exec(compile(ast.Module([node], []), fname, "exec"), ns)
+                continue
+            if isinstance(t, ast.Name) and t.id.startswith("test_map_"):
+                try:
+                    d = ast.literal_eval(node.value)
+                except Exception:
+                    continue
+                if isinstance(d, list):
+                    d = {"map": d}
+                if isinstance(d, dict) and "map" in d:
+                    maps.append((f"{tag}:{t.id}", d))
+        if "staircase" in ns:
+            maps.append((f"{tag}:staircase", {"map": ns["staircase"].astype(np.uint8).tolist()}))
+    tiles = ["AIR", "DIRT"]
+    names, shapes, flat, stats, upstream = [], [], [], [], []
+    for name, d in maps:
+        g = np.array(d["map"], np.uint8)
+        try:
+            sm = helper_3D.get_string_map(g, tiles)
+            loc = helper_3D.get_tile_locations(sm, tiles)
+            plen, _, n_jump = helper_3D.calc_longest_path(sm, loc, ["AIR"], get_path=True)
+            reg = helper_3D.calc_num_regions(sm, loc, ["AIR"])
+        except Exception as ex:  # some upstream maps crash the current code
+            print("  skip", name, g.shape, type(ex).__name__)
+            continue
+        names.append(name); shapes.append(g.shape); flat.append(g.ravel()); stats.append([reg, plen, n_jump])
+        upstream.append([d.get("region_number", -1), d.get("path_length", -1), d.get("jump", -1)])
+    n = max(len(f) for f in flat)
+    grids = np.zeros((len(flat), n), np.uint8)
+    for i, f in enumerate(flat):
+        grids[i, : len(f)] = f
+    np.savez_compressed(os.path.join(OUT, "stats_mc3dmaze_test3d.npz"), names=np.array(names), shapes=np.array(shapes, np.int32),
+                        grids=grids, stats=np.array(stats, np.int32), upstream_expected=np.array(upstream, np.int32),
+                        stat_keys=np.array(STAT_KEYS["minecraft_3D_maze"]))
+    agree = int(sum(1 for s, u in zip(stats, upstream) if s[1] == u[1]))
+    print("stats_mc3d_test3d", len(names), "maps; current code agrees with the upstream path_length on", agree)
+
+
+if __name__ == "__main__" and "test3d" in sys.argv[1:]:
+    gen_stats_mc3d_test3d()

@@ -685,3 +685,15 @@ def test_rollout_kernel_without_auto_reset_and_with_change_budget():
     assert done[-1].any() and not done[0].any()  # the change budget ended some episodes; without auto-reset they stay done
     assert np.array_equal(obs.cpu().numpy(), oobs)
     assert np.array_equal(env.get_state().changes.cpu().numpy(), orc.get_state()["changes"])
+
+
+def test_golden_reference_test3d_maps():
+    """the reference's own 3-D known-answer maps (test3D.py) through pcgrl_stats_for_grids, one shape at a time"""
+    z = np.load(os.path.join(GOLDEN, "stats_mc3dmaze_test3d.npz"))
+    for i, sh in enumerate(z["shapes"]):
+        sh = tuple(int(s) for s in sh)
+        g = z["grids"][i, : int(np.prod(sh))].reshape((1,) + sh)
+        env = _vec("minecraft_3D_maze", "narrow", sh, 1, auto_reset=False, obs_window=(2, 2, 2))
+        got = env.stats_for_grids(torch.as_tensor(g)).cpu().numpy()[0]
+        assert np.array_equal(got, z["stats"][i]), f"{z['names'][i]} {sh}: got {got}, reference {z['stats'][i]}"
+        env.close()
