@@ -29,13 +29,30 @@ ALGO_BYTES = {"binary-narrow": 4 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               "minecraft_3D_maze-narrow": 4 + 344 + 14 ** 3 * 4 + (4 + 1 + 12 + 3),
               # SURVEY 8(f) N2 representation wrappers: + static mask read and one more obs channel / 9 action entries
               "binary-narrow-static": 4 + 257 + 32 + 32 * 32 * 4 + (4 + 1 + 8 + 2),
-              "binary-narrow-patch3x3": 36 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2)}
+              "binary-narrow-patch3x3": 36 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
+              # SURVEY 8(d) "BFS-active" variant: maps with exactly one player / key / door, actions restricted to moves
+              # and {empty, solid, enemy} placements, so both single-source searches run on every change
+              "zelda-turtle-bfs": 4 + 257 + 32 * 32 * 9 + (4 + 1 + 28 + 2)}
 # BASELINE.json configs: (problem, representation, map_shape, envs per GPU)
 WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtle": ("zelda", "turtle", (16, 16), 4096),
              "sokoban-wide": ("sokoban", "wide", (16, 16), 2048),
              "minecraft_3D_maze-narrow": ("minecraft_3D_maze", "narrow", (7, 7, 7), 1024),
              "binary-narrow-static": ("binary", "narrow", (16, 16), 4096, dict(static_prob=0.3, n_static_walls=3)),
-             "binary-narrow-patch3x3": ("binary", "narrow", (16, 16), 4096, dict(act_window=[3, 3]))}
+             "binary-narrow-patch3x3": ("binary", "narrow", (16, 16), 4096, dict(act_window=[3, 3])),
+             "zelda-turtle-bfs": ("zelda", "turtle", (16, 16), 4096)}
+BFS_ACTIONS = [0, 1, 2, 3, 4 + 0, 4 + 1, 4 + 5, 4 + 6, 4 + 7]  # turtle moves, then empty / solid / bat / scorpion / spider
+
+
+def bfs_active_maps(n, seed):
+    """zelda maps with exactly one player (2), key (3) and door (4) among empty / solid / enemy tiles"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    g = rng.choice(np.array([0, 1, 5, 6, 7], np.uint8), size=(n, 256), p=[0.62, 0.26, 0.04, 0.04, 0.04])
+    for i in range(n):
+        c = rng.choice(256, size=3, replace=False)
+        g[i, c[0]], g[i, c[1]], g[i, c[2]] = 2, 3, 4
+    return g.reshape(n, 16, 16)
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -83,14 +100,24 @@ def main():
     wkw = WORKLOADS[args.workload][4] if len(WORKLOADS[args.workload]) > 4 else {}
     N, K, W = (args.envs or default_envs), args.steps, args.warmup
     total_envs = N * world
+    bfs_active = args.workload == "zelda-turtle-bfs"
     env = VecPcgrlEnv(problem, rep, shape, N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world),
-                      auto_reset=True, **wkw)
-    env.reset()
+                      auto_reset=not bfs_active, **wkw)
+    inject = None
+    if bfs_active:  # no auto-reset: a reset would draw maps with ~10 players, which switch the searches off
+        inject = torch.as_tensor(bfs_active_maps(N, 77 + rank), device=dev).contiguous()
+        env.reset(init_grids=inject)
+    else:
+        env.reset()
+    REINJECT = 128  # bfs-active: the turtle eventually overwrites the player / key / door, so the maps are re-injected
     reducer = EpisodeStatsReducer(env.n_stats, dev)
     # synthetic input: uniform random actions, generated on device before the timed region (seed 1234 + rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     POOL = 1024
     actions = torch.randint(0, env.num_actions, (POOL, N * env.action_entries), generator=g, device=dev, dtype=torch.int32)
+    if bfs_active:
+        actions = torch.tensor(BFS_ACTIONS, dtype=torch.int32, device=dev)[
+            torch.randint(0, len(BFS_ACTIONS), (POOL, N), generator=g, device=dev)].contiguous()
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
     base, stride = actions.data_ptr(), N * env.action_entries * 4
@@ -98,6 +125,8 @@ def main():
 
     def run_eager(n, first=0):
         for k in range(first, first + n):
+            if inject is not None and k % REINJECT == 0:
+                env._L.pcgrl_reset(env._h, None, inject.data_ptr(), None, sptr)
             rc = step_raw(base + (k % POOL) * stride, sptr)
             if rc:
                 raise RuntimeError(f"pcgrl_step rc={rc}")
@@ -169,7 +198,7 @@ def main():
 
         def run_rollouts(n):
             for i in range(n):
-                rc = env._L.pcgrl_rollout(env._h, base + ((i * G) % (POOL - G + 1)) * stride, G, 1, obs_r.data_ptr(), 0,
+                rc = env._L.pcgrl_rollout(env._h, base + ((i * G) % (POOL - G + 1)) * stride, G, 0 if bfs_active else 1, obs_r.data_ptr(), 0,
                                           rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
                 if rc:
                     raise RuntimeError(f"pcgrl_rollout rc={rc}")
@@ -204,8 +233,10 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, uniform random actions, auto-reset, "
-                                   "uint8 one-hot obs (channel-last)",
+            "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, "
+                                   + ("injected maps with one player / key / door, random moves and empty / solid / enemy "
+                                      "placements, no auto-reset, " if bfs_active else "uniform random actions, auto-reset, ")
+                                   + "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)",
                        "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step"},
@@ -215,10 +246,15 @@ def main():
                          "avg_launch_us": kernel_ms * 1e3},
             "episodes": ep,
         }
+        if bfs_active:
+            st = env.get_state().stats
+            both = ((st[:, 0] == 1) & (st[:, 1] == 1) & (st[:, 2] == 1)).float().mean().item()
+            out["bfs_active"] = {"reinject_every": REINJECT, "envs_with_both_searches_at_end": both,
+                                 "envs_with_one_player_at_end": (st[:, 0] == 1).float().mean().item()}
         if rollout is not None:
             out["open_loop_rollout"] = rollout
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw)
+            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -239,7 +275,7 @@ def profiled_traffic(workload, n_envs):
     return best
 
 
-def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None):
+def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=False):
     """The oracle (a C port of the reference's algorithm, OpenMP over envs) on the host cores of this box:
     same workload, bounded sample."""
     import numpy as np
@@ -261,13 +297,16 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None):
     def rate(threads, seconds):
         orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads,
                               **(wkw or {}))
-        orc.reset()
+        if bfs_active:
+            orc.reset(init_grids=bfs_active_maps(n_envs, 77))
+        else:
+            orc.reset()
         for k in range(2):
-            orc.step(acts[k], auto_reset=True)
+            orc.step(acts[k], auto_reset=not bfs_active)
         t0 = time.perf_counter()
         steps = 0
         while True:
-            orc.step(acts[steps % 64], auto_reset=True)
+            orc.step(acts[steps % 64], auto_reset=not bfs_active)
             steps += 1
             if steps >= 5 and time.perf_counter() - t0 > seconds:
                 break
@@ -279,6 +318,8 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None):
              "wide": int(np.prod(shape)) * po.N_TILES[problem]}[rep]
     entries = int(np.prod(wkw["act_window"])) if wkw and wkw.get("act_window") else 1
     acts = rng.integers(0, n_act, size=(64, n_envs * entries), dtype=np.int32)
+    if bfs_active:
+        acts = np.array(BFS_ACTIONS, np.int32)[rng.integers(0, len(BFS_ACTIONS), size=(64, n_envs))]
     # pick the thread count that this box actually rewards (short calibration), then time the sample
     cands = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)})
     best_threads, best_rate = 1, 0.0
@@ -287,7 +328,8 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None):
         if r > best_rate:
             best_threads, best_rate = th, r
     value, steps, dt = rate(best_threads, target_s)
-    return {"value": value, "unit": "env-steps/s", "cores": best_threads, "kind": "port",
+    one_core, _, _ = rate(1, 1.5)
+    return {"value": value, "unit": "env-steps/s", "cores": best_threads, "kind": "port", "one_core": one_core,
             "sample": f"{steps} steps x {n_envs} envs of the same workload ({dt:.1f} s, OpenMP over envs with "
                       f"{best_threads} threads of {avail} usable cores, obs encoded as uint8)"}
 
