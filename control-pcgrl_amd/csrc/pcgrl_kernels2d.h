@@ -1299,6 +1299,71 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
   }
 }
 
+// Statistics after a representation update (pcgrl_env.py:314-323), shared by step_kernel and rollout_kernel.
+//   restat  the map of this lane's env really changed (group-uniform)
+//   multi   several cells may have changed at once (representation wrappers); never set in the FAST kernels
+// binary: incremental around the edited cell(s), b[1] / b[2] (fars / best) are maintained;
+// zelda / sokoban: full refresh with the region count updated around the edited cell when it is a one-cell edit.
+template <int PROB, int LPE, typename M, bool FAST>
+__device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, bool restat, bool multi, M tile0_old,
+                                     const M *pre, M *b, M colmask, int32_t *st PHASE_ARG) {
+  constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS;
+  const bool full = PROB != PCGRL_PROB_BINARY && restat;  // binary: always incremental around the edited cell(s)
+  if (__ballot(full) != 0) {
+    int32_t ns[NS];
+    int regions_known = -1;
+    if constexpr (PROB != PCGRL_PROB_BINARY) {
+      // one-cell edit: the region count moves only around that cell
+      constexpr int RI = PROB == PCGRL_PROB_ZELDA ? 4 : 3;
+      const bool one = full && !multi;
+      if (__ballot(one) != 0) {
+        M x = M(0);
+#pragma unroll
+        for (int k = 0; k < NB; k++) x |= pre[k] ^ b[k];
+        x = one ? (x & colmask) : M(0);
+        const int r = regions_update(g, x, region_cells<PROB, M>(pre, colmask), region_cells<PROB, M>(b, colmask), st[RI]);
+        regions_known = one ? r : -1;
+      }
+    }
+    compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns, regions_known);
+    if (full) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) st[k] = ns[k];
+    }
+  }
+  if constexpr (PROB == PCGRL_PROB_BINARY) {
+    const bool inc = restat && !multi;
+    if (__ballot(inc) != 0) {
+      // incremental: only the component(s) touching the edited cell are re-swept
+      const M x = inc ? (tile0_old ^ b[0]) & colmask : M(0);
+      int reg = st[0], len = st[1];
+      M fars = b[1], best = b[2];
+      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS);
+      if (inc) {
+        st[0] = reg;
+        st[1] = len;
+        b[1] = fars;
+        b[2] = best;
+      }
+    }
+    if constexpr (!FAST) {  // several cells at once: only with the representation wrappers
+      const bool many = restat && multi;
+      if (__ballot(many) != 0) {
+        const M X = many ? (tile0_old ^ b[0]) & colmask : M(0);
+        int reg = st[0], len = st[1];
+        M fars = b[1], best = b[2];
+        binary_stats_update_multi(g, X, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
+        if (many) {
+          st[0] = reg;
+          st[1] = len;
+          b[1] = fars;
+          b[2] = best;
+        }
+      }
+    }
+  }
+}
+
 // One workgroup = two specialised wavefronts over the same 64/LPE envs:
 //   wave 0 "simulate": action -> stats -> reward/done -> auto-reset -> state write-back
 //   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
@@ -1399,61 +1464,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     return;
   }
   // the statistics can only move if the map did (with static tiles a build may have been undone: change without edit)
-  const bool restat = change && map_changed;
-  const bool full = PROB != PCGRL_PROB_BINARY && restat;  // binary: always incremental around the edited cell(s)
-  if (__ballot(full) != 0) {
-    int32_t ns[NS];
-    int regions_known = -1;
-    if constexpr (PROB != PCGRL_PROB_BINARY) {
-      // one-cell edit: the region count moves only around that cell
-      constexpr int RI = PROB == PCGRL_PROB_ZELDA ? 4 : 3;
-      const bool one = full && !multi;
-      if (__ballot(one) != 0) {
-        M x = M(0);
-#pragma unroll
-        for (int k = 0; k < NB; k++) x |= pre[k] ^ b[k];
-        x = one ? (x & colmask) : M(0);
-        const int r = regions_update(g, x, region_cells<PROB, M>(pre, colmask), region_cells<PROB, M>(b, colmask), st[RI]);
-        regions_known = one ? r : -1;
-      }
-    }
-    compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns, regions_known);
-    if (full) {
-#pragma unroll
-      for (int k = 0; k < NS; k++) st[k] = ns[k];
-    }
-  }
-  if constexpr (PROB == PCGRL_PROB_BINARY) {
-    const bool inc = restat && !multi;
-    if (__ballot(inc) != 0) {
-      // incremental: only the component(s) touching the edited cell are re-swept
-      const M x = inc ? (tile0_old ^ b[0]) & colmask : M(0);
-      int reg = st[0], len = st[1];
-      M fars = b[1], best = b[2];
-      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS);
-      if (inc) {
-        st[0] = reg;
-        st[1] = len;
-        b[1] = fars;
-        b[2] = best;
-      }
-    }
-    if constexpr (!FAST) {  // several cells at once: only with the representation wrappers
-      const bool many = restat && multi;
-      if (__ballot(many) != 0) {
-        const M X = many ? (tile0_old ^ b[0]) & colmask : M(0);
-        int reg = st[0], len = st[1];
-        M fars = b[1], best = b[2];
-        binary_stats_update_multi(g, X, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
-        if (many) {
-          st[0] = reg;
-          st[1] = len;
-          b[1] = fars;
-          b[2] = best;
-        }
-      }
-    }
-  }
+  refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && map_changed, multi, tile0_old, pre, b, colmask, st PHASE_PASS);
   PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
   // CTRL (controllable mode) is a compile-time variant so that the plain kernel carries none of its code
@@ -1596,39 +1607,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds,
                                        p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes));
     } else {
-      const bool full = PROB != PCGRL_PROB_BINARY && change;
-      if (__ballot(full) != 0) {
-        int32_t ns[NS];
-        int regions_known = -1;
-        if constexpr (PROB != PCGRL_PROB_BINARY) {
-          constexpr int RI = PROB == PCGRL_PROB_ZELDA ? 4 : 3;
-          M x = M(0);
-#pragma unroll
-          for (int i = 0; i < NB; i++) x |= pre[i] ^ b[i];
-          x = full ? (x & colmask) : M(0);
-          const int r = regions_update(g, x, region_cells<PROB, M>(pre, colmask), region_cells<PROB, M>(b, colmask), st[RI]);
-          regions_known = full ? r : -1;
-        }
-        compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns, regions_known);
-        if (full) {
-#pragma unroll
-          for (int i = 0; i < NS; i++) st[i] = ns[i];
-        }
-      }
-      if constexpr (PROB == PCGRL_PROB_BINARY) {
-        if (__ballot(change) != 0) {
-          const M x = change ? (tile0_old ^ b[0]) & colmask : M(0);
-          int reg = st[0], len = st[1];
-          M fars = b[1], best = b[2];
-          binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best);
-          if (change) {
-            st[0] = reg;
-            st[1] = len;
-            b[1] = fars;
-            b[2] = best;
-          }
-        }
-      }
+      refresh_stats<PROB, LPE, M, FAST>(g, p, e, change, false, tile0_old, pre, b, colmask, st);
       const double loss = get_loss<NS>(p.cfg, st);
       const double rew = loss - last_loss;
       last_loss = loss;
