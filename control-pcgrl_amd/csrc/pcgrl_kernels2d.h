@@ -1556,6 +1556,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   g.init();
   const bool observer = threadIdx.x >= 64;  // wave-uniform
   if (observer && p.obs == nullptr) return;
+  PHASE_DECL();  // (development builds: the shared helpers take the phase counters; nothing is flushed here)
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   const int env = blockIdx.x * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
@@ -1607,7 +1608,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds,
                                        p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes));
     } else {
-      refresh_stats<PROB, LPE, M, FAST>(g, p, e, change, false, tile0_old, pre, b, colmask, st);
+      refresh_stats<PROB, LPE, M, FAST>(g, p, e, change, false, tile0_old, pre, b, colmask, st PHASE_PASS);
       const double loss = get_loss<NS>(p.cfg, st);
       const double rew = loss - last_loss;
       last_loss = loss;
