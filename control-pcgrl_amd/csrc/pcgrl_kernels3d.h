@@ -395,6 +395,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
   const int env = blockIdx.x;
   constexpr int NS = M3_NS;
   PHASE_DECL();
+  TRACE_DECL();
   uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * M3_MAXW;  // [dirt words | overlay words]
   EnvState *S = &p.st[env];
 
@@ -591,6 +592,10 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
   }
   PHASE_MARK(6);
   PHASE_FLUSH();
+  TRACE_PUT(0, _tr0);
+  TRACE_PUT(1, TRACE_NOW());
+  TRACE_DRAIN();
+  TRACE_PUT(2, TRACE_NOW());
 }
 
 }  // namespace pcgrl

@@ -24,8 +24,12 @@ import torch
 _lib.LIB_PATH = TRACE_LIB
 from control_pcgrl_amd import VecPcgrlEnv
 
-n = 4096
-env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+three_d = "--3d" in sys.argv
+n = 1024 if three_d else 4096
+if three_d:
+    env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
+else:
+    env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
@@ -33,7 +37,7 @@ sp = torch.cuda.current_stream().cuda_stream
 for k in range(500):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
 torch.cuda.synchronize()
-blocks = n // 4
+blocks = n if three_d else n // 4
 rows = []
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(200):
@@ -46,6 +50,10 @@ for it in range(200):
     out = np.zeros(8 * blocks, np.uint64)
     env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
     t = out.reshape(blocks, 8).astype(np.int64)
+    if three_d:  # one wave per env: slots 0 start, 1 end, 2 end after the stores were acknowledged
+        t0 = t[:, 0].min()
+        rows.append(dict(start=t[:, 0] - t0, end=t[:, 1] - t0, acked=t[:, 2] - t0, per_launch_us=ev0.elapsed_time(ev1) * 1e3 / 8))
+        continue
     t0 = min(t[:, 0].min(), t[:, 2].min())
     rows.append(dict(sim_start=(t[:, 0] - t0), sim_end=(t[:, 1] - t0), obs_start=(t[:, 2] - t0),
                      obs_issued=(t[:, 3] - t0), obs_acked=(t[:, 4] - t0), per_launch_us=ev0.elapsed_time(ev1) * 1e3 / 8))
@@ -56,6 +64,14 @@ def q(a, f):
 
 
 print("all numbers in ns relative to the first wave start of the launch; median over 200 traced launches")
+if three_d:
+    for key in ("start", "end", "acked"):
+        print(f"{key:8s} median wave {np.median([q(r[key], 0.5) for r in rows]):8.0f}   p95 {np.median([q(r[key], 0.95) for r in rows]):8.0f}"
+              f"   last wave {np.median([q(r[key], 1.0) for r in rows]):8.0f}")
+    print(f"wave lifetime mean {np.median([np.mean(r['end'] - r['start']) * 10.0 for r in rows]):.0f} max "
+          f"{np.median([np.max(r['end'] - r['start']) * 10.0 for r in rows]):.0f} ns; per-launch time by HIP events "
+          f"{np.median([r['per_launch_us'] for r in rows]):.2f} us")
+    sys.exit(0)
 for key in ("sim_start", "obs_start", "sim_end", "obs_issued", "obs_acked"):
     med = np.median([q(r[key], 0.5) for r in rows])
     p95 = np.median([q(r[key], 0.95) for r in rows])
