@@ -129,3 +129,20 @@ def test_episode_stats_reduction_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_bench_bfs_active_maps_have_one_player_key_door():
+    """bench.py's SURVEY 8(d) "BFS-active" zelda workload: exactly one player / key / door per injected map, and the
+    restricted action set never places one"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import numpy as np
+    g = bench.bfs_active_maps(64, 3)
+    assert g.shape == (64, 16, 16)
+    for t in (2, 3, 4):
+        assert ((g == t).sum(axis=(1, 2)) == 1).all()
+    assert not {4 + 2, 4 + 3, 4 + 4} & set(bench.BFS_ACTIONS)
+    assert set(bench.WORKLOADS) == set(bench.ALGO_BYTES)
