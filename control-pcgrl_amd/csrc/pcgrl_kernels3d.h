@@ -31,6 +31,7 @@ struct M3Lds {
   uint4 ent[M3_ENT_CAP];        // x | y<<8 | z<<16 | kind<<24 ; len | njump<<16 ; parent ; unused
   uint32_t best[M3_MAXCELLS];   // per cell: len << 16 | accepted entry id (the `paths` dict), 0xFFFFFFFF = none
   uint16_t order[M3_MAXCELLS];  // cells in first-insertion order
+  uint32_t claim[M3_MAXCELLS];  // scratch of m3_search: lowest batch slot that wants to accept a cell (0xFFFFFFFF = none)
   uint32_t dirt[M3_MAXW + 2];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
   uint32_t pathm[M3_MAXW + 2];  // tiles of the best path
   uint32_t over[M3_MAXW + 2];   // overlay mask (transposed index) for the observation
@@ -98,39 +99,62 @@ __device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z *
 
 // One search of helper_3D.run_dijkstra from (sx,sy,sz).  Uniform over the wave; returns number of entries.
 // On overflow of the LDS queue sets *overflow.
+//
+// The reference pops one queue entry at a time.  Here up to 16 consecutive entries are taken per trip, lane 4*i + d
+// working on direction d of entry i, which is exact because:
+//   * whether entry i is accepted (:437-445) depends on earlier entries only through `best` of ITS OWN cell, so a trip is
+//     cut before the second accept candidate of one cell (slots are claimed with an LDS atomic-min; rare);
+//   * a successor is queued unless it would be a no-op when popped (cell without head-room, or `best` of its cell not
+//     longer).  `best` only ever decreases and every entry of this trip is popped before anything queued now, so testing
+//     against `best` AFTER the whole trip's accepts drops exactly entries the sequential run would reject later;
+//   * first-visit order and queue order are kept with prefix counts over the lanes (entry-major, direction-minor).
 __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, bool &overflow) {
-  for (int i = c.lane; i < c.n_cells; i += 64) L.best[i] = 0xFFFFFFFFu;
-  if (c.lane == 0) L.ent[0] = make_uint4((uint32_t)sx | ((uint32_t)sy << 8) | ((uint32_t)sz << 16) | ((uint32_t)M3_ROOT << 24), 1u, 0xFFFFFFFFu, 0u);
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  for (int i = c.lane; i < c.n_cells; i += 64) {
+    L.best[i] = NONE;
+    L.claim[i] = NONE;
+  }
+  if (c.lane == 0) L.ent[0] = make_uint4((uint32_t)sx | ((uint32_t)sy << 8) | ((uint32_t)sz << 16) | ((uint32_t)M3_ROOT << 24), 1u, NONE, 0u);
   int head = 0, tail = 1;
   n_order = 0;
   const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};  // helper_3D.py:220
-  const int dxl = c.lane < 4 ? DX[c.lane & 3] : 0, dyl = c.lane < 4 ? DY[c.lane & 3] : 0;
+  const int slot_i = c.lane >> 2, d = c.lane & 3;
+  const int dxl = DX[d], dyl = DY[d];
+  const uint64_t lt = (1ull << c.lane) - 1ull;
   while (head < tail) {
-    const uint4 e = L.ent[head];
+    const int nb = min(16, tail - head);
+    const bool live = slot_i < nb;
+    const int id = head + (live ? slot_i : 0);
+    const uint4 e = L.ent[id];
     const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255;
     const int len = e.y & 0xFFFF, nj = e.y >> 16;
     const int ci = m3_cell(c, x, y, z);
     const uint32_t b = L.best[ci];
-    bool accept = true;
-    if (b != 0xFFFFFFFFu && (int)(b >> 16) <= len) accept = false;             // :437-440
     const uint32_t cc = L.col[y * c.X + x];
-    if (accept && (z + 1 == c.Z || !((cc >> (z + 1)) & 1u))) accept = false;    // :443-445 no head-room
-    if (!accept) {
-      head++;
-      continue;
-    }
-    if (c.lane == 0) {
-      if (b == 0xFFFFFFFFu) L.order[n_order] = (uint16_t)ci;
-      L.best[ci] = ((uint32_t)len << 16) | (uint32_t)head;
-    }
-    if (b == 0xFFFFFFFFu) n_order++;
-    // successors: lane d < 4 evaluates direction d (helper_3D.py:214-319)
+    bool accept = live;
+    if (b != NONE && (int)(b >> 16) <= len) accept = false;                     // :437-440
+    if (z + 1 == c.Z || !((cc >> (z + 1)) & 1u)) accept = false;                // :443-445 no head-room
+    // cut the trip before the second accept candidate of one cell
+    if (accept && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
+    const bool dup = accept && L.claim[ci] != (uint32_t)slot_i;
+    const uint64_t dupb = __ballot(dup);
+    const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 always owns its cell
+    if (accept && d == 0) L.claim[ci] = NONE;
+    const bool doit = accept && slot_i < nproc;
+    const bool first = doit && d == 0 && b == NONE;
+    const uint64_t fb = __ballot(first);
+    if (first) L.order[n_order + __popcll(fb & lt)] = (uint16_t)ci;
+    n_order += __popcll(fb);
+    if (doit && d == 0) L.best[ci] = ((uint32_t)len << 16) | (uint32_t)id;
+    // successors: direction d of entry slot_i (helper_3D.py:214-319)
     bool ok = false;
     int tx = 0, ty = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
-    if (c.lane < 4) {
+    uint32_t ct = 0;  // column mask of the target cell
+    if (doit) {
       const int nx = x + dxl, ny = y + dyl, nz = z, jx = x + 2 * dxl, jy = y + 2 * dyl;
       if (nx >= 0 && ny >= 0 && nx < c.X && ny < c.Y) {
         const uint32_t cn = L.col[ny * c.X + nx];
+        ct = cn;
         auto A = [&](uint32_t col, int k) -> bool { return (col >> k) & 1u; };
         if ((nz == 0 || !A(cn, nz - 1)) && A(cn, nz) && A(cn, nz + 1)) {
           ok = true; tx = nx; ty = ny; tz = nz; kind = M3_WALK; add = 1;
@@ -141,6 +165,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
         } else if (nz - 2 >= 0 && nz + 2 < c.Z && A(cn, nz + 2) && A(cn, nz + 1) && A(cn, nz) && A(cn, nz - 1) && A(cn, nz - 2) &&
                    A(cc, nz + 2) && jx >= 0 && jy >= 0 && jx < c.X && jy < c.Y) {
           const uint32_t cj = L.col[jy * c.X + jx];
+          ct = cj;
           const int jz = z;
           if (A(cj, jz + 1) && A(cj, jz + 2) && A(cj, jz) && !A(cj, jz - 1)) {
             ok = true; tx = jx; ty = jy; tz = jz; kind = M3_JFLAT; add = 2; nj2 = nj + 1;
@@ -152,14 +177,11 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
         }
       }
     }
-    // Push-time pruning (exact): an entry whose cell already holds a path that is not longer, or whose cell has no
-    // head-room, is a no-op when popped (:437-445; best lengths only ever decrease), so it is never queued.
-    if (ok) {
-      const uint32_t ct = L.col[ty * c.X + tx];
+    if (ok) {  // never queue what would be a no-op when popped
       if (tz + 1 == c.Z || !((ct >> (tz + 1)) & 1u)) ok = false;
       if (ok) {
         const uint32_t bt = L.best[m3_cell(c, tx, ty, tz)];
-        if (bt != 0xFFFFFFFFu && (int)(bt >> 16) <= len + add) ok = false;
+        if (bt != NONE && (int)(bt >> 16) <= len + add) ok = false;
       }
     }
     const uint64_t okb = __ballot(ok);
@@ -168,13 +190,11 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
       overflow = true;
       break;
     }
-    if (ok) {
-      const int slot = tail + __popcll(okb & ((1ull << c.lane) - 1ull));
-      L.ent[slot] = make_uint4((uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)tz << 16) | ((uint32_t)kind << 24),
-                               (uint32_t)(len + add) | ((uint32_t)nj2 << 16), (uint32_t)head, 0u);
-    }
+    if (ok)
+      L.ent[tail + __popcll(okb & lt)] = make_uint4((uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)tz << 16) | ((uint32_t)kind << 24),
+                                                    (uint32_t)(len + add) | ((uint32_t)nj2 << 16), (uint32_t)id, 0u);
     tail += npush;
-    head++;
+    head += nproc;
   }
   return tail;
 }
