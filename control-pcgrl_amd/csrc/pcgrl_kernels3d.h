@@ -129,17 +129,26 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255;
     const int len = e.y & 0xFFFF, nj = e.y >> 16;
     const int ci = m3_cell(c, x, y, z);
+    // everything that depends only on the entry is requested in one LDS round trip: its cell's `best`, its column and
+    // the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map)
+    const int nx = x + dxl, ny = y + dyl, jx = x + 2 * dxl, jy = y + 2 * dyl;
+    const bool n_in = nx >= 0 && ny >= 0 && nx < c.X && ny < c.Y, j_in = jx >= 0 && jy >= 0 && jx < c.X && jy < c.Y;
     const uint32_t b = L.best[ci];
     const uint32_t cc = L.col[y * c.X + x];
+    const uint32_t cn = L.col[n_in ? ny * c.X + nx : 0];
+    const uint32_t cj = L.col[j_in ? jy * c.X + jx : 0];
     bool accept = live;
     if (b != NONE && (int)(b >> 16) <= len) accept = false;                     // :437-440
     if (z + 1 == c.Z || !((cc >> (z + 1)) & 1u)) accept = false;                // :443-445 no head-room
-    // cut the trip before the second accept candidate of one cell
-    if (accept && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
-    const bool dup = accept && L.claim[ci] != (uint32_t)slot_i;
-    const uint64_t dupb = __ballot(dup);
-    const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 always owns its cell
-    if (accept && d == 0) L.claim[ci] = NONE;
+    // cut the trip before the second accept candidate of one cell (nothing to check for a single entry)
+    int nproc = nb;
+    if (nb > 1) {
+      if (accept && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
+      const bool dup = accept && L.claim[ci] != (uint32_t)slot_i;
+      const uint64_t dupb = __ballot(dup);
+      if (dupb) nproc = __builtin_ctzll(dupb) >> 2;  // >= 1: slot 0 always owns its cell
+      if (accept && d == 0) L.claim[ci] = NONE;
+    }
     const bool doit = accept && slot_i < nproc;
     const bool first = doit && d == 0 && b == NONE;
     const uint64_t fb = __ballot(first);
@@ -151,9 +160,8 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     int tx = 0, ty = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
     uint32_t ct = 0;  // column mask of the target cell
     if (doit) {
-      const int nx = x + dxl, ny = y + dyl, nz = z, jx = x + 2 * dxl, jy = y + 2 * dyl;
-      if (nx >= 0 && ny >= 0 && nx < c.X && ny < c.Y) {
-        const uint32_t cn = L.col[ny * c.X + nx];
+      const int nz = z;
+      if (n_in) {
         ct = cn;
         auto A = [&](uint32_t col, int k) -> bool { return (col >> k) & 1u; };
         if ((nz == 0 || !A(cn, nz - 1)) && A(cn, nz) && A(cn, nz + 1)) {
@@ -163,8 +171,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
         } else if (nz + 2 < c.Z && !A(cn, nz) && A(cn, nz + 1) && A(cn, nz + 2) && A(cc, nz + 2)) {
           ok = true; tx = nx; ty = ny; tz = nz + 1; kind = M3_UP; add = 2;
         } else if (nz - 2 >= 0 && nz + 2 < c.Z && A(cn, nz + 2) && A(cn, nz + 1) && A(cn, nz) && A(cn, nz - 1) && A(cn, nz - 2) &&
-                   A(cc, nz + 2) && jx >= 0 && jy >= 0 && jx < c.X && jy < c.Y) {
-          const uint32_t cj = L.col[jy * c.X + jx];
+                   A(cc, nz + 2) && j_in) {
           ct = cj;
           const int jz = z;
           if (A(cj, jz + 1) && A(cj, jz + 2) && A(cj, jz) && !A(cj, jz - 1)) {
