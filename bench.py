@@ -189,7 +189,7 @@ def main():
     # engine's counterpart of the reference's random-action profiling loop (profile_env.py:124-142).  Never `value`.
     rollout = None
     G = args.rollout_steps
-    if G > 0 and not wkw and POOL >= G:
+    if G > 0 and not wkw and not bfs_active and POOL >= G:  # (bfs-active needs the periodic map injection)
         R = max(1, K // G)
         obs_r = torch.empty((G, N) + env.obs_shape, dtype=torch.uint8, device=dev)
         rew_r = torch.empty((G, N), dtype=torch.float32, device=dev)
