@@ -1072,17 +1072,17 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
 
 // ------------------------------------------------------------------------------------------------ kernels
 constexpr int ROW_WORDS = 3;  // words per map row in HBM: tile bit-planes (1 or 3) [+ fars, best for binary]
-template <int N, typename M>
+template <int N, typename M, bool MAP16 = false>
 __device__ inline void load_planes(const Params &p, int env, int row, bool ok, M *b) {
   const M *pl = (const M *)p.planes;
-  const int H = p.cfg.dims[0];
+  const int H = MAP16 ? 16 : p.cfg.dims[0];
 #pragma unroll
   for (int k = 0; k < N; k++) b[k] = ok ? pl[((size_t)env * ROW_WORDS + k) * H + row] : M(0);
 }
-template <int N, typename M>
+template <int N, typename M, bool MAP16 = false>
 __device__ inline void store_planes(const Params &p, int env, int row, bool ok, const M *b) {
   M *pl = (M *)p.planes;
-  const int H = p.cfg.dims[0];
+  const int H = MAP16 ? 16 : p.cfg.dims[0];
   if (ok) {
 #pragma unroll
     for (int k = 0; k < N; k++) pl[((size_t)env * ROW_WORDS + k) * H + row] = b[k];
@@ -1090,11 +1090,11 @@ __device__ inline void store_planes(const Params &p, int env, int row, bool ok, 
 }
 
 // reps/*.update(): returns change flag (uniform over the group); edits the owning lane's planes, updates pos/n_step
-template <int PROB, int LPE, typename M>
+template <int PROB, int LPE, typename M, bool MAP16 = false>
 __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool active, int action, M *b, int *pos,
                                   int &n_step, bool &bad_action) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
-  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int H = MAP16 ? 16 : p.cfg.dims[0], W = MAP16 ? 16 : p.cfg.dims[1];  // MAP16: the 16x16 (FAST) kernels
   int r = pos[0], c = pos[1], tile = -1;
   switch (p.cfg.representation) {
     case PCGRL_REP_NARROW:  // narrow_rep.py:89-102
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   if (observer && p.obs == nullptr) return;  // (no barrier below is reached by wave 0 in that case either)
   PHASE_DECL();
   TRACE_DECL();
-  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
   const int env = (blockIdx.x * PAIRS + pair) * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
   const bool rowok = active && g.row < H;
@@ -1394,9 +1394,9 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
 
   M b[NW];
   if (observer)
-    load_planes<NB, M>(p, e, g.row, rowok, b);
+    load_planes<NB, M, FAST>(p, e, g.row, rowok, b);
   else
-    load_planes<NW, M>(p, e, g.row, rowok, b);
+    load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
   // representation wrappers (static tiles / action patch): run-time option of the general kernels only
   ExtRow<NB, M> X;
   bool ext = false;
@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   if (ext) {
     change = rep_update_ext<PROB, LPE, M>(g, p, e, active, action, b, pos, n_step, bad, X, map_changed, multi);
   } else {
-    change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
+    change = rep_update<PROB, LPE, M, FAST>(g, p, active, action, b, pos, n_step, bad);
     map_changed = change;
   }
   changes += (change && !upd_only) ? 1 : 0;
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   if (bad && g.row == 0 && active) atomicOr(p.err, 1);
   PHASE_MARK(1);  // action + second state loads
   if (upd_only) {  // grid / position only; stats (and the binary fars/best masks) are rebuilt by pcgrl_refresh_stats
-    if (change) store_planes<NB, M>(p, e, g.row, rowok, b);
+    if (change) store_planes<NB, M, FAST>(p, e, g.row, rowok, b);
     if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, false);
     if (active && g.row == 0) {
       S->pos[0] = pos[0];
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     }
   }
   // write back state
-  if (change || do_reset) store_planes<NW, M>(p, e, g.row, rowok, b);
+  if (change || do_reset) store_planes<NW, M, FAST>(p, e, g.row, rowok, b);
   if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, do_reset);
   if (active && g.row == 0) {
     if constexpr (CTRL) {
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   const bool observer = threadIdx.x >= 64;  // wave-uniform
   if (observer && p.obs == nullptr) return;
   PHASE_DECL();  // (development builds: the shared helpers take the phase counters; nothing is flushed here)
-  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
   const int env = blockIdx.x * EPW + (g.lane / LPE);
   const bool active = env < p.n_envs;
   const bool rowok = active && g.row < H;
@@ -1568,9 +1568,9 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
 
   M b[NW];
   if (observer)
-    load_planes<NB, M>(p, e, g.row, rowok, b);
+    load_planes<NB, M, FAST>(p, e, g.row, rowok, b);
   else
-    load_planes<NW, M>(p, e, g.row, rowok, b);
+    load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
@@ -1595,7 +1595,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
     for (int i = 0; i < NB; i++) pre[i] = b[i];
     bool bad = false;
     iteration++;
-    const bool change = rep_update<PROB, LPE, M>(g, p, active, action, b, pos, n_step, bad);
+    const bool change = rep_update<PROB, LPE, M, FAST>(g, p, active, action, b, pos, n_step, bad);
     changes += change ? 1 : 0;
     bool done = iteration > p.cfg.max_iterations;
     if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   }
   if (observer) return;
   if (bad_any && g.row == 0 && active) atomicOr(p.err, 1);
-  if (any_change || any_reset) store_planes<NW, M>(p, e, g.row, rowok, b);
+  if (any_change || any_reset) store_planes<NW, M, FAST>(p, e, g.row, rowok, b);
   if (active && g.row == 0) {
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
