@@ -428,10 +428,17 @@ __device__ inline void binary_stats_full(const Grp<LPE> &g, M pass, int &regions
 // after editing the single cell `x` (row mask, 0 for groups without a change): old passable set p_old, new p_new
 template <int LPE, typename M>
 __device__ inline void binary_stats_update(const Grp<LPE> &g, M x, M p_old, M p_new, int &regions,
-                                           int &path_len, M &fars, M &best PHASE_ARG) {
+                                           int &path_len, M &fars, M &best PHASE_ARG, bool have_pre = false,
+                                           M pre = M(0)) {
   const bool became_pass = g.gany((x & p_new) != 0);
   // cells of the affected components in the NEW map: the merged component of x, or the old component of x minus x
-  M K = flood(g, x, became_pass ? p_new : p_old);
+  // (have_pre: the component of x with x passable was flooded ahead of time, see PREFLOOD)
+  const bool edited = g.gany(x != 0);
+  M K = edited ? pre : M(0);
+  if (__ballot(edited && !have_pre) != 0) {
+    const M Kf = flood(g, x, became_pass ? p_new : p_old);
+    K = have_pre ? K : Kf;
+  }
   K = became_pass ? K : (K & ~x);
   const M touched = K | x;
   const bool hit = g.gany((best & touched) != 0);
@@ -1071,7 +1078,16 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-constexpr int ROW_WORDS = 3;  // words per map row in HBM: tile bit-planes (1 or 3) [+ fars, best for binary]
+// words per map row in HBM: tile bit-planes (1 or 3) [+ fars, best for binary] + the pre-flood plane (see PREFLOOD)
+constexpr int ROW_WORDS = 4;
+// PREFLOOD (binary, narrow / turtle, 16x16 kernels).  The narrow representation visits the cells in a fixed order and the
+// turtle only edits the cell it stands on, so the cell of the NEXT edit is known one step ahead.  The component that cell belongs to once it is passable -- the only thing the
+// incremental update needs a flood fill for -- is computed by the observe wave of the PREVIOUS launch, after it has issued
+// its observation stores and while the simulate wave is still searching, and handed over in plane 3 of the state (bit 31
+// of every row word = valid).  This takes the flood fill of the slowest env off the critical path of the next launch.
+// Every path that changes map or position without refreshing the plane clears it (then the flood runs in the kernel).
+constexpr int PRE_PLANE = 3;
+constexpr uint32_t PRE_VALID = 1u << 31;
 template <int N, typename M, bool MAP16 = false>
 __device__ inline void load_planes(const Params &p, int env, int row, bool ok, M *b) {
   const M *pl = (const M *)p.planes;
@@ -1306,7 +1322,8 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
 // zelda / sokoban: full refresh with the region count updated around the edited cell when it is a one-cell edit.
 template <int PROB, int LPE, typename M, bool FAST>
 __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, bool restat, bool multi, M tile0_old,
-                                     const M *pre, M *b, M colmask, int32_t *st PHASE_ARG) {
+                                     const M *pre, M *b, M colmask, int32_t *st PHASE_ARG, bool have_pre = false,
+                                     M preflood = M(0)) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS;
   const bool full = PROB != PCGRL_PROB_BINARY && restat;  // binary: always incremental around the edited cell(s)
   if (__ballot(full) != 0) {
@@ -1338,7 +1355,7 @@ __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, 
       const M x = inc ? (tile0_old ^ b[0]) & colmask : M(0);
       int reg = st[0], len = st[1];
       M fars = b[1], best = b[2];
-      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS);
+      binary_stats_update(g, x, ~tile0_old & colmask, ~b[0] & colmask, reg, len, fars, best PHASE_PASS, have_pre, preflood);
       if (inc) {
         st[0] = reg;
         st[1] = len;
@@ -1404,6 +1421,13 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     ext = p.ext != 0;
     if (ext) X.load(p, e, g.row, rowok);
   }
+  // PREFLOOD hand-over plane (binary 16x16 kernels): written by the observe wave of the previous launch
+  constexpr bool PRE = FAST && PROB == PCGRL_PROB_BINARY;
+  M *pre_word = (M *)p.planes + ((size_t)e * ROW_WORDS + PRE_PLANE) * (FAST ? 16 : p.cfg.dims[0]) + g.row;
+  M pre3 = M(0);
+  if constexpr (PRE) {
+    if (!observer && rowok) pre3 = *pre_word;
+  }
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
@@ -1439,6 +1463,15 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
       encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds);
     else
       encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds);
+    if constexpr (PRE) {
+      // narrow: the next edit goes to `pos`; turtle: an edit can only happen at `pos` (moves edit nothing).  Flood the
+      // component of that cell ahead of time.
+      if (p.cfg.representation != PCGRL_REP_WIDE) {
+        const M xbit = (rowok && g.row == pos[0]) ? (M(1) << pos[1]) : M(0);
+        const M comp = flood(g, xbit, (~b[0] & colmask) | xbit);
+        if (rowok) *pre_word = comp | (M)PRE_VALID;
+      }
+    }
     TRACE_PUT(2, _tr0);
     TRACE_PUT(3, TRACE_NOW());
     TRACE_DRAIN();
@@ -1455,6 +1488,9 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   PHASE_MARK(1);  // action + second state loads
   if (upd_only) {  // grid / position only; stats (and the binary fars/best masks) are rebuilt by pcgrl_refresh_stats
     if (change) store_planes<NB, M, FAST>(p, e, g.row, rowok, b);
+    if constexpr (PRE) {
+      if (p.obs == nullptr && rowok && pre3 != M(0)) *pre_word = M(0);  // no observe wave: the plane goes stale
+    }
     if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, false);
     if (active && g.row == 0) {
       S->pos[0] = pos[0];
@@ -1464,7 +1500,8 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     return;
   }
   // the statistics can only move if the map did (with static tiles a build may have been undone: change without edit)
-  refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && map_changed, multi, tile0_old, pre, b, colmask, st PHASE_PASS);
+  refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && map_changed, multi, tile0_old, pre, b, colmask, st PHASE_PASS,
+                                    PRE && g.gany((pre3 & (M)PRE_VALID) != 0), pre3 & colmask);
   PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
   // CTRL (controllable mode) is a compile-time variant so that the plain kernel carries none of its code
@@ -1520,6 +1557,9 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   }
   // write back state
   if (change || do_reset) store_planes<NW, M, FAST>(p, e, g.row, rowok, b);
+  if constexpr (PRE) {
+    if (p.obs == nullptr && rowok && pre3 != M(0)) *pre_word = M(0);  // no observe wave: the plane goes stale
+  }
   if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, do_reset);
   if (active && g.row == 0) {
     if constexpr (CTRL) {
@@ -1655,6 +1695,9 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   if (observer) return;
   if (bad_any && g.row == 0 && active) atomicOr(p.err, 1);
   if (any_change || any_reset) store_planes<NW, M, FAST>(p, e, g.row, rowok, b);
+  if constexpr (PROB == PCGRL_PROB_BINARY) {  // PREFLOOD plane: stale after a rollout
+    if (rowok) ((M *)p.planes)[((size_t)e * ROW_WORDS + PRE_PLANE) * H + g.row] = M(0);
+  }
   if (active && g.row == 0) {
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
@@ -1722,6 +1765,9 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   int32_t st[NS];
   compute_stats<PROB, LPE, M>(g, p, e, active, b, colmask, st);
   store_planes<NW, M>(p, e, g.row, rowok, b);
+  if constexpr (PROB == PCGRL_PROB_BINARY) {  // PREFLOOD plane: stale after a reset (map and position changed)
+    if (rowok && !p.refresh_only) ((M *)p.planes)[((size_t)e * ROW_WORDS + PRE_PLANE) * H + g.row] = M(0);
+  }
   if (ext && !p.refresh_only) X.store(p, e, g.row, rowok, active && g.row == 0, true);
   if (p.refresh_only) {
     if (active && g.row == 0) {
