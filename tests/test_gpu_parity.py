@@ -697,3 +697,48 @@ def test_golden_reference_test3d_maps():
         got = env.stats_for_grids(torch.as_tensor(g)).cpu().numpy()[0]
         assert np.array_equal(got, z["stats"][i]), f"{z['names'][i]} {sh}: got {got}, reference {z['stats'][i]}"
         env.close()
+
+
+@pytest.mark.parametrize("rep", ["narrow", "turtle"])
+def test_steps_without_observation_output_and_mixed_call_sequences(rep):
+    """pcgrl_step with d_obs = NULL (no observe wave), mixed with normal steps, updates, refreshes, rollouts and masked
+    resets: the hand-over plane of the pre-flooded component must never be used stale"""
+    n = 256
+    env = _vec("binary", rep, (16, 16), n, seeds=5 + np.arange(n), auto_reset=True, change_percentage=0.4)
+    orc = po.OracleVecEnv("binary", rep, (16, 16), n, seeds=5 + np.arange(n), threads=8, change_percentage=0.4)
+    assert np.array_equal(env.reset()[0].cpu().numpy(), orc.reset())
+    g = torch.Generator().manual_seed(4)
+    sp = torch.cuda.current_stream().cuda_stream
+    for t in range(400):
+        a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        ad = a.to(env.device)
+        kind = t % 7
+        if kind in (0, 1, 2):  # normal step
+            obs, rew, done, _, info = env.step(ad)
+            oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True)
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+        elif kind in (3, 4):  # no observation output
+            _lib_check = env._L.pcgrl_step(env._h, ad.data_ptr(), 1, None, env._ptrs[1], env._ptrs[2], env._ptrs[3], sp)
+            assert _lib_check == 0
+            info = {"stats": env._stats}
+            oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=False)
+        elif kind == 5:  # rep.update only, then a stats refresh
+            env.update(ad)
+            orc.update(a.numpy())
+            assert np.array_equal(env.refresh_stats().cpu().numpy(), orc.refresh_stats())
+            continue
+        else:  # a short rollout, or a masked reset
+            if t % 14 == 6:
+                acts = torch.randint(0, env.num_actions, (3, n), generator=g, dtype=torch.int32)
+                _, _, _, stats = env.rollout(acts.to(env.device), want_obs="none")
+                for k in range(3):
+                    _, _, _, ostats = orc.step(acts[k].numpy(), auto_reset=True, want_obs=False)
+                info = {"stats": stats[-1]}
+            else:
+                mask = (torch.arange(n) % 3 == 0).to(torch.uint8)
+                env.reset(mask=mask)
+                orc.reset(mask=mask.numpy())
+                continue
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t} (kind {kind})"
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    env.check_errors()
