@@ -1,10 +1,11 @@
 // pcgrl_common.h -- state layout shared by the host API (pcgrl_engine.hip) and the gfx950 kernels.
 //
 // HBM layout (all arrays owned by the engine, contiguous over envs):
-//   planes  M[N][NB][H]   tile grid as NB = ceil(log2(n_tiles)) bit-planes; word (e,k,r) holds bit k of the
-//                         tile ids of row r (bit x = column x).  One wavefront lane owns one row, so a
-//                         16x16 binary map is 16 consecutive 32-bit words and a group of 16 lanes loads
-//                         its env with one coalesced 64-byte access per plane.
+//   planes  M[N][ROW_WORDS = 4][H]  planes 0..NB-1: tile grid as NB = ceil(log2(n_tiles)) bit-planes; word (e,k,r)
+//                         holds bit k of the tile ids of row r (bit x = column x).  One wavefront lane owns one row, so
+//                         a 16x16 binary map is 16 consecutive 32-bit words and a group of 16 lanes loads its env with
+//                         one coalesced 64-byte access per plane.  binary: planes 1, 2 = fars / best (incremental
+//                         path-length state), plane 3 = pre-flooded component of the next edit cell (PREFLOOD).
 //   st      EnvState[N]   128-byte record of per-env scalars (one cache line).
 //   rng     RngState[N]   two PCG64 streams (representation, problem), numpy-compatible.
 //   xplanes M[N][1+NB][H] only with static tiles / action patches: static mask + lagging bordered-map planes
