@@ -742,3 +742,17 @@ def test_steps_without_observation_output_and_mixed_call_sequences(rep):
         assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t} (kind {kind})"
     assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
     env.check_errors()
+
+
+def test_rollout_rejects_modes_it_does_not_cover():
+    a = torch.zeros((2, 4), dtype=torch.int32)
+    env = _vec("binary", "narrow", (16, 16), 4, controls=["regions"], reward_dtype=torch.float64)
+    env.reset()
+    with pytest.raises(NotImplementedError):
+        env.rollout(a.to(env.device))
+    env2 = _vec("binary", "narrow", (16, 16), 4, static_prob=0.2)
+    env2.reset()
+    with pytest.raises(NotImplementedError):
+        env2.rollout(a.to(env2.device))
+    with pytest.raises(ValueError):
+        _vec("binary", "narrow", (16, 16), 4).rollout(torch.zeros((2, 5), dtype=torch.int32))
