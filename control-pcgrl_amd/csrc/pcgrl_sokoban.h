@@ -360,6 +360,8 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
   const SokoPool &pool = *(const SokoPool *)p.soko;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   constexpr int EPW = 64 / LPE;
+  // one simulate wave per workgroup calls the solver, and it serves its groups one after the other
+  __shared__ SokoLevel s_level;
   for (int gi = 0; gi < EPW; gi++) {
     const bool mine = need && (g.lane / LPE) == gi;
     if (__ballot(mine) == 0) continue;
@@ -377,7 +379,7 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
       slot = s;
       uint8_t *b = pool.base + (size_t)slot * pool.slot_bytes;
       c.max_nodes = pool.max_nodes;
-      c.lv = (SokoLevel *)b;
+      c.lv = &s_level;  // the level description (wall / dead / target / occupancy rows) is the hottest data: LDS
       b += (sizeof(SokoLevel) + 15) & ~(size_t)15;
       c.nodes = (SokoNode *)b;
       b += sizeof(SokoNode) * (size_t)c.max_nodes;
