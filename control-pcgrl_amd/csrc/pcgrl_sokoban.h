@@ -187,13 +187,20 @@ __device__ inline uint32_t sk_hash(const SokoCtx &c, int n) {
   uint32_t h = 2166136261u;
   h = (h ^ c.nodes[n].px) * 16777619u;
   h = (h ^ c.nodes[n].py) * 16777619u;
-  for (int i = 0; i < 2 * c.ncr; i++) h = (h ^ cr[i]) * 16777619u;
+  // 8 bytes at a time: the crate lists are 256-byte aligned and zero-padded to a multiple of 8 bytes (root: see
+  // sokoban_solve; children copy whole words), so equal keys hash and compare equal word by word
+  const uint64_t *w = (const uint64_t *)cr;
+  for (int i = 0; i < (2 * c.ncr + 7) / 8; i++) {
+    const uint64_t v = w[i];
+    h = (h ^ (uint32_t)v) * 16777619u;
+    h = (h ^ (uint32_t)(v >> 32)) * 16777619u;
+  }
   return h;
 }
 __device__ inline bool sk_same_key(const SokoCtx &c, int a, int b) {  // State.getKey engine.py:330-336
   if (c.nodes[a].px != c.nodes[b].px || c.nodes[a].py != c.nodes[b].py) return false;
-  const uint8_t *ca = sk_crates(c, a), *cb = sk_crates(c, b);
-  for (int i = 0; i < 2 * c.ncr; i++)
+  const uint64_t *ca = (const uint64_t *)sk_crates(c, a), *cb = (const uint64_t *)sk_crates(c, b);
+  for (int i = 0; i < (2 * c.ncr + 7) / 8; i++)
     if (ca[i] != cb[i]) return false;
   return true;
 }
@@ -256,7 +263,7 @@ __device__ inline int sk_children(SokoCtx &c, int n, int *out) {
     }
     int k = c.n_nodes++;
     uint8_t *ncr = sk_crates(c, k);
-    for (int i = 0; i < 2 * c.ncr; i++) ncr[i] = cr[i];
+    for (int i = 0; i < (2 * c.ncr + 7) / 8; i++) ((uint64_t *)ncr)[i] = ((const uint64_t *)cr)[i];
     if (moved >= 0) {
       ncr[2 * moved] = (uint8_t)(nx + DX[d]);
       ncr[2 * moved + 1] = (uint8_t)(ny + DY[d]);
@@ -438,6 +445,7 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
         atomicOr(p.err, 2);  // beyond the device solver's limits: reported by pcgrl_poll_error
       } else {
         c.ncr = ncr;
+        for (int i = 2 * ncr; i < ((2 * ncr + 7) / 8) * 8; i++) c.crates[i] = 0;  // zero padding of the root's crate list
         c.lv->ncr = ncr;
         c.lv->ntg = ntg;
         sk_init_deadlocks(c);
