@@ -6,15 +6,25 @@ stats -> reward -> done/auto-reset -> cropped one-hot observation written to HBM
 BASELINE configs[1]: binary-narrow 16x16, 4096 envs on one GPU, uniform random actions, auto-reset.
 Inputs (actions) are resident in HBM before the timed region; outputs (obs/reward/done/stats) are written to HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: one process per GPU.  Started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+the script is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment); started plainly it launches the N
+ranks itself (child processes, before anything in this process touches the GPU) and relays rank 0's line.
+
+Timed region = K launches + the path's only exchange (pcgrl_reduce_episodes: one launch; all-reduce over RCCL
+when N > 1; one device->host copy), bracketed by barrier + synchronize, max over ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM bandwidth with the algorithmic
-bytes of SURVEY.md section 8(d); `cpu_baseline` is the CPU oracle (oracle/, a port of the reference's algorithm)
-timed on this box's host cores on a bounded sample of the same workload.
+bytes of SURVEY.md section 8(d): `achieved` / `frac` use the same wall clock as `value`, `achieved_hip_events` /
+`frac_hip_events` the HIP-event time of the K launches on the launch stream.  `cpu_baseline` is the CPU oracle
+(oracle/, a port of the reference's algorithm) timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -70,18 +80,47 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=64,
                     help="also time the open-loop rollout kernel (pcgrl_rollout) with this many steps per launch and "
                          "report it as `open_loop_rollout`; 0 = skip")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / sharding only (gloo, no GPU, nothing timed): what the CPU test of the N > 1 path runs")
+    ap.add_argument("--rollout-launches", type=int, default=200, help="timed pcgrl_rollout launches of the secondary figure")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU (no
+        # torch import yet), and the ranks are ordinary child processes -- never an exec of a process that holds a GPU.
+        sys.exit(launch_ranks(args.gpus))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (it launches its own ranks) "
+                 f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from control_pcgrl_amd import VecPcgrlEnv
-    from control_pcgrl_amd.dist import EpisodeStatsReducer, shard_seeds
+    from control_pcgrl_amd.dist import shard_env_range, shard_seeds
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        n_envs = args.envs or WORKLOADS[args.workload][3]
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        mine = torch.tensor(shard_seeds(0x5EED, n_envs * world, rank, world)[:: max(1, n_envs - 1)], dtype=torch.int64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "envs_per_gpu": n_envs, "global_envs": n_envs * world,
+                              "first_last_seed_per_rank": [e.tolist() for e in every]}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # test hooks (a 1-GPU box can still exercise the multi-process path): all ranks on one device, gloo collectives
     if os.environ.get("PCGRL_BENCH_SINGLE_DEVICE"):
         local_rank = 0
@@ -89,11 +128,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     problem, rep, shape, default_envs = WORKLOADS[args.workload][:4]
@@ -110,7 +149,6 @@ def main():
     else:
         env.reset()
     REINJECT = 128  # bfs-active: the turtle eventually overwrites the player / key / door, so the maps are re-injected
-    reducer = EpisodeStatsReducer(env.n_stats, dev)
     # synthetic input: uniform random actions, generated on device before the timed region (seed 1234 + rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     POOL = 1024
@@ -156,78 +194,102 @@ def main():
             graph.replay()
         run_eager(n % G, first=G)
 
-    run(W)
-    # warm the reporting path too (first use loads torch's reduction kernels), then start from clean accumulators
-    reducer.update_from_env(env)
-    reducer.reduce(device=coll_dev)
-    reducer.reset()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(K)
-    ev1.record(stream)
-    # the path's only exchange: episodic-return reduction (one small all-reduce over RCCL when world > 1)
-    reducer.update_from_env(env)
-    ep = reducer.reduce(device=coll_dev)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
-    env.check_errors()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
-    # Secondary figure: the same K steps through pcgrl_rollout (G steps per launch, every observation written), the
-    # engine's counterpart of the reference's random-action profiling loop (profile_env.py:124-142).  Never `value`.
+    def max_over_ranks(x):
+        if world == 1:
+            return x, [x]
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        vals = [float(v.item()) for v in every]
+        return max(vals), vals
+
+    # Secondary figure, measured FIRST (it also brings the device to its steady clocks before the short timed region
+    # below): the open-loop rollout kernel (pcgrl_rollout, GR steps per launch, every observation written), the engine's
+    # counterpart of the reference's random-action profiling loop (profile_env.py:124-142).  Its size does not depend
+    # on --steps.  Never `value`.
     rollout = None
-    G = args.rollout_steps
-    if G > 0 and not wkw and not bfs_active and POOL >= G:  # (bfs-active needs the periodic map injection)
-        R = max(1, K // G)
-        obs_r = torch.empty((G, N) + env.obs_shape, dtype=torch.uint8, device=dev)
-        rew_r = torch.empty((G, N), dtype=torch.float32, device=dev)
-        done_r = torch.empty((G, N), dtype=torch.uint8, device=dev)
-        stats_r = torch.empty((G, N, env.n_stats), dtype=torch.int32, device=dev)
+    GR = args.rollout_steps
+    if GR > 0 and not wkw and not bfs_active and POOL >= GR:  # (bfs-active needs the periodic map injection)
+        R = max(args.rollout_launches, 1)
+        obs_r = torch.empty((GR, N) + env.obs_shape, dtype=torch.uint8, device=dev)
+        rew_r = torch.empty((GR, N), dtype=torch.float32, device=dev)
+        done_r = torch.empty((GR, N), dtype=torch.uint8, device=dev)
+        stats_r = torch.empty((GR, N, env.n_stats), dtype=torch.int32, device=dev)
 
         def run_rollouts(n):
             for i in range(n):
-                rc = env._L.pcgrl_rollout(env._h, base + ((i * G) % (POOL - G + 1)) * stride, G, 0 if bfs_active else 1, obs_r.data_ptr(), 0,
+                rc = env._L.pcgrl_rollout(env._h, base + ((i * GR) % (POOL - GR + 1)) * stride, GR, 1, obs_r.data_ptr(), 0,
                                           rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
                 if rc:
                     raise RuntimeError(f"pcgrl_rollout rc={rc}")
 
         run_rollouts(max(1, R // 10))
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        barrier()
         t1 = time.perf_counter()
         run_rollouts(R)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        el_r = time.perf_counter() - t1
+        barrier()
+        el_r, _ = max_over_ranks(time.perf_counter() - t1)
         env.check_errors()
-        if world > 1:
-            t = torch.tensor([el_r], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_r = float(t.item())
-        us = el_r / (R * G) * 1e6
-        rollout = {"value": total_envs * R * G / el_r, "unit": "env-steps/s", "steps_per_launch": G, "launches": R,
+        us = el_r / (R * GR) * 1e6
+        rollout = {"value": total_envs * R * GR / el_r, "unit": "env-steps/s", "steps_per_launch": GR, "launches": R,
                    "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                   "note": "open-loop action sequences only (actions known in advance); all per-step outputs written"}
+                   "note": "open-loop action sequences only (actions known in advance); all per-step outputs written; "
+                           "measured before the timed region"}
+        del obs_r
+
+    run(W)
+    # warm the reporting path too (pinned buffer, first all-reduce), then start from clean accumulators
+    ep_dev = torch.zeros(3 + env.n_stats, dtype=torch.float64, device=dev)
+    ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
+
+    def reduce_episodes():
+        """the path's only exchange: one pcgrl_reduce_episodes launch (+ one small all-reduce over RCCL when world > 1)
+        and one device -> host copy"""
+        env.reduce_episodes(clear=True, out=ep_dev)
+        if world > 1:
+            if coll_dev.type == "cpu":  # gloo test hook
+                t = ep_dev.cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                ep_host.copy_(t)
+                return
+            dist.all_reduce(ep_dev, op=dist.ReduceOp.SUM)
+        ep_host.copy_(ep_dev, non_blocking=True)
+        torch.cuda.synchronize(dev)
+
+    reduce_episodes()
+    local_eps = torch.zeros(1, dtype=torch.float64, device=dev)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(K)
+    ev1.record(stream)
+    if world > 1:  # (test evidence: this rank's own episode count, read after the timed region)
+        local_eps = env.reduce_episodes(clear=False)[2:3].clone()
+    reduce_episodes()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
+    env.check_errors()
+    elapsed, per_rank_elapsed = max_over_ranks(elapsed)
+    _, per_rank_eps = max_over_ranks(float(local_eps.item()))
+    h = ep_host.tolist()
+    n_ep = max(h[2], 1.0)
+    ep = {"episodes": h[2], "mean_return": h[0] / n_ep, "mean_length": h[1] / n_ep,
+          "mean_final_stats": [x / n_ep for x in h[3:]]}
 
     if rank == 0:
         value = total_envs * K / elapsed
         bytes_per_launch = ALGO_BYTES[args.workload] * N
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        achieved = bytes_per_launch / (elapsed / K) / 1e9          # same clock as `value`
+        achieved_ev = bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # HIP events around the K launches
+        traffic, traffic_src = profiled_traffic(args.workload, N)
         out = {
             "metric": "env-steps/sec at N envs/GPU (binary 16x16), 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -239,13 +301,20 @@ def main():
                                    + "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)",
-                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step"},
+                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step",
+                       "seed_ranges": [[0x5EED + lo, 0x5EED + hi - 1] for lo, hi in
+                                       (shard_env_range(total_envs, r, world) for r in range(world))]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(args.workload, N),
-                         "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel", "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "clock": "wall clock of the timed region / steps (the clock of `value`)",
+                         "achieved_hip_events": achieved_ev, "frac_hip_events": achieved_ev / HBM_PEAK_GBS,
                          "avg_launch_us": kernel_ms * 1e3},
             "episodes": ep,
         }
+        if world > 1:
+            out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "episodes": per_rank_eps}
         if bfs_active:
             st = env.get_state().stats
             both = ((st[:, 0] == 1) & (st[:, 1] == 1) & (st[:, 2] == 1)).float().mean().item()
@@ -257,19 +326,43 @@ def main():
             out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this process never touches
+    the GPU), relay rank 0's JSON line, return the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def profiled_traffic(workload, n_envs):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r*_summary.json: WRITE_SIZE + 2 x FETCH_SIZE); None when not profiled."""
-    if workload != "binary-narrow" or n_envs != 4096:
-        return None
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*_summary.json: WRITE_SIZE + 2 x FETCH_SIZE, see DESIGN.md section 5) and where the number comes from;
+    (None, None) when that workload / batch was not profiled.  Counters cannot be collected inside a timing run."""
     import glob
-    best = None
+    best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
         try:
-            best = json.load(open(f))["hbm_traffic_per_launch"]["traffic_bytes"]
+            s = json.load(open(f))
+            rec = s.get("hbm_traffic_per_launch_by_workload", {}).get(f"{workload}@{n_envs}")
+            if rec is None and workload == "binary-narrow" and n_envs == 4096:
+                rec = s.get("hbm_traffic_per_launch")
+            if rec is not None:
+                best = (rec["traffic_bytes"], os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)")
         except Exception:
             pass
     return best
@@ -329,7 +422,16 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
             best_threads, best_rate = th, r
     value, steps, dt = rate(best_threads, target_s)
     one_core, _, _ = rate(1, 1.5)
-    return {"value": value, "unit": "env-steps/s", "cores": best_threads, "kind": "port", "one_core": one_core,
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": value, "unit": "env-steps/s", "cores": best_threads, "cpu_model": model, "usable_cores": avail,
+            "kind": "port", "one_core": one_core,
             "sample": f"{steps} steps x {n_envs} envs of the same workload ({dt:.1f} s, OpenMP over envs with "
                       f"{best_threads} threads of {avail} usable cores, obs encoded as uint8)"}
 

@@ -7,8 +7,14 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpcgrl_amd.so")
-SOURCES = ["pcgrl_engine.hip", "pcgrl_kernels2d.h", "pcgrl_kernels3d.h", "pcgrl_sokoban.h", "pcgrl_common.h"]
+# translation units (compiled in parallel, see csrc/pcgrl_dispatch.h) and the headers they depend on
+UNITS = ["pcgrl_engine.hip", "pcgrl_k_binary32.hip", "pcgrl_k_binary64.hip", "pcgrl_k_zelda32.hip", "pcgrl_k_zelda64.hip",
+         "pcgrl_k_sokoban32_8.hip", "pcgrl_k_sokoban32_16.hip", "pcgrl_k_sokoban32_32.hip",
+         "pcgrl_k_sokoban32_64.hip", "pcgrl_k_3d.hip"]
+HEADERS = ["pcgrl_kernels2d.h", "pcgrl_kernels3d.h", "pcgrl_sokoban.h", "pcgrl_common.h", "pcgrl_dispatch.h"]
+SOURCES = UNITS + HEADERS
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pcgrl_amd.h")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-falign-loops=32", "-fPIC"]
 
 PCGRL_MAX_STATS = 8
 ERRORS = {1: "EINVAL", 2: "EUNSUPPORTED", 3: "EHIP", 4: "EACTION"}
@@ -53,6 +59,13 @@ SYMBOLS = {
     "pcgrl_get_last_episode": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "pcgrl_stats_for_grids": (C.c_int, [C.POINTER(PcgrlConfig), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p]),
+    "pcgrl_stats_for_grids_h": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_stats_poll_error": (C.c_int, [C.POINTER(PcgrlConfig), C.c_int32]),
+    "pcgrl_stats_cache_clear": (None, []),
+    "pcgrl_reduce_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "pcgrl_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "pcgrl_get_rng_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_set_rng_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_poll_error": (C.c_int, [C.c_void_p]),
     "pcgrl_debug_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "pcgrl_last_error": (C.c_char_p, []),
@@ -60,19 +73,45 @@ SYMBOLS = {
 }
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Rebuilds when a source is newer."""
+def build(force=False, verbose=False, out=None, defines=(), jobs=None):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU), one object per translation unit, compiled in
+    parallel, then linked into the shared library.  Rebuilds when a source is newer than the library.
+    `out` / `defines`: development builds (tools/phase_timing.py, tools/wave_trace.py)."""
+    out = out or LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
-        return LIB_PATH
+    if (not force and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-falign-loops=32", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(CSRC, "pcgrl_engine.hip")]
+    tag = "".join(sorted(d.replace("=", "_") for d in defines))
+    objdir = os.path.join(CSRC, "_obj" + ("_" + tag if tag else ""))
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_time = max(hdr_time, os.path.getmtime(HEADER))
+    jobs_todo, objs = [], []
+    for u in UNITS:
+        obj = os.path.join(objdir, u.replace(".hip", ".o"))
+        objs.append(obj)
+        if (force or not os.path.exists(obj)
+                or os.path.getmtime(obj) < max(hdr_time, os.path.getmtime(os.path.join(CSRC, u)))):
+            jobs_todo.append([hipcc] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, u), "-o", obj])
+    if jobs_todo:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+        with ThreadPoolExecutor(max_workers=jobs or min(len(jobs_todo), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs_todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 _lib = None

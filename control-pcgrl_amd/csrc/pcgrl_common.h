@@ -22,7 +22,7 @@ struct alignas(16) EnvState {
   int32_t n_step;
   int32_t iteration;
   int32_t changes;
-  int32_t ep_len;
+  int32_t flags;  // ENV_STATS_DIRTY (the episode length is `iteration`: both count PcgrlEnv.step calls since the reset)
   int32_t last_ep_len;
   double last_loss;
   double ep_return;
@@ -32,6 +32,21 @@ struct alignas(16) EnvState {
   int32_t final_stats[PCGRL_MAX_STATS];
 };
 static_assert(sizeof(EnvState) == 128, "EnvState must be one 128-byte line");
+
+// EnvState::flags
+//   ENV_STATS_DIRTY  pcgrl_update changed the map and the statistics (and the binary fars / best masks) have not been
+//                    refreshed: the next CHANGING step recomputes them from scratch, exactly like the reference's
+//                    get_stats (pcgrl_env.py:314-323); cleared by that step, pcgrl_refresh_stats and every reset.
+constexpr int32_t ENV_STATS_DIRTY = 1;
+
+// Per-env totals over the episodes finished since the last pcgrl_reduce_episodes (written only at an env's reset, summed
+// in a fixed order by the reduction kernel: no atomics, deterministic).  rl/callbacks.py:91-117 reads the same values.
+struct alignas(8) EpAcc {
+  double sum_return;
+  int64_t sum_len;
+  int64_t n;
+  int64_t sum_stats[PCGRL_MAX_STATS];
+};
 
 struct alignas(16) RngState {
   uint64_t rep[4];   // state_hi, state_lo, inc_hi, inc_lo
@@ -54,6 +69,7 @@ struct Params {
   RngState *rng;
   const JumpEntry *jump;  // [H+1]: skip by row*W draws; entry H = H*W draws
   int32_t *err;           // device error word
+  EpAcc *ep_acc;          // [N] finished-episode totals (pcgrl_reduce_episodes)
   void *soko;             // SokoPool* (sokoban solver workspace), else null
   // per-call I/O
   const int32_t *actions;
@@ -67,6 +83,10 @@ struct Params {
   const uint8_t *mask;
   const uint8_t *init_grids;
   const int32_t *init_pos;
+  // pcgrl_set_state (reset kernel with init_grids): counters / loss / return to restore, any may be null
+  const int32_t *in_counters;   // [N][4] iteration, changes, n_step, (ignored)
+  const double *in_ep_return;   // [N]
+  int32_t set_state;
   // get_state outputs
   uint8_t *out_grids;
   int32_t *out_pos;

@@ -5,15 +5,21 @@
 // hidden synchronisation in reset/step/observe.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "pcgrl_common.h"
-#include "pcgrl_kernels2d.h"
-#include "pcgrl_sokoban.h"
-#include "pcgrl_kernels3d.h"
+#include "pcgrl_dispatch.h"
+#include "pcgrl_kernels2d.h"  // U128 / Pcg (host side of the RNG), the small engine-level kernels
+#include "pcgrl_sokoban.h"    // sokoban_alloc
+#include "pcgrl_kernels3d.h"  // M3_* limits
 
 using namespace pcgrl;
 
@@ -28,6 +34,9 @@ static int fail(int code, const std::string &msg) {
     if (_e != hipSuccess) return fail(PCGRL_EHIP, std::string(#x) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+namespace pcgrl {
+struct RedScratch;
+}
 struct pcgrl_engine {
   Params p;
   int device = 0;
@@ -37,6 +46,7 @@ struct pcgrl_engine {
   int64_t obs_bytes = 0;
   int obs_ndim = 0;
   int32_t obs_shape[4] = {0, 0, 0, 0};
+  RedScratch *red = nullptr;  // pcgrl_reduce_episodes block partials
   std::vector<void *> allocs;
 };
 
@@ -162,6 +172,9 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   if (H < 1 || W < 1 || H > 64 || W > 64) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 64");
   if (W > 32 && H <= 16) return fail(PCGRL_EUNSUPPORTED, "maps wider than 32 need more than 16 rows (64-bit row-mask kernels)");
   if (W > 32 && c.problem == PCGRL_PROB_SOKOBAN) return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32");
+  if (c.problem == PCGRL_PROB_SOKOBAN && (c.solver_power < 1 || c.solver_power > SK_MAX_POWER))
+    return fail(PCGRL_EUNSUPPORTED, "sokoban: solver_power must be in [1, " + std::to_string(SK_MAX_POWER) +
+                                        "] (the device solver's visited table and node ids are sized for that)");
   lpe = H <= 8 ? 8 : (H <= 16 ? 16 : (H <= 32 ? 32 : 64));
   if (c.representation == PCGRL_REP_WIDE) {
     if (c.obs_window[0] != H || c.obs_window[1] != W)
@@ -213,121 +226,141 @@ static std::vector<JumpEntry> make_jump_table(int H, int W, int last = -1) {
 }
 
 // ---------------------------------------------------------------------------------------------- dispatch
-enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS, K_ROLLOUT };
-
-// LDS above the 64 KiB default needs an explicit opt-in per kernel (64x64 zelda rows are 1152 B x 65 = 74 KiB)
-template <typename K>
-static hipError_t allow_lds(K kernel, size_t lds) {
-  if (lds <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
-template <int PROB, int LPE, typename M>
-static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_t s) {
-  const int epw = 64 / LPE;
-  dim3 grid((p.n_envs + epw - 1) / epw), block(64);
-  // compile-time specialised observation path: 16x16 map, 32x32 window (reference default obs_window = 2*map)
-  const bool fast = p.cfg.representation != PCGRL_REP_WIDE && p.cfg.dims[0] == 16 && p.cfg.dims[1] == 16 &&
-                    p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32 && !p.ext;
-  hipError_t e = hipSuccess;
-  switch (id) {
-    case K_STEP:
-      if constexpr (LPE == 16 && sizeof(M) == 4) {
-        if (fast) {
-          const bool ctrl = p.trg || p.reward64;
-#if !defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_WAVE_TRACE)  // (the development counters are indexed by workgroup)
-          if constexpr (PROB == PCGRL_PROB_BINARY) {  // two wave pairs per workgroup
-            const dim3 g2((grid.x + 1) / 2);
-            if (ctrl)
-              hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true, 2>), g2, dim3(256), 2 * lds, s, p);
-            else
-              hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false, 2>), g2, dim3(256), 2 * lds, s, p);
-            break;
-          }
-#endif
-          if (ctrl)
-            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128), lds, s, p);
-          else
-            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128), lds, s, p);
-          break;
-        }
-      }
-      if (p.trg || p.reward64) {
-        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, true>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, true>), grid, dim3(128), lds, s, p);
-      } else {
-        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, false>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128), lds, s, p);
-      }
-      break;
-    case K_ROLLOUT:
-      if constexpr (LPE == 16 && sizeof(M) == 4) {
-        if (fast) {
-          hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true>), grid, dim3(128), lds, s, p);
-          break;
-        }
-      }
-      if ((e = allow_lds(rollout_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, false>), grid, dim3(128), lds, s, p);
-      break;
-    case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
-    case K_OBSERVE:
-      if constexpr (LPE == 16 && sizeof(M) == 4) {
-        if (fast) {
-          hipLaunchKernelGGL((observe_kernel<PROB, LPE, M, true>), grid, block, lds, s, p);
-          break;
-        }
-      }
-      if ((e = allow_lds(observe_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL((observe_kernel<PROB, LPE, M, false>), grid, block, lds, s, p);
-      break;
-    case K_GET_STATE: hipLaunchKernelGGL((get_state_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
-    case K_LAST_EPISODE:
-      hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
-      break;
-    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
-  }
-  return hipGetLastError();
-}
-
-template <int PROB>
-static hipError_t launch_p(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s) {
-  if (p.cfg.dims[1] > 32) {  // 64-bit row masks (W <= 64); validate() guarantees lpe >= 32 here
-    if (lpe == 32) return launch_pl<PROB, 32, uint64_t>(id, p, lds, s);
-    return launch_pl<PROB, 64, uint64_t>(id, p, lds, s);
-  }
-  switch (lpe) {
-    case 8: return launch_pl<PROB, 8, uint32_t>(id, p, lds, s);
-    case 16: return launch_pl<PROB, 16, uint32_t>(id, p, lds, s);
-    case 32: return launch_pl<PROB, 32, uint32_t>(id, p, lds, s);
-    default: return launch_pl<PROB, 64, uint32_t>(id, p, lds, s);
-  }
-}
-
-static hipError_t launch3d(KernelId id, const Params &p, int cpl, hipStream_t s) {
-  dim3 grid(p.n_envs), block(64);
-  switch (id) {
-    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP>), grid, block, 0, s, p, cpl); break;
-    case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET>), grid, block, 0, s, p, cpl); break;
-    case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE>), grid, block, 0, s, p, cpl); break;
-    case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE>), grid, block, 0, s, p, cpl); break;
-    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((m3_kernel<M3_STATS_FOR_GRIDS>), grid, block, 0, s, p, cpl); break;
-    case K_LAST_EPISODE:
-      hipLaunchKernelGGL((last_episode_kernel<PCGRL_PROB_MC3DMAZE, 64>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
-      break;
-    case K_ROLLOUT: hipLaunchKernelGGL((m3_kernel<M3_ROLLOUT>), grid, block, 0, s, p, cpl); break;
-  }
-  return hipGetLastError();
-}
-
+// The kernels live in their own translation units (pcgrl_k_*.hip, see pcgrl_dispatch.h).
 static hipError_t launch(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s, int cpl = 0) {
-  if (p.cfg.problem == PCGRL_PROB_MC3DMAZE) return launch3d(id, p, cpl, s);
+  const bool wide64 = p.cfg.dims[1] > 32;  // 64-bit row masks (W <= 64); validate() guarantees lpe >= 32 there
   switch (p.cfg.problem) {
-    case PCGRL_PROB_BINARY: return launch_p<PCGRL_PROB_BINARY>(id, lpe, p, lds, s);
-    case PCGRL_PROB_ZELDA: return launch_p<PCGRL_PROB_ZELDA>(id, lpe, p, lds, s);
-    default: return launch_p<PCGRL_PROB_SOKOBAN>(id, lpe, p, lds, s);
+    case PCGRL_PROB_MC3DMAZE: return launch_3d(id, p, cpl, s);
+    case PCGRL_PROB_BINARY: return wide64 ? launch_binary64(id, lpe, p, lds, s) : launch_binary32(id, lpe, p, lds, s);
+    case PCGRL_PROB_ZELDA: return wide64 ? launch_zelda64(id, lpe, p, lds, s) : launch_zelda32(id, lpe, p, lds, s);
+    default: return launch_sokoban32(id, lpe, p, lds, s);  // validate() rejects sokoban maps wider than 32
   }
 }
+
+// Every entry point runs on the engine's device whatever the caller's current device is, and leaves the caller's
+// current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    else if (err == hipSuccess) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define ON_DEVICE(dev)                                                                            \
+  DeviceGuard _guard(dev);                                                                        \
+  if (_guard.err != hipSuccess) return fail(PCGRL_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(_guard.err))
+
+// ---------------------------------------------------------------------------------------------- engine-level kernels
+namespace pcgrl {
+
+__global__ __launch_bounds__(64) void queue_targets_kernel(Params p, const double *lo, const double *hi) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= p.n_envs || (p.mask != nullptr && p.mask[env] == 0)) return;
+  double *q = p.trg_pending + (size_t)env * PCGRL_MAX_STATS * 2;
+  for (int k = 0; k < p.cfg.n_stats; k++) {
+    q[2 * k] = lo[(size_t)env * p.cfg.n_stats + k];
+    q[2 * k + 1] = hi[(size_t)env * p.cfg.n_stats + k];
+  }
+  p.trg_flag[env] = 1;
+}
+
+// pcgrl_reduce_episodes: sum of the per-env episode totals in a FIXED order (block b owns envs [b*chunk, (b+1)*chunk),
+// the last block to finish adds the block partials in block order), so the result does not depend on timing.
+constexpr int RED_BLOCKS = 64, RED_THREADS = 256, RED_W = 3 + PCGRL_MAX_STATS;
+struct RedScratch {
+  double part[RED_BLOCKS][RED_W];
+  unsigned int ticket;
+};
+__global__ __launch_bounds__(RED_THREADS) void reduce_episodes_kernel(Params p, RedScratch *scr, double *out, int n_blocks, int clear) {
+  __shared__ double sh[RED_THREADS / 64][RED_W];
+  __shared__ bool last;
+  const int chunk = (p.n_envs + n_blocks - 1) / n_blocks;
+  const int lo = blockIdx.x * chunk, hi = min(p.n_envs, lo + chunk);
+  double ret = 0.0;
+  int64_t v[RED_W - 1];
+  for (int k = 0; k < RED_W - 1; k++) v[k] = 0;
+  for (int e = lo + (int)threadIdx.x; e < hi; e += RED_THREADS) {  // fixed env -> thread assignment
+    EpAcc *A = &p.ep_acc[e];
+    ret += A->sum_return;
+    v[0] += A->sum_len;
+    v[1] += A->n;
+    for (int k = 0; k < PCGRL_MAX_STATS; k++) v[2 + k] += A->sum_stats[k];
+    if (clear) {
+      A->sum_return = 0.0;
+      A->sum_len = 0;
+      A->n = 0;
+      for (int k = 0; k < PCGRL_MAX_STATS; k++) A->sum_stats[k] = 0;
+    }
+  }
+  // lanes -> wave (xor butterfly: a fixed tree), waves -> block (in wave order)
+  double w[RED_W];
+  w[0] = ret;
+  for (int k = 1; k < RED_W; k++) w[k] = (double)v[k - 1];  // integer totals < 2^53: exact in double from here on
+  for (int k = 0; k < RED_W; k++)
+    for (int o = 32; o >= 1; o >>= 1) w[k] += __shfl_xor(w[k], o, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < RED_W; k++) sh[wave][k] = w[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < RED_W; k++) {
+      double s = 0.0;
+      for (int i = 0; i < RED_THREADS / 64; i++) s += sh[i][k];
+      scr->part[blockIdx.x][k] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(&scr->ticket, 1u) == (unsigned)n_blocks - 1u;
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  if (threadIdx.x < RED_W) {
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; b++) s += __hip_atomic_load(&scr->part[b][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // out = sum_return, sum_len, n_episodes, sum_final_stats[n_stats]
+    if ((int)threadIdx.x < 3 + p.cfg.n_stats) out[threadIdx.x] = s;
+  }
+  if (threadIdx.x == 0) scr->ticket = 0;  // ready for the next call on the same stream
+}
+
+// pcgrl_get_rng_state / pcgrl_set_rng_state: [N][10] = rep state hi, lo, inc hi, lo; prob state hi, lo, inc hi, lo;
+// representation-wrapper flags | has32 << 32, val32
+__global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, const uint64_t *in) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= p.n_envs || (p.mask != nullptr && p.mask[env] == 0)) return;
+  RngState *r = &p.rng[env];
+  uint32_t *xs = p.xstate ? p.xstate + (size_t)env * 4 : nullptr;
+  if (out) {
+    uint64_t *o = out + (size_t)env * 10;
+    for (int k = 0; k < 4; k++) {
+      o[k] = r->rep[k];
+      o[4 + k] = r->prob[k];
+    }
+    o[8] = xs ? ((uint64_t)xs[0] | ((uint64_t)xs[1] << 32)) : 0ull;
+    o[9] = xs ? (uint64_t)xs[2] : 0ull;
+  }
+  if (in) {
+    const uint64_t *i = in + (size_t)env * 10;
+    for (int k = 0; k < 4; k++) {
+      r->rep[k] = i[k];
+      r->prob[k] = i[4 + k];
+    }
+    if (xs) {
+      xs[0] = (uint32_t)i[8];
+      xs[1] = (uint32_t)(i[8] >> 32);
+      xs[2] = (uint32_t)i[9];
+    }
+  }
+}
+
+}  // namespace pcgrl
 
 // ---------------------------------------------------------------------------------------------- C ABI
 extern "C" {
@@ -342,7 +375,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   int32_t shape[4] = {0, 0, 0, 0};
   int rc = validate(*cfg, lpe, obs_bytes, obs_chunks, shape, ndim);
   if (rc) return rc;
-  HIPCHK(hipSetDevice(device));
+  ON_DEVICE(device);
   pcgrl_engine *e = new pcgrl_engine();
   e->device = device;
   e->lpe = lpe;
@@ -386,6 +419,8 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
+  CREATE_CHK(dalloc((void **)&p.ep_acc, (size_t)n_envs * sizeof(EpAcc)));
+  CREATE_CHK(dalloc((void **)&e->red, sizeof(RedScratch)));
   // [0..3] error flags; from int 64 on: per-workgroup phase-timing accumulators (PCGRL_PHASE_TIMING builds)
   CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 64 + sizeof(uint64_t) * 8 * (size_t)(n_envs + 64)));
   std::vector<JumpEntry> jt = is3d ? make_jump_table(64, e->cpl, p.n_cells) : make_jump_table(H, W);
@@ -427,14 +462,14 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
 
 void pcgrl_destroy(pcgrl_handle h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   for (void *a : h->allocs) (void)hipFree(a);
   delete h;
 }
 
 int pcgrl_seed(pcgrl_handle h, const uint64_t *seeds) {
   if (!h || !seeds) return fail(PCGRL_EINVAL, "pcgrl_seed: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  ON_DEVICE(h->device);
   std::vector<RngState> r(h->p.n_envs);
   for (int i = 0; i < h->p.n_envs; i++) {
     pcg64_seed_state(seeds[i], r[i].rep);
@@ -449,6 +484,7 @@ int pcgrl_seed(pcgrl_handle h, const uint64_t *seeds) {
 
 int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_grids, const int32_t *d_init_pos, void *stream) {
   if (!h) return fail(PCGRL_EINVAL, "pcgrl_reset: null handle");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.mask = d_mask;
   p.init_grids = d_init_grids;
@@ -460,6 +496,7 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
 int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done,
                int32_t *d_stats, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step: bad arguments");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.actions = d_actions;
   p.auto_reset = auto_reset;
@@ -474,6 +511,7 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
 int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                   double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step_ex: bad arguments");
+  ON_DEVICE(h->device);
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_step_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   Params p = h->p;
   p.actions = d_actions;
@@ -491,6 +529,7 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream) {
   if (!h || !d_actions || n_steps < 1) return fail(PCGRL_EINVAL, "pcgrl_rollout: bad arguments");
+  ON_DEVICE(h->device);
   if (h->p.ext || h->p.cfg.n_ctrl > 0)
     return fail(PCGRL_EUNSUPPORTED, "pcgrl_rollout: plain mode only (no controls, no representation wrappers)");
   Params p = h->p;
@@ -509,6 +548,7 @@ int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int
 
 int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_update: bad arguments");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.actions = d_actions;
   p.obs = d_obs;
@@ -519,6 +559,7 @@ int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void 
 
 int pcgrl_refresh_stats(pcgrl_handle h, int32_t *d_stats, void *stream) {
   if (!h) return fail(PCGRL_EINVAL, "pcgrl_refresh_stats: null handle");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.refresh_only = 1;
   p.stats_out = d_stats;
@@ -528,6 +569,7 @@ int pcgrl_refresh_stats(pcgrl_handle h, int32_t *d_stats, void *stream) {
 
 int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_trg_lo, const double *d_trg_hi, void *stream) {
   if (!h || !d_trg_lo || !d_trg_hi) return fail(PCGRL_EINVAL, "pcgrl_queue_targets: bad arguments");
+  ON_DEVICE(h->device);
   if (h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_queue_targets: the engine was created without control metrics");
   Params p = h->p;
   p.mask = d_mask;
@@ -538,6 +580,7 @@ int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_t
 
 int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream) {
   if (!h || !d_ctrl_obs) return fail(PCGRL_EINVAL, "pcgrl_ctrl_observe: bad arguments");
+  ON_DEVICE(h->device);
   if (h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_ctrl_observe: the engine was created without control metrics");
   Params p = h->p;
   p.ctrl_obs = d_ctrl_obs;
@@ -553,6 +596,7 @@ int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream) {
 
 int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream) {
   if (!h || !d_obs) return fail(PCGRL_EINVAL, "pcgrl_observe: bad arguments");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.obs = d_obs;
   HIPCHK(launch(K_OBSERVE, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
@@ -561,6 +605,7 @@ int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream) {
 
 int pcgrl_get_static(pcgrl_handle h, uint8_t *d_static, void *stream) {
   if (!h || !d_static) return fail(PCGRL_EINVAL, "pcgrl_get_static: bad arguments");
+  ON_DEVICE(h->device);
   if (!h->p.cfg.static_tiles) return fail(PCGRL_EINVAL, "pcgrl_get_static: the engine was created without static tiles");
   Params p = h->p;
   p.out_static = d_static;
@@ -597,6 +642,7 @@ int pcgrl_obs_shape(pcgrl_handle h, int32_t shape_out[4], int32_t *ndim_out) {
 int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d_counters, int32_t *d_stats, double *d_last_loss,
                     double *d_ep_return, void *stream) {
   if (!h) return fail(PCGRL_EINVAL, "pcgrl_get_state: null handle");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.out_grids = d_grids;
   p.out_pos = d_pos;
@@ -611,6 +657,7 @@ int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d
 int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_len, int32_t *d_final_stats, int64_t *d_n_episodes,
                            void *stream) {
   if (!h) return fail(PCGRL_EINVAL, "pcgrl_get_last_episode: null handle");
+  ON_DEVICE(h->device);
   Params p = h->p;
   p.out_ep_return = d_ep_return;
   p.out_ep_len = d_ep_len;
@@ -620,45 +667,111 @@ int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_le
   return PCGRL_OK;
 }
 
-int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_grids, int32_t *d_stats, int32_t device, void *stream) {
-  if (!cfg || n < 1 || !d_grids || !d_stats) return fail(PCGRL_EINVAL, "pcgrl_stats_for_grids: bad arguments");
-  int lpe = 16, obs_chunks = 0, ndim = 0;
-  int64_t obs_bytes = 0;
-  int32_t shape[4];
-  pcgrl_config c = *cfg;
+// Scratch engines of the handle-less pcgrl_stats_for_grids: one per (problem, map shape, solver_power, device), created
+// on first use and kept until pcgrl_stats_cache_clear() / process exit.  The statistics kernel needs no per-env state,
+// only the engine's error word and (sokoban) solver workspace pool, so one engine serves any batch size.
+static std::mutex g_stats_mu;
+static std::map<std::tuple<int, int, int, int, int, int>, pcgrl_handle> g_stats_engines;
+
+static int stats_engine_for(const pcgrl_config &cfg, int device, pcgrl_handle *out) {
+  pcgrl_config c = cfg;
   c.representation = PCGRL_REP_NARROW;
   c.obs_window[0] = 2 * c.dims[0];
-  c.obs_window[1] = c.ndim == 3 ? 2 * c.dims[1] : 32;  // unused here; any legal value
+  c.obs_window[1] = c.ndim == 3 ? 2 * c.dims[1] : 32;  // unused by the statistics; any legal value
   c.obs_window[2] = c.ndim == 3 ? 2 * c.dims[2] : 1;
-  int rc = validate(c, lpe, obs_bytes, obs_chunks, shape, ndim);
-  if (rc) return rc;
-  if (c.problem == PCGRL_PROB_SOKOBAN || c.problem == PCGRL_PROB_MC3DMAZE) {
-    // the solver / the overflow flag need engine-owned scratch: go through a transient engine
+  c.n_ctrl = 0;
+  c.static_tiles = 0;
+  c.static_prob = 0.0;
+  c.n_static_walls = 0;
+  c.act_window[0] = c.act_window[1] = c.act_window[2] = 0;
+  const auto key = std::make_tuple((int)c.problem, (int)c.dims[0], (int)c.dims[1], (int)(c.ndim == 3 ? c.dims[2] : 1),
+                                   (int)c.solver_power, device);
+  std::lock_guard<std::mutex> lock(g_stats_mu);
+  auto it = g_stats_engines.find(key);
+  if (it == g_stats_engines.end()) {
     pcgrl_handle h = nullptr;
-    rc = pcgrl_create(&c, n, device, &h);
+    int rc = pcgrl_create(&c, 64, device, &h);  // 64 "envs": sizes the sokoban solver's workspace pool
     if (rc) return rc;
-    Params p = h->p;
-    p.init_grids = d_grids;
-    p.stats_out = d_stats;
-    hipError_t e2 = launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream, h->cpl);
-    hipError_t e3 = hipStreamSynchronize((hipStream_t)stream);
-    int perr = pcgrl_poll_error(h);
-    pcgrl_destroy(h);
-    if (perr) return perr;
-    if (e2 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e2));
-    if (e3 != hipSuccess) return fail(PCGRL_EHIP, hipGetErrorString(e3));
-    return PCGRL_OK;
+    it = g_stats_engines.emplace(key, h).first;
   }
-  HIPCHK(hipSetDevice(device));
-  Params p;
-  memset(&p, 0, sizeof(p));
-  p.cfg = c;
-  p.n_envs = n;
-  p.n_tiles = n_tiles_of(c.problem);
-  p.n_cells = c.dims[0] * c.dims[1];
+  *out = it->second;
+  return PCGRL_OK;
+}
+
+int pcgrl_stats_for_grids_h(pcgrl_handle h, int32_t n, const uint8_t *d_grids, int32_t *d_stats, void *stream) {
+  if (!h || n < 1 || !d_grids || !d_stats) return fail(PCGRL_EINVAL, "pcgrl_stats_for_grids_h: bad arguments");
+  ON_DEVICE(h->device);
+  Params p = h->p;
+  p.n_envs = n;  // the kernel touches no per-env engine state
   p.init_grids = d_grids;
   p.stats_out = d_stats;
-  HIPCHK(launch(K_STATS_FOR_GRIDS, lpe, p, 0, (hipStream_t)stream));
+  HIPCHK(launch(K_STATS_FOR_GRIDS, h->lpe, p, 0, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_grids, int32_t *d_stats, int32_t device, void *stream) {
+  if (!cfg || n < 1 || !d_grids || !d_stats) return fail(PCGRL_EINVAL, "pcgrl_stats_for_grids: bad arguments");
+  pcgrl_handle h = nullptr;
+  int rc = stats_engine_for(*cfg, device, &h);
+  if (rc) return rc;
+  return pcgrl_stats_for_grids_h(h, n, d_grids, d_stats, stream);
+}
+
+int pcgrl_stats_poll_error(const pcgrl_config *cfg, int32_t device) {
+  if (!cfg) return fail(PCGRL_EINVAL, "pcgrl_stats_poll_error: bad arguments");
+  pcgrl_handle h = nullptr;
+  int rc = stats_engine_for(*cfg, device, &h);
+  if (rc) return rc;
+  return pcgrl_poll_error(h);
+}
+
+void pcgrl_stats_cache_clear(void) {
+  std::lock_guard<std::mutex> lock(g_stats_mu);
+  for (auto &kv : g_stats_engines) pcgrl_destroy(kv.second);
+  g_stats_engines.clear();
+}
+
+int pcgrl_reduce_episodes(pcgrl_handle h, double *d_out, int32_t clear, void *stream) {
+  if (!h || !d_out) return fail(PCGRL_EINVAL, "pcgrl_reduce_episodes: bad arguments");
+  ON_DEVICE(h->device);
+  const int n_blocks = std::min(RED_BLOCKS, (h->p.n_envs + RED_THREADS - 1) / RED_THREADS);
+  hipLaunchKernelGGL(reduce_episodes_kernel, dim3(n_blocks), dim3(RED_THREADS), 0, (hipStream_t)stream, h->p, h->red, d_out, n_blocks,
+                     clear ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_set_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_grids, const int32_t *d_pos, const int32_t *d_counters,
+                    const double *d_ep_return, void *stream) {
+  if (!h || !d_grids) return fail(PCGRL_EINVAL, "pcgrl_set_state: bad arguments");
+  if (h->p.ext) return fail(PCGRL_EUNSUPPORTED, "pcgrl_set_state: not with static tiles / action patches (their masks are drawn at reset)");
+  ON_DEVICE(h->device);
+  Params p = h->p;
+  p.mask = d_mask;
+  p.init_grids = d_grids;
+  p.init_pos = d_pos;
+  p.in_counters = d_counters;
+  p.in_ep_return = d_ep_return;
+  p.set_state = 1;
+  HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_get_rng_state(pcgrl_handle h, uint64_t *d_out, void *stream) {
+  if (!h || !d_out) return fail(PCGRL_EINVAL, "pcgrl_get_rng_state: bad arguments");
+  ON_DEVICE(h->device);
+  hipLaunchKernelGGL(rng_state_kernel, dim3((h->p.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->p, d_out, (const uint64_t *)nullptr);
+  HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_set_rng_state(pcgrl_handle h, const uint8_t *d_mask, const uint64_t *d_in, void *stream) {
+  if (!h || !d_in) return fail(PCGRL_EINVAL, "pcgrl_set_rng_state: bad arguments");
+  ON_DEVICE(h->device);
+  Params p = h->p;
+  p.mask = d_mask;
+  hipLaunchKernelGGL(rng_state_kernel, dim3((p.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, (uint64_t *)nullptr, d_in);
+  HIPCHK(hipGetLastError());
   return PCGRL_OK;
 }
 
@@ -673,7 +786,7 @@ int pcgrl_debug_counters(pcgrl_handle h, uint64_t *out, int32_t n) {
 
 int pcgrl_poll_error(pcgrl_handle h) {
   if (!h) return fail(PCGRL_EINVAL, "pcgrl_poll_error: null handle");
-  HIPCHK(hipSetDevice(h->device));
+  ON_DEVICE(h->device);
   HIPCHK(hipDeviceSynchronize());
   int32_t flags[4] = {0, 0, 0, 0};
   HIPCHK(hipMemcpy(flags, h->p.err, sizeof(flags), hipMemcpyDeviceToHost));

@@ -1,0 +1,20 @@
+// pcgrl_k_3d.hip -- translation unit: the minecraft_3D_maze kernels (see pcgrl_dispatch.h)
+#define PCGRL_KERNEL_TU
+#include "pcgrl_dispatch.h"
+#include "pcgrl_kernels3d.h"
+
+hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s) {
+  dim3 grid(p.n_envs), block(64);
+  switch (id) {
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP>), grid, block, 0, s, p, cpl); break;
+    case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET>), grid, block, 0, s, p, cpl); break;
+    case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE>), grid, block, 0, s, p, cpl); break;
+    case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE>), grid, block, 0, s, p, cpl); break;
+    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((m3_kernel<M3_STATS_FOR_GRIDS>), grid, block, 0, s, p, cpl); break;
+    case K_LAST_EPISODE:
+      hipLaunchKernelGGL((last_episode_kernel<PCGRL_PROB_MC3DMAZE, 64>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
+      break;
+    case K_ROLLOUT: hipLaunchKernelGGL((m3_kernel<M3_ROLLOUT>), grid, block, 0, s, p, cpl); break;
+  }
+  return hipGetLastError();
+}

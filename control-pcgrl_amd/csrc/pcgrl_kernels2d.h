@@ -1381,6 +1381,24 @@ __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, 
   }
 }
 
+// Episode end (auto-reset): what RLlib's callbacks read at that point (rl/callbacks.py:91-117) is latched in the env
+// record (pcgrl_get_last_episode) and added to the env's running totals (pcgrl_reduce_episodes).  One lane per env.
+template <int NS>
+__device__ inline void latch_episode(const Params &p, int e, EnvState *S, double ep_return, int ep_len, const int32_t *st) {
+  S->last_ep_return = ep_return;
+  S->last_ep_len = ep_len;
+  S->n_episodes += 1;
+  EpAcc *A = &p.ep_acc[e];
+  A->sum_return += ep_return;
+  A->sum_len += ep_len;
+  A->n += 1;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    S->final_stats[k] = st[k];
+    A->sum_stats[k] += st[k];
+  }
+}
+
 // One workgroup = two specialised wavefronts over the same 64/LPE envs:
 //   wave 0 "simulate": action -> stats -> reward/done -> auto-reset -> state write-back
 //   wave 1 "observe" : replays the (cheap) action / reset on its own registers and encodes the observation
@@ -1432,6 +1450,14 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   const int action = active ? p.actions[e] : 0;
+  // An auto-reset of this step replays the env's RNG streams in BOTH waves; the simulate wave stores the advanced
+  // streams at the end of the launch, so the observe wave takes its copy before the barrier (like every other piece
+  // of old state).
+  Pcg obs_rp, obs_rr;
+  if (observer && p.auto_reset != 0 && (iteration + 1 > p.cfg.max_iterations || p.cfg.max_changes >= 0)) {
+    obs_rp.load(p.rng[e].prob);
+    obs_rr.load(p.rng[e].rep);
+  }
   // both waves have read the old state before wave 0 may overwrite it
   if (p.obs != nullptr) __syncthreads();
   PHASE_MARK(0);  // loads + barrier
@@ -1458,7 +1484,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
 
   if (observer) {
     if (__ballot(do_reset) != 0)
-      reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/false, ext ? &X : nullptr);
+      reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/false, ext ? &X : nullptr, &obs_rp, &obs_rr);
     if (ext && p.cfg.static_tiles)
       encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds);
     else
@@ -1479,15 +1505,16 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     return;
   }
 
-  int ep_len = S->ep_len;
+  int flags = S->flags;
   double last_loss = S->last_loss, ep_return = S->ep_return;
   int32_t st[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
   if (bad && g.row == 0 && active) atomicOr(p.err, 1);
   PHASE_MARK(1);  // action + second state loads
-  if (upd_only) {  // grid / position only; stats (and the binary fars/best masks) are rebuilt by pcgrl_refresh_stats
+  if (upd_only) {  // grid / position only; the stats (and the binary fars / best masks) go stale: ENV_STATS_DIRTY
     if (change) store_planes<NB, M, FAST>(p, e, g.row, rowok, b);
+    if (change && map_changed && active && g.row == 0) S->flags = flags | ENV_STATS_DIRTY;
     if constexpr (PRE) {
       if (p.obs == nullptr && rowok && pre3 != M(0)) *pre_word = M(0);  // no observe wave: the plane goes stale
     }
@@ -1500,7 +1527,17 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     return;
   }
   // the statistics can only move if the map did (with static tiles a build may have been undone: change without edit)
-  refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && map_changed, multi, tile0_old, pre, b, colmask, st PHASE_PASS,
+  const bool stale = (flags & ENV_STATS_DIRTY) != 0 && change && map_changed;  // after pcgrl_update: from scratch
+  if (__ballot(stale) != 0) {
+    int32_t ns[NS];
+    compute_stats<PROB, LPE, M>(g, p, e, stale && active, b, colmask, ns);
+    if (stale) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) st[k] = ns[k];
+      flags &= ~ENV_STATS_DIRTY;
+    }
+  }
+  refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && map_changed && !stale, multi, tile0_old, pre, b, colmask, st PHASE_PASS,
                                     PRE && g.gany((pre3 & (M)PRE_VALID) != 0), pre3 & colmask);
   PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
@@ -1516,7 +1553,6 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   double rew = loss - last_loss;
   last_loss = loss;
   ep_return += rew;
-  ep_len++;
   if (active && g.row == 0) {
     if (p.reward) p.reward[e] = (float)rew;
     if constexpr (CTRL) {
@@ -1529,13 +1565,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     }
   }
   if (__ballot(do_reset) != 0) {
-    if (do_reset && g.row == 0) {
-      S->last_ep_return = ep_return;
-      S->last_ep_len = ep_len;
-      S->n_episodes += 1;
-#pragma unroll
-      for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
-    }
+    if (do_reset && g.row == 0) latch_episode<NS>(p, e, S, ep_return, iteration, st);
     reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/true, ext ? &X : nullptr);
     int32_t ns[NS];
     compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
@@ -1545,7 +1575,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
       iteration = 0;
       changes = 0;
       n_step = 0;
-      ep_len = 0;
+      flags = 0;
       ep_return = 0.0;
       if constexpr (!CTRL) {
         last_loss = get_loss<NS>(p.cfg, st);
@@ -1556,7 +1586,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     }
   }
   // write back state
-  if (change || do_reset) store_planes<NW, M, FAST>(p, e, g.row, rowok, b);
+  if (change || do_reset) store_planes<NW, M, FAST>(p, e, g.row, rowok, b);  // (stale implies change)
   if constexpr (PRE) {
     if (p.obs == nullptr && rowok && pre3 != M(0)) *pre_word = M(0);  // no observe wave: the plane goes stale
   }
@@ -1571,7 +1601,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     S->n_step = n_step;
     S->iteration = iteration;
     S->changes = changes;
-    S->ep_len = ep_len;
+    S->flags = flags;
     S->last_loss = last_loss;
     S->ep_return = ep_return;
 #pragma unroll
@@ -1614,7 +1644,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
-  int ep_len = S->ep_len;
+  int flags = S->flags;
   double last_loss = S->last_loss, ep_return = S->ep_return;
   int32_t st[NS];
 #pragma unroll
@@ -1648,12 +1678,21 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds,
                                        p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes));
     } else {
-      refresh_stats<PROB, LPE, M, FAST>(g, p, e, change, false, tile0_old, pre, b, colmask, st PHASE_PASS);
+      const bool stale = (flags & ENV_STATS_DIRTY) != 0 && change;  // first changing step after pcgrl_update
+      if (__ballot(stale) != 0) {
+        int32_t ns[NS];
+        compute_stats<PROB, LPE, M>(g, p, e, stale && active, b, colmask, ns);
+        if (stale) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) st[i] = ns[i];
+          flags &= ~ENV_STATS_DIRTY;
+        }
+      }
+      refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && !stale, false, tile0_old, pre, b, colmask, st PHASE_PASS);
       const double loss = get_loss<NS>(p.cfg, st);
       const double rew = loss - last_loss;
       last_loss = loss;
       ep_return += rew;
-      ep_len++;
       if (active && g.row == 0) {
         const size_t o = (size_t)k * N + (size_t)e;
         if (p.reward) p.reward[o] = (float)rew;
@@ -1664,20 +1703,14 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         }
       }
       if (__ballot(do_reset) != 0) {
-        if (do_reset && g.row == 0) {
-          S->last_ep_return = ep_return;
-          S->last_ep_len = ep_len;
-          S->n_episodes += 1;
-#pragma unroll
-          for (int i = 0; i < NS; i++) S->final_stats[i] = st[i];
-        }
+        if (do_reset && g.row == 0) latch_episode<NS>(p, e, S, ep_return, iteration, st);
         reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, true, nullptr, &rp, &rr);
         int32_t ns[NS];
         compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
         if (do_reset) {
 #pragma unroll
           for (int i = 0; i < NS; i++) st[i] = ns[i];
-          ep_len = 0;
+          flags = 0;
           ep_return = 0.0;
           last_loss = get_loss<NS>(p.cfg, st);
         }
@@ -1704,7 +1737,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
     S->n_step = n_step;
     S->iteration = iteration;
     S->changes = changes;
-    S->ep_len = ep_len;
+    S->flags = flags;
     S->last_loss = last_loss;
     S->ep_return = ep_return;
 #pragma unroll
@@ -1774,6 +1807,7 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
       EnvTargets<NS> trg;
       trg.load(p, e, false);
       S->last_loss = trg.loss(p.cfg, st);
+      S->flags &= ~ENV_STATS_DIRTY;
 #pragma unroll
       for (int k = 0; k < NS; k++) {
         S->stats[k] = st[k];
@@ -1789,8 +1823,16 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
     S->n_step = 0;
     S->iteration = 0;
     S->changes = 0;
-    S->ep_len = 0;
+    S->flags = 0;
     S->ep_return = 0.0;
+    if (p.set_state) {  // pcgrl_set_state: the map was injected above, the counters / return come from the caller
+      if (p.in_counters) {
+        S->iteration = p.in_counters[(size_t)e * 4 + 0];
+        S->changes = p.in_counters[(size_t)e * 4 + 1];
+        S->n_step = p.in_counters[(size_t)e * 4 + 2];
+      }
+      if (p.in_ep_return) S->ep_return = p.in_ep_return[e];
+    }
     EnvTargets<NS> trg;
     trg.load(p, e, true);
     S->last_loss = trg.loss(p.cfg, st);
@@ -1813,17 +1855,6 @@ __global__ __launch_bounds__(64) void ctrl_observe_kernel(Params p) {
 #pragma unroll
   for (int k = 0; k < NS; k++) st[k] = p.st[env].stats[k];
   trg.write_ctrl_obs(p, env, st);
-}
-
-__global__ __launch_bounds__(64) void queue_targets_kernel(Params p, const double *lo, const double *hi) {
-  const int env = blockIdx.x * 64 + threadIdx.x;
-  if (env >= p.n_envs || (p.mask != nullptr && p.mask[env] == 0)) return;
-  double *q = p.trg_pending + (size_t)env * PCGRL_MAX_STATS * 2;
-  for (int k = 0; k < p.cfg.n_stats; k++) {
-    q[2 * k] = lo[(size_t)env * p.cfg.n_stats + k];
-    q[2 * k + 1] = hi[(size_t)env * p.cfg.n_stats + k];
-  }
-  p.trg_flag[env] = 1;
 }
 
 template <int PROB, int LPE, typename M, bool FAST>
@@ -1889,7 +1920,7 @@ __global__ __launch_bounds__(64) void get_state_kernel(Params p) {
       p.out_counters[(size_t)env * 4 + 0] = S->iteration;
       p.out_counters[(size_t)env * 4 + 1] = S->changes;
       p.out_counters[(size_t)env * 4 + 2] = S->n_step;
-      p.out_counters[(size_t)env * 4 + 3] = S->ep_len;
+      p.out_counters[(size_t)env * 4 + 3] = S->iteration;  // episode length so far
     }
     if (p.stats_out)
       for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = S->stats[k];

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
         p.out_counters[(size_t)env * 4 + 0] = S->iteration;
         p.out_counters[(size_t)env * 4 + 1] = S->changes;
         p.out_counters[(size_t)env * 4 + 2] = S->n_step;
-        p.out_counters[(size_t)env * 4 + 3] = S->ep_len;
+        p.out_counters[(size_t)env * 4 + 3] = S->iteration;  // episode length so far
       }
       if (p.stats_out)
         for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = S->stats[k];
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     return;
   }
 
-  int n_step = S->n_step, iteration = S->iteration, changes = S->changes, ep_len = S->ep_len;
+  int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   double last_loss = S->last_loss, ep_return = S->ep_return;
   int32_t st[NS];
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
@@ -511,8 +511,16 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     }
     uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
     m3_stats(L, c, air, st, ovf PHASE_PASS);
-    n_step = iteration = changes = ep_len = 0;
+    n_step = iteration = changes = 0;
     ep_return = 0.0;
+    if (p.set_state) {  // pcgrl_set_state: injected map, the caller's counters / return
+      if (p.in_counters) {
+        iteration = p.in_counters[(size_t)env * 4 + 0];
+        changes = p.in_counters[(size_t)env * 4 + 1];
+        n_step = p.in_counters[(size_t)env * 4 + 2];
+      }
+      if (p.in_ep_return) ep_return = p.in_ep_return[env];
+    }
     trg.load(p, env, true);
     last_loss = trg.loss(p.cfg, st);
   } else {
@@ -570,7 +578,6 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     const double rew = loss - last_loss;
     last_loss = loss;
     ep_return += rew;
-    ep_len++;
     if (c.lane == 0) {
       if (p.reward) p.reward[o] = (float)rew;
       if (p.reward64) p.reward64[o] = rew;
@@ -579,17 +586,12 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
         for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
     }
     if (do_reset) {
-      if (c.lane == 0) {
-        S->last_ep_return = ep_return;
-        S->last_ep_len = ep_len;
-        S->n_episodes += 1;
-        for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
-      }
+      if (c.lane == 0) latch_episode<NS>(p, env, S, ep_return, iteration, st);
       m3_reset_rng(L, c, p, env, cpl);
       pos[0] = pos[1] = pos[2] = 0;
       uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
       m3_stats(L, c, air, st, ovf PHASE_PASS);
-      n_step = iteration = changes = ep_len = 0;
+      n_step = iteration = changes = 0;
       ep_return = 0.0;
       trg.load(p, env, true);
       last_loss = trg.loss(p.cfg, st);
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     S->n_step = n_step;
     S->iteration = iteration;
     S->changes = changes;
-    S->ep_len = ep_len;
+    S->flags = 0;
     S->last_loss = last_loss;
     S->ep_return = ep_return;
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];

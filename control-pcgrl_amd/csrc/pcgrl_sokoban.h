@@ -22,6 +22,7 @@ namespace pcgrl {
 constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
 constexpr int SK_MAXDIM = 34;    // bordered level side (W+2, H+2 <= 34)
 constexpr int SK_VCAP = 1 << 15; // visited table slots (>= 2 x iterations per stage)
+constexpr int SK_MAX_POWER = SK_VCAP / 2;  // cfg.solver_power accepted by pcgrl_create
 
 struct SokoLevel {
   int32_t w, h, ncr, ntg;

@@ -26,7 +26,6 @@ class EpisodeStatsReducer:
     def __init__(self, n_stats, device):
         self.n_stats = int(n_stats)
         self.acc = torch.zeros(3 + self.n_stats, dtype=torch.float64, device=device)
-        self._seen = None
 
     def update(self, done, ep_return, ep_len, final_stats):
         """done: bool [N]; the others are the per-env values of the episodes that just finished."""
@@ -37,13 +36,10 @@ class EpisodeStatsReducer:
         self.acc[3:] += (final_stats.to(torch.float64) * d[:, None]).sum(0)
 
     def update_from_env(self, env):
-        """Pull newly finished episodes from a VecPcgrlEnv (auto-reset mode)."""
-        le = env.last_episode()
-        if self._seen is None:
-            self._seen = torch.zeros_like(le.n_episodes)
-        new = le.n_episodes > self._seen
-        self._seen = le.n_episodes.clone()
-        self.update(new, le.ep_return, le.ep_len, le.final_stats)
+        """Add the episodes a VecPcgrlEnv finished (auto-reset mode) since the last call: one pcgrl_reduce_episodes
+        launch (fixed-order sum on the device, accumulators cleared), no host synchronisation."""
+        self._buf = env.reduce_episodes(clear=True, out=getattr(self, "_buf", None))
+        self.acc += self._buf
 
     def reduce(self, group=None, device=None):
         """Returns dict of global means; collective over `group` when torch.distributed is initialised.
@@ -53,9 +49,10 @@ class EpisodeStatsReducer:
             v = v.to(device)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
-        n = max(float(v[2].item()), 1.0)
-        return {"episodes": float(v[2].item()), "mean_return": float(v[0].item()) / n,
-                "mean_length": float(v[1].item()) / n, "mean_final_stats": (v[3:] / n).tolist()}
+        h = v.tolist()  # the one device -> host copy (and synchronisation) of a reporting interval
+        n = max(h[2], 1.0)
+        return {"episodes": h[2], "mean_return": h[0] / n, "mean_length": h[1] / n,
+                "mean_final_stats": [x / n for x in h[3:]]}
 
     def reset(self):
         self.acc.zero_()

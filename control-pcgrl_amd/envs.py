@@ -61,6 +61,8 @@ class PcgrlGymEnv:
         # controllable mode prepends 2 * len(controls) constant planes (control_wrappers.py:86-104, :189-214)
         self._n_ctrl_planes = 2 * len(v.controls)
         shape = v.obs_shape[:-1] + (v.obs_shape[-1] + self._n_ctrl_planes,)
+        # ToImage takes high = max over the stacked spaces (wrappers.py:113-123); the control planes are declared
+        # Box(0, 1) by the reference (control_wrappers.py:96-104) although target / range can leave that interval
         self.observation_space = Box(low=0, high=1, shape=shape, dtype=np.float32)
         if v.act_window:  # envs/reps/wrappers.py:434-439: one tile id per cell of the action patch
             self.action_space = MultiDiscrete([v.spec.n_tiles] * v.action_entries)

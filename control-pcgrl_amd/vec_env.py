@@ -343,14 +343,56 @@ class VecPcgrlEnv:
         return out
 
     def stats_for_grids(self, grids):
-        """Problem.get_stats on caller maps (the evolution driver's entry, evo/evolve.py:1083-1120)."""
+        """Problem.get_stats on caller maps (the evolution driver's entry, evo/evolve.py:1083-1120).  Any number of
+        maps; asynchronous (uses this engine's scratch; device-side errors surface in check_errors())."""
         g = torch.as_tensor(grids, device=self.device).to(torch.uint8).contiguous()
         n = g.numel() // self.n_cells
         out = torch.empty((n, self.n_stats), dtype=torch.int32, device=self.device)
-        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _lib.check(self._L.pcgrl_stats_for_grids(C.byref(self.cfg), n, g.data_ptr(), out.data_ptr(), dev_index,
-                                                 self._stream()), "pcgrl_stats_for_grids")
+        _lib.check(self._L.pcgrl_stats_for_grids_h(self._h, n, g.data_ptr(), out.data_ptr(), self._stream()),
+                   "pcgrl_stats_for_grids_h")
         return out
+
+    # -- episodic-return reduction (rl/callbacks.py:91-117 on_episode_end, summed over the batch) -------------------
+    def reduce_episodes(self, clear=True, out=None):
+        """float64 [3 + n_stats] on the env's GPU: sum of returns, sum of lengths, number of episodes, sum of final
+        stats over the episodes that ended by auto-reset since the last clearing call.  One launch, no sync."""
+        if out is None:
+            out = torch.empty(3 + self.n_stats, dtype=torch.float64, device=self.device)
+        _lib.check(self._L.pcgrl_reduce_episodes(self._h, out.data_ptr(), 1 if clear else 0, self._stream()),
+                   "pcgrl_reduce_episodes")
+        return out
+
+    # -- checkpoint / restore (envs/pcgrl_env.py:102-112 get_task / set_task pickle the env) ------------------------
+    def get_rng_state(self):
+        """uint64-as-int64 [N, 10]: both numpy-compatible PCG64 streams of every env (see include/pcgrl_amd.h)."""
+        out = torch.empty((self.num_envs, 10), dtype=torch.int64, device=self.device)
+        _lib.check(self._L.pcgrl_get_rng_state(self._h, out.data_ptr(), self._stream()), "pcgrl_get_rng_state")
+        return out
+
+    def set_rng_state(self, rng, mask=None):
+        r = torch.as_tensor(rng, device=self.device).to(torch.int64).contiguous()
+        assert r.shape == (self.num_envs, 10)
+        m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        _lib.check(self._L.pcgrl_set_rng_state(self._h, m.data_ptr() if m is not None else None, r.data_ptr(),
+                                               self._stream()), "pcgrl_set_rng_state")
+
+    def state_dict(self):
+        """Everything needed to continue bit-exactly later: maps, positions, counters, running returns, RNG streams."""
+        st = self.get_state()
+        return {"grids": st.grids.clone(), "pos": st.pos.clone(), "counters": st.counters.clone(),
+                "ep_return": st.ep_return.clone(), "rng": self.get_rng_state()}
+
+    def load_state_dict(self, sd, mask=None):
+        def dev(t, dtype):
+            return torch.as_tensor(t, device=self.device).to(dtype).contiguous()
+
+        g, p, c = dev(sd["grids"], torch.uint8), dev(sd["pos"], torch.int32), dev(sd["counters"], torch.int32)
+        r = dev(sd["ep_return"], torch.float64)
+        m = None if mask is None else dev(mask, torch.uint8)
+        assert g.numel() == self.num_envs * self.n_cells and p.shape == (self.num_envs, 3) and c.shape == (self.num_envs, 4)
+        _lib.check(self._L.pcgrl_set_state(self._h, m.data_ptr() if m is not None else None, g.data_ptr(), p.data_ptr(),
+                                           c.data_ptr(), r.data_ptr(), self._stream()), "pcgrl_set_state")
+        self.set_rng_state(sd["rng"], mask=mask)
 
 
 def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):

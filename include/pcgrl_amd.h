@@ -21,8 +21,10 @@
  *   pcgrl_rollout                  the random-action rollout loop of profile_env.py:124-142 / train_reward_model.py:43-45
  *                                  (K x PcgrlEnv.step with actions that do not depend on the observations)
  *   pcgrl_get_static / _set_static envs/reps/wrappers.py:234-376 StaticTileRepresentation.static_tiles, set_static_prob ...
- *   pcgrl_stats_for_grids          envs/probs/problem.py:128 Problem.get_stats(map) as called directly by
+ *   pcgrl_stats_for_grids[_h]      envs/probs/problem.py:128 Problem.get_stats(map) as called directly by
  *                                  evo/evolve.py:1083-1120
+ *   pcgrl_reduce_episodes          rl/callbacks.py:91-117 on_episode_end metrics, summed over the batch
+ *   pcgrl_set_state / _rng_state   envs/pcgrl_env.py:102-112 get_task / set_task (env pickling = checkpoint / restore)
  *
  * Conventions
  *   - every `d_` pointer is a DEVICE pointer on the engine's GPU; the caller owns all I/O buffers,
@@ -137,7 +139,9 @@ int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream);
 /* Evolution-driver pattern (evo/evolve.py:1083-1120): the representation is updated directly, PcgrlEnv.step() is not
  * involved and the statistics are only computed at the end.
  *   pcgrl_update         rep.update(action) for every env + the observation (d_obs may be NULL); iteration / changes
- *                        counters, stats, reward and done are not touched
+ *                        counters, stats, reward and done are not touched.  An env whose map changed is marked "stats
+ *                        stale": pcgrl_get_state keeps returning the old statistics (the reference's _rep_stats), and the
+ *                        next pcgrl_step that changes its map recomputes them from scratch (pcgrl_env.py:314-323)
  *   pcgrl_refresh_stats  Problem.get_stats() of the current maps -> engine state (and d_stats int32 [N][n_stats] if
  *                        non-NULL); also re-bases the loss so that later pcgrl_step rewards are consistent */
 int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void *stream);
@@ -147,7 +151,7 @@ int pcgrl_observe(pcgrl_handle h, uint8_t *d_obs, void *stream);
 int64_t pcgrl_obs_bytes(pcgrl_handle h); /* bytes per env: prod(obs_shape) */
 int pcgrl_obs_shape(pcgrl_handle h, int32_t shape_out[4], int32_t *ndim_out);
 
-/* d_counters int32 [N][4] = iteration, changes, n_step, episode_len.  Any pointer may be NULL. */
+/* d_counters int32 [N][4] = iteration, changes, n_step, episode length so far (== iteration).  Any pointer may be NULL. */
 int pcgrl_get_state(pcgrl_handle h, uint8_t *d_grids, int32_t *d_pos, int32_t *d_counters, int32_t *d_stats,
                     double *d_last_loss, double *d_ep_return, void *stream);
 int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_len, int32_t *d_final_stats,
@@ -160,9 +164,41 @@ int pcgrl_get_static(pcgrl_handle h, uint8_t *d_static, void *stream);
  * env's next reset.  n_static_walls < 0 or static_prob < 0 leave that value unchanged. */
 int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls, int32_t eval_mode);
 
-/* Stateless Problem.get_stats on n maps: d_grids uint8 [n][cells] -> d_stats int32 [n][n_stats]. */
+/* Problem.get_stats on n caller-provided maps (evo/evolve.py:1083-1120 calls it once per individual):
+ * d_grids uint8 [n][cells] -> d_stats int32 [n][n_stats].  Asynchronous on `stream`.
+ *   pcgrl_stats_for_grids_h  uses the scratch (error word, sokoban solver workspace) of an existing engine of the same
+ *                            problem and map shape; n is independent of the engine's batch size; device-side errors
+ *                            (a level beyond the solver's limits) are reported by pcgrl_poll_error(h)
+ *   pcgrl_stats_for_grids    handle-less: keeps one hidden scratch engine per (problem, map shape, solver_power, device),
+ *                            created on first use; its device-side errors are read with pcgrl_stats_poll_error (which
+ *                            synchronises); pcgrl_stats_cache_clear frees the hidden engines */
+int pcgrl_stats_for_grids_h(pcgrl_handle h, int32_t n, const uint8_t *d_grids, int32_t *d_stats, void *stream);
 int pcgrl_stats_for_grids(const pcgrl_config *cfg, int32_t n, const uint8_t *d_grids, int32_t *d_stats,
                           int32_t device, void *stream);
+int pcgrl_stats_poll_error(const pcgrl_config *cfg, int32_t device);
+void pcgrl_stats_cache_clear(void);
+
+/* Episodic-return reduction (the only quantity the data-parallel path ever exchanges; rl/callbacks.py:91-117
+ * on_episode_end reads the same values per env).  Sums, over every env of the engine, the episodes that ended by
+ * auto-reset since the last call with clear != 0:
+ *   d_out double [3 + n_stats] = sum of returns, sum of lengths, number of episodes, sum of final stats (stat order)
+ * One launch, fixed summation order (bit-reproducible), asynchronous on `stream`.  A multi-GPU caller all-reduces
+ * d_out (RCCL) and divides by d_out[2]. */
+int pcgrl_reduce_episodes(pcgrl_handle h, double *d_out, int32_t clear, void *stream);
+
+/* Checkpoint / restore (envs/pcgrl_env.py:102-112 get_task / set_task pickle the whole env object).
+ *   pcgrl_set_state      the inverse of pcgrl_get_state for the envs selected by d_mask (NULL = all): maps d_grids uint8
+ *                        [N][cells], positions d_pos int32 [N][3] (NULL = origin), d_counters int32 [N][4] = iteration,
+ *                        changes, n_step, (ignored) and the running return d_ep_return double [N] (either may be NULL =
+ *                        zero).  Statistics and the loss base are recomputed from the map (they are a function of it).
+ *                        Not available with static tiles / action patches.
+ *   pcgrl_get/set_rng_state  both numpy-compatible PCG64 streams of every env (+ the buffered 32-bit half used by the
+ *                        representation wrappers): uint64 [N][10] = rep {state hi, lo, inc hi, lo}, prob {...},
+ *                        flags | has32 << 32, val32. */
+int pcgrl_set_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_grids, const int32_t *d_pos,
+                    const int32_t *d_counters, const double *d_ep_return, void *stream);
+int pcgrl_get_rng_state(pcgrl_handle h, uint64_t *d_out, void *stream);
+int pcgrl_set_rng_state(pcgrl_handle h, const uint8_t *d_mask, const uint64_t *d_in, void *stream);
 
 /* Synchronises the device and returns PCGRL_EACTION if any kernel saw an out-of-range action since the
  * last poll (the reference raises IndexError there), PCGRL_EHIP on a pending HIP error, else 0. */

@@ -756,3 +756,151 @@ def test_rollout_rejects_modes_it_does_not_cover():
         env2.rollout(a.to(env2.device))
     with pytest.raises(ValueError):
         _vec("binary", "narrow", (16, 16), 4).rollout(torch.zeros((2, 5), dtype=torch.int32))
+
+
+# ---------------------------------------------------------------- round 2: races, stale stats, reductions, checkpoints
+@pytest.mark.parametrize("problem,rep", [("binary", "narrow"), ("zelda", "turtle")])
+def test_auto_reset_every_few_steps_4096_envs_vs_oracle(problem, rep):
+    """Auto-reset stress: max_changes = 1, so an env resets at its second change -- some envs of every launch reset,
+    and both waves of their workgroup replay the env's RNG streams (the observe wave from the copy it took before the
+    barrier).  Thousands of launches at the BASELINE batch size, every output against the oracle."""
+    n = 4096
+    _rollout_vs_oracle(problem, rep, (16, 16), n, 1500, seed0=31, full_every=211, threads=16, change_percentage=0.001)
+
+
+@pytest.mark.parametrize("problem,rep,shape", [("binary", "narrow", (16, 16)), ("binary", "turtle", (20, 24)),
+                                               ("zelda", "narrow", (16, 16)), ("sokoban", "turtle", (16, 16)),
+                                               ("binary", "narrow", (40, 48))])
+def test_update_then_step_without_refresh_vs_oracle(problem, rep, shape):
+    """pcgrl_update leaves the statistics stale; the next CHANGING pcgrl_step must recompute them from scratch (the
+    reference's get_stats, pcgrl_env.py:314-323) -- not incrementally from the stale masks -- and non-changing steps in
+    between keep reporting the old values (the reference's _rep_stats)."""
+    n = 192
+    seeds = 900 + np.arange(n)
+    env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=False)
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds)
+    env.reset(); orc.reset()
+    g = torch.Generator().manual_seed(5)
+    for rnd in range(4):
+        for t in range(25):
+            a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+            env.update(a.to(env.device), want_obs=(t % 2 == 0))
+            orc.update(a.numpy())
+        for t in range(30):
+            a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+            if rnd == 3:  # through the rollout kernel
+                _, rew, done, stats = env.rollout(a.to(env.device)[None], want_obs="none")
+                rew, stats = rew[0], stats[0]
+            else:
+                _, rew, done, _, info = env.step(a.to(env.device))
+                stats = info["stats"]
+            _, orew, odone, ostats = orc.step(a.numpy())
+            assert np.array_equal(stats.cpu().numpy(), ostats), f"stats @ round {rnd} step {t}"
+            assert np.max(np.abs(rew.cpu().numpy() - orew)) <= REW_TOL, f"reward @ round {rnd} step {t}"
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep,shape,n", [("binary", "narrow", (16, 16), 4096), ("zelda", "turtle", (16, 16), 1000),
+                                                 ("minecraft_3D_maze", "narrow", (3, 3, 3), 700)])
+def test_reduce_episodes_equals_per_env_totals(problem, rep, shape, n):
+    """pcgrl_reduce_episodes = sum over envs and episodes of what pcgrl_get_last_episode latches, bit-reproducible;
+    clear restarts the totals."""
+    env = _vec(problem, rep, shape, n, seeds=np.arange(n), auto_reset=True, change_percentage=0.02)
+    env.reset()
+    g = torch.Generator(device=env.device).manual_seed(2)
+    tot = np.zeros(3 + env.n_stats)
+    seen = np.zeros(n, np.int64)
+    for t in range(400):
+        a = torch.randint(0, env.num_actions, (n,), generator=g, device=env.device, dtype=torch.int32)
+        _, _, done, _, _ = env.step(a)
+        if done.any():
+            le = env.last_episode()
+            d = done.cpu().numpy()
+            tot[0] += le.ep_return.cpu().numpy()[d].sum()
+            tot[1] += le.ep_len.cpu().numpy()[d].sum()
+            tot[2] += d.sum()
+            tot[3:] += le.final_stats.cpu().numpy()[d].sum(0)
+            seen += d
+        if t == 250:
+            a1 = env.reduce_episodes(clear=False).cpu().numpy()
+            a2 = env.reduce_episodes(clear=False).cpu().numpy()
+            assert np.array_equal(a1, a2)
+            assert np.allclose(a1, tot, rtol=0, atol=1e-6), (a1, tot)
+            part = tot.copy()
+            assert np.array_equal(env.reduce_episodes(clear=True).cpu().numpy(), a1)
+            assert not env.reduce_episodes(clear=False).cpu().numpy().any()
+    assert tot[2] > n  # several episodes per env
+    assert np.array_equal(env.last_episode().n_episodes.cpu().numpy(), seen)
+    assert np.allclose(env.reduce_episodes().cpu().numpy(), tot - part, rtol=0, atol=1e-6)
+    env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep,shape", [("binary", "narrow", (16, 16)), ("zelda", "turtle", (16, 16)),
+                                               ("sokoban", "wide", (16, 16)), ("minecraft_3D_maze", "narrow", (7, 7, 7)),
+                                               ("binary", "turtle", (40, 48))])
+def test_state_dict_round_trip_continues_bit_exactly(problem, rep, shape):
+    """checkpoint / restore (pcgrl_get_state + pcgrl_get_rng_state -> pcgrl_set_state + pcgrl_set_rng_state): a run
+    restored into ANOTHER engine continues with identical outputs, including auto-resets drawn from the restored RNG."""
+    n = 96
+    kw = dict(seeds=40 + np.arange(n), auto_reset=True, change_percentage=0.05)
+    env = _vec(problem, rep, shape, n, **kw)
+    env.reset()
+    g = torch.Generator().manual_seed(8)
+    acts = torch.randint(0, env.num_actions, (140, n), generator=g, dtype=torch.int32).to(env.device)
+    for t in range(60):
+        env.step(acts[t])
+    sd = env.state_dict()
+    want = []
+    for t in range(60, 140):
+        obs, rew, done, _, info = env.step(acts[t])
+        want.append((obs.clone(), rew.clone(), done.clone(), info["stats"].clone()))
+    other = _vec(problem, rep, shape, n, seeds=np.zeros(n, np.int64), auto_reset=True, change_percentage=0.05)
+    other.reset()
+    other.load_state_dict(sd)
+    st = other.get_state()
+    assert torch.equal(st.grids, sd["grids"]) and torch.equal(st.counters[:, :3], sd["counters"][:, :3])
+    for t in range(60, 140):
+        obs, rew, done, _, info = other.step(acts[t])
+        w = want[t - 60]
+        assert torch.equal(info["stats"], w[3]), f"stats @ {t}"
+        assert torch.equal(rew, w[1]) and torch.equal(done, w[2]), f"reward / done @ {t}"
+        assert torch.equal(obs, w[0]), f"obs @ {t}"
+    other.check_errors()
+
+
+def test_stats_for_grids_any_batch_size_and_async():
+    """Problem.get_stats through an existing engine's scratch: the number of maps is independent of the engine's batch."""
+    z = np.load(os.path.join(GOLDEN, "stats_sokoban.npz"))
+    env = _vec("sokoban", "narrow", z["grids"].shape[1:], 3, auto_reset=False)
+    got = env.stats_for_grids(torch.as_tensor(z["grids"]))
+    assert np.array_equal(got.cpu().numpy(), z["stats"])
+    z = np.load(os.path.join(GOLDEN, "stats_mc3dmaze.npz"))
+    env3 = _vec("minecraft_3D_maze", "narrow", z["grids"].shape[1:], 2, auto_reset=False)
+    assert np.array_equal(env3.stats_for_grids(torch.as_tensor(z["grids"])).cpu().numpy(), z["stats"])
+    env.check_errors(); env3.check_errors()
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py --gpus 2 started plainly: it launches its own two ranks (here both on cuda:0, gloo collectives), shards
+    the envs, and the reduced episode count is the sum of the shards'."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PCGRL_BENCH_SINGLE_DEVICE="1", PCGRL_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "256", "--steps", "800",
+                        "--warmup", "0", "--no-cpu-baseline", "--rollout-steps", "0"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["config"]["envs_per_gpu"] == 256 and out["config"]["global_envs"] == 512
+    assert out["config"]["seed_ranges"] == [[0x5EED, 0x5EED + 255], [0x5EED + 256, 0x5EED + 511]]
+    # 800 steps of a 770-step episode: every env of both shards finished exactly one episode
+    assert out["per_rank"]["episodes"] == [256.0, 256.0] and out["episodes"]["episodes"] == 512.0
+    assert out["episodes"]["mean_length"] == 770.0
+    assert len(out["per_rank"]["env_steps_per_s"]) == 2
+    rf = out["roofline"]
+    assert abs(rf["frac"] - rf["algorithmic_bytes_per_launch"] / (out["ms_per_step"] * 1e-3) / 1e9 / rf["peak"]) < 1e-9

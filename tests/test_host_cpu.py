@@ -146,3 +146,21 @@ def test_bench_bfs_active_maps_have_one_player_key_door():
         assert ((g == t).sum(axis=(1, 2)) == 1).all()
     assert not {4 + 2, 4 + 3, 4 + 4} & set(bench.BFS_ACTIONS)
     assert set(bench.WORKLOADS) == set(bench.ALGO_BYTES)
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (gloo rendezvous on 127.0.0.1), shards the
+    envs with contiguous seed ranges, and rank 0 alone prints the line; --gpus N under a mismatching WORLD_SIZE fails."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--envs", "100"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["global_envs"] == 200
+    assert out["first_last_seed_per_rank"] == [[0x5EED, 0x5EED + 99], [0x5EED + 100, 0x5EED + 199]]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

@@ -15,9 +15,7 @@ NAMES = ["loads+barrier", "action+state", "stats refresh (total)", "  flood", " 
          "loss/outputs/write-back"]
 
 if "--build" in sys.argv:
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-falign-loops=32", "-fPIC",
-                    "-shared", "-DPCGRL_PHASE_TIMING", "-o", TIMING_LIB, os.path.join(_lib.CSRC, "pcgrl_engine.hip")],
-                   check=True)
+    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",))
     print("built", TIMING_LIB)
     sys.exit(0)
 

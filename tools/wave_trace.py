@@ -12,9 +12,7 @@ from control_pcgrl_amd import _lib
 
 TRACE_LIB = os.path.join(_lib.CSRC, "libpcgrl_amd_trace.so")
 if "--build" in sys.argv:
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-falign-loops=32",
-                    "-fPIC", "-shared", "-DPCGRL_WAVE_TRACE", "-o", TRACE_LIB, os.path.join(_lib.CSRC, "pcgrl_engine.hip")],
-                   check=True)
+    _lib.build(force=True, out=TRACE_LIB, defines=("PCGRL_WAVE_TRACE",))
     print("built", TRACE_LIB)
     sys.exit(0)
 
