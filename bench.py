@@ -249,16 +249,22 @@ def main():
     ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
 
     def reduce_episodes():
-        """the path's only exchange: one pcgrl_reduce_episodes launch (+ one small all-reduce over RCCL when world > 1)
-        and one device -> host copy"""
+        """the path's only exchange: one pcgrl_reduce_episodes launch; world == 1: the kernel writes its 3 + n_stats
+        doubles straight into pinned host memory (no copy); world > 1: one small all-reduce over RCCL, then one
+        device -> host copy.  Ends with the device synchronised."""
+        if world == 1:
+            rc = env._L.pcgrl_reduce_episodes(env._h, ep_host.data_ptr(), 1, sptr)
+            if rc:
+                raise RuntimeError(f"pcgrl_reduce_episodes rc={rc}")
+            torch.cuda.synchronize(dev)
+            return
         env.reduce_episodes(clear=True, out=ep_dev)
-        if world > 1:
-            if coll_dev.type == "cpu":  # gloo test hook
-                t = ep_dev.cpu()
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                ep_host.copy_(t)
-                return
-            dist.all_reduce(ep_dev, op=dist.ReduceOp.SUM)
+        if coll_dev.type == "cpu":  # gloo test hook
+            t = ep_dev.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ep_host.copy_(t)
+            return
+        dist.all_reduce(ep_dev, op=dist.ReduceOp.SUM)
         ep_host.copy_(ep_dev, non_blocking=True)
         torch.cuda.synchronize(dev)
 
@@ -272,8 +278,9 @@ def main():
     ev1.record(stream)
     if world > 1:  # (test evidence: this rank's own episode count, read after the timed region)
         local_eps = env.reduce_episodes(clear=False)[2:3].clone()
-    reduce_episodes()
-    barrier()
+    reduce_episodes()  # (synchronises the device)
+    if world > 1:
+        barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
     env.check_errors()

@@ -180,8 +180,7 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
     if (c.obs_window[0] != H || c.obs_window[1] != W)
       return fail(PCGRL_EINVAL, "wide representation needs obs_window == map_shape (reference wrappers.py:140-150 reshape)");
     if (H != W) return fail(PCGRL_EUNSUPPORTED, "wide representation: the reference's transposed write needs a square map");
-    if ((W * nt) % 16) return fail(PCGRL_EUNSUPPORTED, "wide observation rows must be a multiple of 16 bytes");
-    obs_chunks = W * nt / 16;
+    obs_chunks = (W * nt + 15) / 16;  // rows that are not a multiple of 16 bytes take the byte-string store path
     obs_bytes = (int64_t)H * W * nt;
     shape[0] = H;
     shape[1] = W;
@@ -190,8 +189,7 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
   } else {
     const int OH = c.obs_window[0], OW = c.obs_window[1], C = nt + 1 + (c.static_tiles ? 1 : 0);
     if (OH < 1 || OW < 1) return fail(PCGRL_EINVAL, "obs_window must be positive");
-    if ((OW * C) % 16) return fail(PCGRL_EUNSUPPORTED, "obs_window[1] * channels must be a multiple of 16 bytes");
-    obs_chunks = OW * C / 16;
+    obs_chunks = (OW * C + 15) / 16;
     obs_bytes = (int64_t)OH * OW * C;
     shape[0] = OH;
     shape[1] = OW;

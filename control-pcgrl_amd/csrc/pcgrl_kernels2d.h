@@ -943,7 +943,7 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
 // One lane assembles one observation row (OW*C bytes) in its own LDS row (row stride = bytes + 16, which keeps
 // 16-byte alignment and makes the 16-byte fills / read-backs bank-conflict free), scatters the one-hot bytes of
 // its map row into it, and streams it out with 16-byte stores.
-__device__ inline int lds_row_stride(int row_bytes) { return row_bytes + 16; }
+__device__ inline int lds_row_stride(int row_bytes) { return ((row_bytes + 15) & ~15) + 16; }
 
 // 16-byte observation store, write-through (sc1): the line leaves the XCD's L2 while the kernel is still running
 // instead of being written back at the kernel boundary (MI355X_MICROARCH.md "boundary" / "publish-large" rows: a
@@ -954,6 +954,32 @@ __device__ inline void store_obs16(void *dst, uint4 v) {
   // the trailing s_nop covers the gfx9 hazard "VALU overwrites the data VGPRs of a >64-bit VMEM store" (2 wait states),
   // which the compiler's hazard recognizer cannot see through an asm statement
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
+}
+
+// Observation rows that are not a multiple of 16 bytes (e.g. the reference's zelda_small task: 22 pixels x 9 channels =
+// 198 bytes): the env's observation is streamed as one byte string of n_rows * RB bytes, byte k taken from the LDS row
+// row_ptr(k / RB) at offset k % RB -- dwords when the env size allows aligned ones, bytes otherwise.  Plain stores.
+template <int LPE, typename RowFn>
+__device__ inline void stream_obs_bytes(const Grp<LPE> &g, uint8_t *base, int n_rows, int RB, RowFn row_ptr) {
+  const int T = n_rows * RB;
+  const float inv = 1.0f / (float)RB;  // floor((k + 0.5) / RB) is exact in fp32 for k < 2^20
+  if ((T & 3) == 0) {
+    for (int k4 = g.row; k4 < (T >> 2); k4 += LPE) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = 4 * k4 + j;
+        const int i = (int)(((float)k + 0.5f) * inv);
+        v |= (uint32_t)row_ptr(i)[k - i * RB] << (8 * j);
+      }
+      *(uint32_t *)(base + 4 * (size_t)k4) = v;
+    }
+  } else {
+    for (int k = g.row; k < T; k += LPE) {
+      const int i = (int)(((float)k + 0.5f) * inv);
+      base[k] = row_ptr(i)[k - i * RB];
+    }
+  }
 }
 
 // 16-byte chunk q of the all-out-of-bounds row pattern (byte k is 1 iff k % C == 0)
@@ -1000,11 +1026,19 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
   if (obs_base == nullptr) obs_base = p.obs;
   if (p.cfg.representation == PCGRL_REP_WIDE) {
     // wrappers.py:502-526: plain one-hot of the map, (H, W, NT), no out-of-bounds channel
-    const int row_bytes = W * NT, chunks = row_bytes >> 4;
+    const int row_bytes = W * NT, chunks = (row_bytes + 15) >> 4;
     uint8_t *row = lds + g.lane * lds_row_stride(row_bytes);
     for (int q = 0; q < chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
-    if (active && g.row < H) {
+    if (active && g.row < H)
       for (int x = 0; x < W; x++) row[x * NT + tile_at<NB, M>(b, x)] = 1;
+    if (row_bytes & 15) {  // rows of odd size: the group streams the env's observation as one byte string
+      const int gb = g.gbase, stride = lds_row_stride(row_bytes);
+      if (active)
+        stream_obs_bytes(g, obs_base + (size_t)env * H * row_bytes, H, row_bytes,
+                         [&](int i) -> const uint8_t * { return lds + (gb + i) * stride; });
+      return;
+    }
+    if (active && g.row < H) {
       uint8_t *dst = obs_base + ((size_t)env * H + g.row) * row_bytes;
       for (int q = 0; q < chunks; q++) store_obs16(dst + q * 16, *(uint4 *)(row + q * 16));
     }
@@ -1022,7 +1056,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
   const int OH = FAST ? FOH : p.cfg.obs_window[0], OW = FAST ? FOW : p.cfg.obs_window[1];
   const int CW = FAST ? FW : W;
   const int CH = FAST ? FOW * C / 16 : p.obs_chunks;  // 16-byte chunks per observation row
-  const int RB = OW * C, STRIDE = RB + 16;
+  const int RB = OW * C, STRIDE = CH * 16 + 16;
   uint8_t *row = lds + g.lane * STRIDE;
   uint8_t *oob_row = lds + 64 * STRIDE;
   const int top = pos[0] - OH / 2;   // map row shown by obs row 0
@@ -1066,6 +1100,12 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
         const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
         store_obs16(base + (size_t)k * 16, *(const uint4 *)src);
       }
+    } else if (RB & 15) {
+      const int gb = g.gbase;
+      stream_obs_bytes(g, base, OH, RB, [&](int i) -> const uint8_t * {
+        const int m = i + top;
+        return (unsigned)m < (unsigned)H ? lds + (gb + m) * STRIDE : oob_row;
+      });
     } else {
       for (int k = g.row; k < total; k += LPE) {
         int i = k / CH, q = k - i * CH;
@@ -1276,7 +1316,7 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   if (p.obs == nullptr) return;
   const int H = p.cfg.dims[0], OH = p.cfg.obs_window[0], OW = p.cfg.obs_window[1];
-  const int C = NT + 2, CH = p.obs_chunks, RB = OW * C, STRIDE = RB + 16;
+  const int C = NT + 2, CH = p.obs_chunks, RB = OW * C, STRIDE = CH * 16 + 16;
   const int top = pos[0] - OH / 2, left = pos[1] - OW / 2;
   // LDS rows: 0..63 one per lane (bordered row index = map row index), 64 the all-out-of-bounds row,
   // 65 + 2*group + {0, 1}: bordered rows H and H+1 of the group's env
@@ -1303,6 +1343,14 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
   if (active) {
     uint8_t *base = p.obs + (size_t)env * OH * RB;
     const int total = OH * CH;
+    if (RB & 15) {
+      const int gb = g.gbase;
+      stream_obs_bytes(g, base, OH, RB, [&](int i) -> const uint8_t * {
+        const int m = i + top;
+        return (unsigned)m < (unsigned)H ? lds + (gb + m) * STRIDE : ((m == H || m == H + 1) ? xrows + (m - H) * STRIDE : oob_row);
+      });
+      return;
+    }
     const float inv_ch = 1.0f / (float)CH;  // floor((k + 0.5) / CH) is exact in fp32 for k < 2^20
     for (int k = g.row; k < total; k += LPE) {
       const int i = (int)(((float)k + 0.5f) * inv_ch), q = k - i * CH;

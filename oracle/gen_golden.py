@@ -637,3 +637,145 @@ def gen_stats_mc3d_test3d():
 
 if __name__ == "__main__" and "test3d" in sys.argv[1:]:
     gen_stats_mc3d_test3d()
+
+
+# ------------------------------------------------------------------ map shapes off the 16x16 point
+# The reference's own larger / smaller task configs (configs/task/binary_big.yaml 32x32 obs 64, binary_bigger.yaml and
+# zelda_bigger.yaml 64x64 obs 128, zelda_big.yaml 32x32, zelda_small.yaml 7x11 obs 22x22) plus shapes that select every
+# other kernel family of the engine (lanes per env 8 / 16 / 32 / 64 x 32- / 64-bit row masks, non-square maps).
+# Episodes are kept short with cfg.change_percentage (pcgrl_env.py:235-239, :308-309): reset -> episode -> reset -> a few
+# more steps.  Compact format: per-step CRC32 of grid and observation, everything else in full; full grids /
+# observations only at a handful of steps.
+SHAPE_CONFIGS = {
+    # name: (problem, representation, map_shape, obs_window or None (reference default), max_changes wanted)
+    "binary_big_narrow": ("binary", "narrow", (32, 32), (64, 64), 70),
+    "binary_bigger_turtle": ("binary", "turtle", (64, 64), (128, 128), 25),
+    "zelda_bigger_narrow": ("zelda", "narrow", (64, 64), (128, 128), 120),
+    "zelda_big_turtle": ("zelda", "turtle", (32, 32), (64, 64), 80),
+    "zelda_small_turtle": ("zelda", "turtle", (7, 11), (22, 22), 60),
+    "zelda_small_narrow": ("zelda", "narrow", (7, 11), (22, 22), 70),
+    "binary_narrow_8x8": ("binary", "narrow", (8, 8), None, 40),
+    "binary_narrow_12x20": ("binary", "narrow", (12, 20), None, 60),
+    "binary_turtle_24x20": ("binary", "turtle", (24, 20), None, 25),
+    "binary_narrow_40x24": ("binary", "narrow", (40, 24), None, 60),
+    "binary_narrow_20x40": ("binary", "narrow", (20, 40), None, 60),
+    "binary_narrow_40x48": ("binary", "narrow", (40, 48), None, 60),
+    "binary_wide_32x32": ("binary", "wide", (32, 32), None, 60),
+    "zelda_wide_8x8": ("zelda", "wide", (8, 8), None, 60),
+    "sokoban_turtle_10x12": ("sokoban", "turtle", (10, 12), None, 40),
+    "sokoban_narrow_20x20": ("sokoban", "narrow", (20, 20), None, 80),
+    "sokoban_narrow_40x30": ("sokoban", "narrow", (40, 30), None, 80),
+    "sokoban_wide_8x8": ("sokoban", "wide", (8, 8), None, 50),
+}
+
+
+def run_shape_episode(name, seed, extra_steps=30):
+    problem, rep, shape, ow, mc = SHAPE_CONFIGS[name]
+    n_cells = int(np.prod(shape))
+    cp = (mc + 0.5) / n_cells  # int(cp * n_cells) == mc
+    cfg = ref_env.make_cfg(problem, rep, shape, obs_window=ow, change_percentage=cp)
+    env = ref_env.make_reference_env(cfg, seed=seed)
+    core = env.unwrapped
+    assert core._max_changes == mc, (core._max_changes, mc)
+    n_act = env.action_space.n
+    arng = np.random.default_rng(5000 + seed)
+    rec = {k: [] for k in ("grid_crc", "pos", "stats", "reward", "done", "changes", "iterations", "obs_crc", "action")}
+    grids, obss = {}, {}
+    resets = {k: [] for k in ("step", "grid", "pos", "stats", "obs_crc")}
+
+    def cur_pos():
+        p = getattr(core._rep.unwrapped, "_pos", None)
+        return np.zeros(len(shape), np.int64) if p is None else np.array(p, dtype=np.int64).copy()
+
+    def do_reset(step_idx):
+        obs, _ = env.reset()
+        resets["step"].append(step_idx)
+        resets["grid"].append(core._rep.unwrapped._map.astype(np.uint8).ravel().copy())
+        resets["pos"].append(cur_pos())
+        resets["stats"].append(stats_vec(problem, core._rep_stats))
+        resets["obs_crc"].append(zlib.crc32(obs_u8(obs).tobytes()))
+
+    t, ep_len = 0, None
+    do_reset(0)
+    while True:
+        a = int(arng.integers(n_act))
+        obs, r, d, tr, info = env.step(a)
+        g = core._rep.unwrapped._map.astype(np.uint8).ravel().copy()
+        u = obs_u8(obs)
+        rec["action"].append(a); rec["grid_crc"].append(zlib.crc32(g.tobytes())); rec["pos"].append(cur_pos())
+        rec["stats"].append(stats_vec(problem, core._rep_stats)); rec["reward"].append(float(r)); rec["done"].append(bool(d))
+        rec["changes"].append(int(info["changes"])); rec["iterations"].append(int(info["iterations"]))
+        rec["obs_crc"].append(zlib.crc32(u.tobytes()))
+        grids[t], obss[t] = g, u.ravel().copy()
+        t += 1
+        if d:
+            if ep_len is None:
+                ep_len = t
+                do_reset(t)
+            else:
+                break
+        if ep_len is not None and t >= ep_len + extra_steps:
+            break
+    keep = sorted(set([0, 1, ep_len // 2, ep_len - 1, ep_len, t - 1]))
+    out = dict(
+        problem=problem, representation=rep, map_shape=np.array(shape), obs_window=np.array(cfg.task.obs_window), seed=seed,
+        change_percentage=cp, max_changes=mc, stat_keys=np.array(STAT_KEYS[problem]), n_actions=n_act, episode_len=ep_len,
+        action=np.array(rec["action"], np.int32), grid_crc=np.array(rec["grid_crc"], np.uint32),
+        pos=np.array(rec["pos"], np.int16), stats=np.array(rec["stats"], np.int32), reward=np.array(rec["reward"], np.float64),
+        done=np.array(rec["done"], np.bool_), changes=np.array(rec["changes"], np.int32),
+        iterations=np.array(rec["iterations"], np.int32), obs_crc=np.array(rec["obs_crc"], np.uint32),
+        full_steps=np.array(keep, np.int32), grid_full=np.array([grids[k] for k in keep], np.uint8),
+        obs_full=np.array([obss[k] for k in keep], np.uint8),
+        reset_step=np.array(resets["step"], np.int32), reset_grid=np.array(resets["grid"], np.uint8),
+        reset_pos=np.array(resets["pos"], np.int16), reset_stats=np.array(resets["stats"], np.int32),
+        reset_obs_crc=np.array(resets["obs_crc"], np.uint32))
+    path = os.path.join(OUT, f"shape_{name}_s{seed}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "T=", t, "ep_len=", ep_len, os.path.getsize(path), "bytes", flush=True)
+
+
+def gen_stats_shapes():
+    """Problem.get_stats known answers at the same shapes (random densities + a snake per shape): one array pair per
+    (problem, shape) in a single file."""
+    rng = np.random.default_rng(21)
+    out = {}
+    for problem, shape, n in (("binary", (32, 32), 24), ("binary", (64, 64), 10), ("binary", (8, 8), 40), ("binary", (40, 48), 12),
+                              ("binary", (20, 40), 16), ("binary", (40, 24), 16), ("zelda", (64, 64), 8), ("zelda", (32, 32), 16),
+                              ("zelda", (7, 11), 60), ("sokoban", (20, 20), 16), ("sokoban", (40, 30), 10), ("sokoban", (8, 8), 30)):
+        core = _problem(problem, shape)
+        nt = {"binary": 2, "zelda": 8, "sokoban": 5}[problem]
+        grids = []
+        if problem == "binary":
+            grids += [snake(*shape), snake(shape[1], shape[0], True) if shape[0] != shape[1] else snake(*shape, True),
+                      np.zeros(shape, np.uint8), np.ones(shape, np.uint8)]
+        for i in range(n):
+            if problem == "binary":
+                grids.append((rng.random(shape) < rng.uniform(0.1, 0.7)).astype(np.uint8))
+            elif problem == "zelda":  # mostly one player / key / door so the searches run
+                g = np.where(rng.random(shape) < rng.uniform(0.05, 0.45), 1, 0).astype(np.uint8)
+                for tile, cnt in ((5, 2), (6, 1), (7, 2)):
+                    for _ in range(cnt):
+                        g[tuple(rng.integers(s) for s in shape)] = tile
+                cells = rng.permutation(int(np.prod(shape)))[:3]
+                for c, tile in zip(cells, (2, 3, 4)):
+                    g[c // shape[1], c % shape[1]] = tile
+                if i % 4 == 3:
+                    g[tuple(rng.integers(s) for s in shape)] = 2  # sometimes a second player
+                grids.append(g)
+            else:
+                probs = rng.random(nt); probs[0] += 1.0; probs /= probs.sum()
+                grids.append(rng.choice(nt, size=shape, p=probs).astype(np.uint8))
+        grids = np.array(grids, np.uint8)
+        stats = np.array([_get_stats(core, problem, g) for g in grids], np.int32)
+        key = f"{problem}_{shape[0]}x{shape[1]}"
+        out["grids_" + key], out["stats_" + key] = grids, stats
+        print("stats_shapes", key, grids.shape, "max", stats.max(0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "stats_shapes.npz"), **out)
+
+
+if __name__ == "__main__" and "shapes" in sys.argv[1:]:
+    only = [a for a in sys.argv[1:] if a in SHAPE_CONFIGS]
+    for i, name in enumerate(only or SHAPE_CONFIGS):
+        run_shape_episode(name, 60 + list(SHAPE_CONFIGS).index(name))
+    if not only:
+        gen_stats_shapes()

@@ -904,3 +904,79 @@ def test_bench_two_ranks_on_one_device():
     assert len(out["per_rank"]["env_steps_per_s"]) == 2
     rf = out["roofline"]
     assert abs(rf["frac"] - rf["algorithmic_bytes_per_launch"] / (out["ms_per_step"] * 1e-3) / 1e9 / rf["peak"]) < 1e-9
+
+
+# ---------------------------------------------------------------- map shapes off the 16x16 point, reference-pinned
+SHAPES = sorted(glob.glob(os.path.join(GOLDEN, "shape_*.npz")))
+
+
+@pytest.mark.parametrize("path", SHAPES, ids=[os.path.basename(p)[6:-4] for p in SHAPES])
+def test_golden_shape_episode_replay(path):
+    """Reference episodes at the reference's own binary_big (32x32) / binary_bigger, zelda_bigger (64x64, obs 128x128) /
+    zelda_big / zelda_small (7x11, obs 22x22: rows of 198 bytes) task configs and at shapes that select every other
+    kernel family (8 / 16 / 32 / 64 lanes per env, 32- and 64-bit row masks, non-square maps, sokoban off 16x16)."""
+    z = np.load(path)
+    problem, rep = str(z["problem"]), str(z["representation"])
+    shape = tuple(int(s) for s in z["map_shape"])
+    env = _vec(problem, rep, shape, 1, seeds=[int(z["seed"])], auto_reset=False,
+               obs_window=tuple(int(s) for s in z["obs_window"]), change_percentage=float(z["change_percentage"]))
+    assert env.cfg.max_changes == int(z["max_changes"])
+    T, ep_len = len(z["action"]), int(z["episode_len"])
+    full = {int(s): i for i, s in enumerate(z["full_steps"])}
+
+    def check_reset(k):
+        obs, _ = env.reset()
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["reset_grid"][k]), "reset grid (RNG stream)"
+        if rep != "wide":
+            assert np.array_equal(st.pos[0, :2].cpu().numpy(), z["reset_pos"][k])
+        assert np.array_equal(st.stats[0].cpu().numpy(), z["reset_stats"][k])
+        assert zlib.crc32(obs[0].cpu().numpy().tobytes()) == int(z["reset_obs_crc"][k])
+
+    check_reset(0)
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    for t in range(T):
+        obs, rew, done, _, info = env.step(acts[t:t + 1])
+        st = env.get_state()
+        g = st.grids[0].cpu().numpy()
+        assert zlib.crc32(g.tobytes()) == int(z["grid_crc"][t]), f"grid @ {t}"
+        if rep != "wide":
+            assert np.array_equal(st.pos[0, :2].cpu().numpy(), z["pos"][t]), f"pos @ {t}"
+        got = info["stats"][0].cpu().numpy()
+        assert np.array_equal(got, z["stats"][t]), f"stats @ {t}: {got} vs {z['stats'][t]}"
+        assert abs(float(rew[0]) - z["reward"][t]) <= REW_TOL, f"reward @ {t}"
+        assert bool(done[0]) == bool(z["done"][t]), f"done @ {t}"
+        assert int(st.changes[0]) == z["changes"][t] and int(st.iteration[0]) == z["iterations"][t]
+        o = obs[0].cpu().numpy()
+        assert zlib.crc32(o.tobytes()) == int(z["obs_crc"][t]), f"obs crc @ {t}"
+        if t in full:
+            assert np.array_equal(g.ravel(), z["grid_full"][full[t]])
+            assert np.array_equal(o.ravel(), z["obs_full"][full[t]])
+        if t == ep_len - 1:
+            check_reset(1)
+    env.check_errors()
+
+
+def test_golden_shape_stats_known_answers():
+    z = np.load(os.path.join(GOLDEN, "stats_shapes.npz"))
+    for key in sorted(k[6:] for k in z.files if k.startswith("grids_")):
+        problem = key.split("_")[0]
+        grids = z["grids_" + key]
+        env = _vec(problem, "narrow", grids.shape[1:], 1, auto_reset=False)
+        got = env.stats_for_grids(torch.as_tensor(grids)).cpu().numpy()
+        assert np.array_equal(got, z["stats_" + key]), key
+        env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep,shape,ow", [("zelda", "turtle", (7, 11), (22, 22)), ("zelda", "narrow", (7, 11), (22, 22)),
+                                                  ("binary", "narrow", (9, 9), (11, 13)), ("sokoban", "wide", (10, 10), None),
+                                                  ("binary", "turtle", (33, 35), (7, 5)), ("zelda", "wide", (6, 6), None)])
+def test_observation_rows_of_odd_size_vs_oracle(problem, rep, shape, ow):
+    """observation rows that are not a multiple of 16 bytes (byte-string store path), batch of envs"""
+    kw = {} if ow is None else {"obs_window": ow}
+    _rollout_vs_oracle(problem, rep, shape, 77, 200, seed0=700, full_every=9, change_percentage=0.3, **kw)
+
+
+def test_static_tiles_with_odd_observation_rows_vs_oracle():
+    _rollout_vs_oracle("zelda", "narrow", (7, 11), 50, 220, seed0=720, full_every=7, obs_window=(22, 22),
+                       static_prob=0.2, n_static_walls=2)
