@@ -980,3 +980,43 @@ def test_observation_rows_of_odd_size_vs_oracle(problem, rep, shape, ow):
 def test_static_tiles_with_odd_observation_rows_vs_oracle():
     _rollout_vs_oracle("zelda", "narrow", (7, 11), 50, 220, seed0=720, full_every=7, obs_window=(22, 22),
                        static_prob=0.2, n_static_walls=2)
+
+
+@pytest.mark.parametrize("name", ["binary_narrow", "zelda_turtle", "sokoban_wide"])
+def test_rllib_vector_env_adapter_matches_golden(name):
+    """PcgrlVectorEnv (ray.rllib VectorEnv call shape, duck-typed: no ray here): three reference episodes side by side
+    in ONE engine -- vector_reset / vector_step / reset_at / get_sub_environments against the fixtures."""
+    from control_pcgrl_amd import PcgrlVectorEnv
+    zs = [np.load(os.path.join(GOLDEN, f"episode_{name}_s{s}.npz")) for s in (1, 2, 3)]
+    z0 = zs[0]
+    cfg = {"task": {"problem": str(z0["problem"]), "map_shape": [int(s) for s in z0["map_shape"]],
+                    "obs_window": [int(s) for s in z0["obs_window"]], "weights": None},
+           "representation": str(z0["representation"])}
+    env = PcgrlVectorEnv(cfg, num_envs=3, seeds=[int(z["seed"]) for z in zs], obs_dtype=np.float32)
+    assert env.observation_space.shape == tuple(int(s) for s in z0["obs_shape"]) and env.action_space.n == int(z0["n_actions"])
+    obs, infos = env.vector_reset()
+    assert len(obs) == 3 and infos == [{}, {}, {}]
+    for k, z in enumerate(zs):
+        assert obs[k].dtype == np.float32 and np.array_equal(obs[k].astype(np.uint8).ravel(), z["reset_obs"][0])
+    ep_len = int(z0["episode_len"])
+    T = min(len(z["action"]) for z in zs)
+    for t in range(T):
+        obs, rew, term, trunc, infos = env.vector_step([int(z["action"][t]) for z in zs])
+        assert term == trunc and len(infos) == 3
+        for k, z in enumerate(zs):
+            assert zlib.crc32(obs[k].astype(np.uint8).tobytes()) == int(z["obs_crc"][t]), f"obs env {k} @ {t}"
+            assert abs(rew[k] - z["reward"][t]) <= REW_TOL and term[k] == bool(z["done"][t])
+        if t % 97 == 0 or t == ep_len - 1:
+            for k, z in enumerate(zs):
+                want = dict(zip([str(s) for s in z["stat_keys"]], z["stats"][t].tolist()))
+                info = infos[k]
+                assert {s: info[s] for s in want} == want and info["iterations"] == int(z["iterations"][t])
+                assert env.get_sub_environments()[k].unwrapped._rep_stats == want
+        if t == ep_len - 1:
+            assert all(term)
+            for k in (2, 0, 1):  # RLlib resets each finished env; one masked launch serves all three
+                o, info = env.reset_at(k)
+                assert info == {} and np.array_equal(o.astype(np.uint8).ravel(), zs[k]["reset_obs"][1])
+    with pytest.raises(IndexError):
+        env.vector_step([0, 10 ** 6, 0])
+    env.close()

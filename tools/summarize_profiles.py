@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV outputs (gpurun_out/prof_*) into small tracked summaries under profiles/.
+"""Condense rocprofv3 CSV outputs (gpurun_out/prof_<workload>_{kt,fetch,write,sq}) into small tracked summaries.
 
-  python tools/summarize_profiles.py r01 [outdir]
+  python tools/summarize_profiles.py r02 [outdir]
 (on the GPU box: outdir = gpurun_out/summary, then delete the raw traces -- gpurun only copies back 64 MiB)
-writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim top rows) and
-profiles/<tag>_summary.json (per-kernel durations, PMC counters per launch, derived HBM traffic).
+writes <outdir>/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats rows of the engine's kernels, verbatim, one block
+per workload) and <outdir>/<tag>_summary.json (per workload: per-kernel durations, distribution of the dominant kernel's
+begin-end times, PMC counters per launch, derived HBM traffic, LDS bank-conflict rate, waves per CU).
+Produced by tools/profile_all.sh.
 """
 import csv
 import glob
@@ -16,6 +18,9 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
+sys.path.insert(0, ROOT)
+ENVS = {"binary-narrow": 4096, "zelda-turtle": 4096, "sokoban-wide": 2048, "minecraft_3D_maze-narrow": 1024,
+        "zelda-turtle-bfs": 4096, "sokoban-wide-solver": 2048}
 
 
 def first(pattern):
@@ -24,41 +29,43 @@ def first(pattern):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")[:60]
+    return name.split("(")[0].replace("void ", "")[:72]
 
 
-def main(tag, outdir=None):
-    outdir = outdir or os.path.join(ROOT, "profiles")
-    os.makedirs(outdir, exist_ok=True)
-    out = {"tag": tag, "source": "rocprofv3 on python3 bench.py (binary-narrow 16x16, 4096 envs, 1 MI355X)"}
-    ks = first("prof_kt/**/*kernel_stats.csv")
+def summarize(w, stats_rows):
+    import bench
+    out = {}
+    dom = "m3_kernel" if "3D" in w else "step_kernel"
+    ks = first(f"prof_{w}_kt/**/*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
         keep = [r for r in rows if "pcgrl" in r["Name"]]
-        with open(os.path.join(outdir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=rows[0].keys())
-            w.writeheader()
-            for r in keep:
-                w.writerow(r)
+        for r in keep:
+            stats_rows.append(dict(r, Workload=w))
         out["kernel_stats"] = [{"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                 "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                 "pct": float(r["Percentage"])} for r in keep]
-    kt = first("prof_kt/**/*kernel_trace.csv")
+    kt = first(f"prof_{w}_kt/**/*kernel_trace.csv")
     if kt:
-        rows = [r for r in csv.DictReader(open(kt)) if "step_kernel" in r["Kernel_Name"]]
-        gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
-        r0 = rows[0]
-        durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
-        periods = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["Start_Timestamp"]) for i in range(len(rows) - 1)]
-        q = lambda f: durs[min(len(durs) - 1, int(f * len(durs)))]
-        out["step_kernel_launch"] = {"grid": int(r0["Grid_Size_X"]), "workgroup": int(r0["Workgroup_Size_X"]),
-                                     "median_gap_between_launches_ns": statistics.median(gaps),
-                                     "duration_ns": {"p10": q(0.1), "median": q(0.5), "p90": q(0.9), "p99": q(0.99),
-                                                     "mean": statistics.mean(durs)},
-                                     "median_start_to_start_ns": statistics.median(periods)}
+        rows = [r for r in csv.DictReader(open(kt)) if dom in r["Kernel_Name"] and "M3_ROLLOUT" not in r["Kernel_Name"]
+                and ("m3_kernel<(pcgrl::M3Mode)0>" in r["Kernel_Name"] or dom == "step_kernel")]
+        if len(rows) > 2:
+            gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
+            r0 = rows[0]
+            durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+            periods = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["Start_Timestamp"]) for i in range(len(rows) - 1)]
+            q = lambda f: durs[min(len(durs) - 1, int(f * len(durs)))]
+            out["dominant_kernel_launch"] = {
+                "kernel": short(r0["Kernel_Name"]), "launches": len(rows), "grid": int(r0["Grid_Size_X"]),
+                "workgroup": int(r0["Workgroup_Size_X"]), "lds_bytes": int(r0.get("LDS_Block_Size", 0) or 0),
+                "vgpr": int(r0.get("VGPR_Count", 0) or 0), "sgpr": int(r0.get("SGPR_Count", 0) or 0),
+                "scratch_bytes": int(r0.get("Scratch_Size", 0) or 0),
+                "median_gap_between_launches_ns": statistics.median(gaps),
+                "duration_ns": {"p10": q(0.1), "median": q(0.5), "p90": q(0.9), "p99": q(0.99), "mean": statistics.mean(durs)},
+                "median_start_to_start_ns": statistics.median(periods)}
     counters = defaultdict(dict)
-    for d in ("prof_fetch", "prof_write", "prof_sq"):
-        f = first(f"{d}/**/*counter_collection.csv")
+    for d in ("fetch", "write", "sq", "sq2"):
+        f = first(f"prof_{w}_{d}/**/*counter_collection.csv")
         if not f:
             continue
         agg = defaultdict(list)
@@ -68,25 +75,53 @@ def main(tag, outdir=None):
         for (k, c), v in agg.items():
             counters[k][c] = {"mean_per_launch": statistics.mean(v), "launches": len(v)}
     out["pmc"] = counters
-    # HBM traffic of the step kernel per launch.  FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md: FETCH_SIZE
-    # under-reports wide coalesced reads by 2x on gfx950; WRITE_SIZE is calibrated here on observe_kernel, which writes
-    # exactly 4096 * 3072 B with the same store pattern as the step kernel.
-    step = next((k for k in counters if "step_kernel" in k), None)
-    obs = next((k for k in counters if "observe_kernel" in k), None)
-    if step and "WRITE_SIZE" in counters[step]:
-        wcal = None
-        if obs and "WRITE_SIZE" in counters[obs]:
-            wcal = (4096 * 3072) / (counters[obs]["WRITE_SIZE"]["mean_per_launch"] * 1024)
-        wr = counters[step]["WRITE_SIZE"]["mean_per_launch"] * 1024
-        rd = counters[step].get("FETCH_SIZE", {"mean_per_launch": 0})["mean_per_launch"] * 1024
-        out["hbm_traffic_per_launch"] = {
-            "write_bytes_raw": wr, "write_calibration_factor": wcal, "fetch_bytes_raw": rd,
-            "fetch_bytes_x2_correction": 2 * rd, "traffic_bytes": (wr * (wcal or 1.0)) + 2 * rd,
-            "algorithmic_bytes": 4096 * 3348}
+    step = next((k for k in counters if dom in k and "M3Mode)5" not in k and ("M3Mode)0" in k or dom == "step_kernel")), None)
+    n = ENVS.get(w, 0)
+    if step:
+        c = counters[step]
+        if "WRITE_SIZE" in c:
+            # FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x
+            # on gfx950; WRITE_SIZE was calibrated in round 1 on observe_kernel (exactly 4096 * 3072 B written with the
+            # step kernel's store pattern): factor 1.00.
+            wr = c["WRITE_SIZE"]["mean_per_launch"] * 1024
+            rd = c.get("FETCH_SIZE", {"mean_per_launch": 0})["mean_per_launch"] * 1024
+            algo = bench.ALGO_BYTES[w] * n
+            out["hbm_traffic_per_launch"] = {"write_bytes": wr, "fetch_bytes_raw": rd, "fetch_bytes_x2_correction": 2 * rd,
+                                             "traffic_bytes": wr + 2 * rd, "algorithmic_bytes": algo,
+                                             "traffic_over_algorithmic": (wr + 2 * rd) / algo}
+        if "SQ_WAVES" in c:
+            waves = c["SQ_WAVES"]["mean_per_launch"]
+            out["occupancy"] = {"waves_per_launch": waves, "waves_per_cu": waves / 256.0}
+        if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] > 0:
+            out["lds"] = {"bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"],
+                          "lds_active_cycles": c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"],
+                          "bank_conflict_rate": c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"],
+                          "lds_instructions": c.get("SQ_INSTS_LDS", {}).get("mean_per_launch")}
+    return out
+
+
+def main(tag, outdir=None):
+    outdir = outdir or os.path.join(ROOT, "profiles")
+    os.makedirs(outdir, exist_ok=True)
+    out = {"tag": tag, "source": "rocprofv3 on python3 bench.py --workload W (BASELINE.json batch sizes, 1 MI355X); tools/profile_all.sh",
+           "workloads": {}, "hbm_traffic_per_launch_by_workload": {}}
+    stats_rows = []
+    for d in sorted(glob.glob(os.path.join(G, "prof_*_kt"))):
+        w = os.path.basename(d)[5:-3]
+        s = summarize(w, stats_rows)
+        out["workloads"][w] = s
+        if "hbm_traffic_per_launch" in s:
+            out["hbm_traffic_per_launch_by_workload"][f"{w}@{ENVS.get(w, 0)}"] = s["hbm_traffic_per_launch"]
+    if stats_rows:
+        with open(os.path.join(outdir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w_ = csv.DictWriter(f, fieldnames=["Workload"] + [k for k in stats_rows[0].keys() if k != "Workload"])
+            w_.writeheader()
+            for r in stats_rows:
+                w_.writerow(r)
     with open(os.path.join(outdir, f"{tag}_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps(out, indent=1)[:3000])
+    print(json.dumps(out, indent=1)[:6000])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else None)
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02", sys.argv[2] if len(sys.argv) > 2 else None)
