@@ -71,6 +71,7 @@ struct Params {
   int32_t *err;           // device error word
   EpAcc *ep_acc;          // [N] finished-episode totals (pcgrl_reduce_episodes)
   void *soko;             // SokoPool* (sokoban solver workspace), else null
+  void *m3cache;          // M3Slot[N][M3_SLOTS]: cached path-search results per start plane (3-D maze), else null
   // per-call I/O
   const int32_t *actions;
   uint8_t *obs;

@@ -411,9 +411,10 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
       return fail(PCGRL_EHIP, std::string(#x) + ": " + hipGetErrorString(_e));                       \
     }                                                                                                \
   } while (0)
-  if (is3d)
+  if (is3d) {
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * M3_MAXW * sizeof(uint32_t)));  // [tile bits | path overlay bits]
-  else
+    CREATE_CHK(dalloc(&p.m3cache, (size_t)n_envs * M3_SLOTS * sizeof(M3Slot)));      // all slots invalid
+  } else
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));

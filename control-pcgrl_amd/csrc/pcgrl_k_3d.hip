@@ -6,7 +6,7 @@
 hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
   switch (id) {
-    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP>), grid, block, 0, s, p, cpl); break;
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP>), grid, dim3(128), 0, s, p, cpl); break;  // simulate + observe wave
     case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET>), grid, block, 0, s, p, cpl); break;
     case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE>), grid, block, 0, s, p, cpl); break;
     case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE>), grid, block, 0, s, p, cpl); break;

@@ -1,19 +1,30 @@
-// pcgrl_kernels3d.h -- gfx950 kernels for minecraft_3D_maze (narrow representation), one wavefront per env.
+// pcgrl_kernels3d.h -- gfx950 kernels for minecraft_3D_maze (narrow representation).
 //
 // Reference (paths relative to control_pcgrl/): envs/probs/minecraft/minecraft_3D_maze_prob.py:143-181 get_stats,
 // :84-93 process_observation; envs/helper_3D.py: _passable :214-319, _flood_fill :354-383, calc_num_regions :396-406,
 // run_dijkstra :422-490, calc_longest_path :503-563, remove_stacked_path_tiles :657-675; envs/pcgrl_env.py:267-342.
 //
-// Lane roles inside the wavefront:
+// One workgroup per env.  pcgrl_step runs TWO specialised wavefronts over the env (like the 2-D step kernel):
+//   wave 0 "simulate"  action -> statistics (regions, path searches) -> reward / done -> auto-reset -> state write-back
+//   wave 1 "observe"   replays the (trivial) action / reset on its own copy and streams the observation, which shows the
+//                      path overlay of the PREVIOUS statistics update (pcgrl_env.py:298-299 vs :314-323), so it does
+//                      not depend on this step's searches.
+// Lane roles inside the simulate wave:
 //   lanes 0..Z-1   one z-plane each as a (Y*X)-bit mask: 6-neighbour flood fill = shifts by 1 / X inside the lane and a
 //                  DPP row_shr/row_shl between planes; start-candidate masks for the path search
-//   lanes 0..3     the four move directions of helper_3D._passable, evaluated together for each queue entry
-//   all 64 lanes   grid/overlay conversion, farthest-cell arg-max, path-overlay post-processing, reset RNG (LCG skip-ahead
-//                  per lane) and the observation (one 16-byte chunk = 4 cells x 4 one-hot channels per lane per store,
-//                  1 KiB contiguous per wave instruction)
-// The path search is the reference's FIFO label-correcting search and must keep its pop order (tie-breaks decide
-// n_jump, the farthest cell and the path drawn into the next observation), so its queue, the per-cell best-entry table
-// and the first-insertion order list live in LDS and one entry is popped per iteration.
+//   lane 4*i + d   move direction d of queue entry i of the current trip of the path search (16 entries per trip)
+//   all 64 lanes   farthest-cell arg-max, overlay post-processing, reset RNG (LCG skip-ahead per lane)
+//
+// PATH SEARCH.  helper_3D.run_dijkstra is a FIFO label-correcting search whose pop order decides n_jump, the farthest
+// cell and the path drawn into the next observation, so the queue order is kept exactly (see m3_search).
+//
+// SLOT CACHE.  calc_longest_path (:503-563) starts one pair of searches per start candidate, and its whole-plane visited
+// marking (:531) leaves at most ONE processed candidate per z-plane: the first candidate of the plane in (y, x) order.
+// Everything a plane's pair of searches produces -- the marks, max_dist, n_jump, the path tiles -- is a function of the
+// cells the searches READ.  The engine keeps, per env and plane, that result together with the read set (per column:
+// the z range the move rules looked at, a superset) in HBM.  A step edits one cell: slots whose read set contains it are
+// dropped, every other slot is still exact, and the sequential candidate walk re-runs only the searches it actually
+// needs.  Under random edits most steps re-run no or one pair instead of all of them.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,16 +37,36 @@ constexpr int M3_MAXCELLS = 512;
 constexpr int M3_MAXW = M3_MAXCELLS / 32;  // bit words
 constexpr int M3_ENT_CAP = 1536;           // queue entries per search (LDS)
 constexpr int M3_NS = 3;
+constexpr int M3_SLOTS = 6;                // start planes z = 1 .. Z-2 (Z <= 8)
+
+// cached result of one start plane (see SLOT CACHE)
+struct alignas(8) M3Slot {
+  uint8_t start;   // bit index (y*X + x) of the start cell in its plane
+  uint8_t valid;
+  uint16_t max_dist;
+  uint16_t n_jump;
+  uint16_t mk;     // z-planes marked visited by the first search (the fancy-index bug, :531)
+  uint32_t rs[16];          // read set: byte q = z bits of column q = y*X + x the searches depended on
+  uint32_t pathm[M3_MAXW];  // tiles of paths[farthest] of the second search
+};
+static_assert(sizeof(M3Slot) == 136, "slot layout");
+constexpr int M3_SLOT_WORDS = (int)(sizeof(M3Slot) / 4) * M3_SLOTS;
 
 struct M3Lds {
-  uint4 ent[M3_ENT_CAP];        // x | y<<8 | z<<16 | kind<<24 ; len | njump<<16 ; parent ; unused
-  uint32_t best[M3_MAXCELLS];   // per cell: len << 16 | accepted entry id (the `paths` dict), 0xFFFFFFFF = none
+  uint2 ent[M3_ENT_CAP];        // cell | kind<<9 | njump<<12 | parent<<20 ; len
+  uint32_t best[M3_MAXCELLS];   // per cell: epoch<<24 | len<<12 | accepted entry id (the `paths` dict of the current search)
   uint16_t order[M3_MAXCELLS];  // cells in first-insertion order
-  uint32_t claim[M3_MAXCELLS];  // scratch of m3_search: lowest batch slot that wants to accept a cell (0xFFFFFFFF = none)
+  uint32_t claim[M3_MAXCELLS];  // scratch of m3_search: lowest trip slot popping a cell (0xFFFFFFFF between trips)
   uint32_t dirt[M3_MAXW + 2];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
   uint32_t pathm[M3_MAXW + 2];  // tiles of the best path
   uint32_t over[M3_MAXW + 2];   // overlay mask (transposed index) for the observation
   uint8_t col[64];              // per (y,x): AIR bits over z
+  M3Slot slot[M3_SLOTS];
+  uint32_t epoch;               // current search id in `best`
+};
+struct M3ObsLds {  // the observe wave's own copy
+  uint32_t dirt[M3_MAXW + 2];
+  uint32_t over[M3_MAXW + 2];
 };
 
 struct M3Ctx {
@@ -43,16 +74,17 @@ struct M3Ctx {
 };
 
 enum { M3_WALK = 0, M3_DOWN = 1, M3_UP = 2, M3_JFLAT = 3, M3_JUP = 4, M3_JDOWN = 5, M3_ROOT = 6 };
+constexpr uint32_t M3_NOPARENT = 0xFFFu;
 
-__device__ inline bool m3_dirt(const M3Lds &L, int cell) { return (L.dirt[cell >> 5] >> (cell & 31)) & 1u; }
+__device__ inline bool m3_bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 
 // (Y*X)-bit AIR mask of plane z from the flat bit string
-__device__ inline uint64_t m3_plane_air(const M3Lds &L, const M3Ctx &c, int z) {
+__device__ inline uint64_t m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int z) {
   const int pbits = c.Y * c.X, b0 = z * pbits;
   const int w = b0 >> 5, s = b0 & 31;
-  uint64_t lo = (uint64_t)L.dirt[w] | ((uint64_t)L.dirt[w + 1] << 32);
+  uint64_t lo = (uint64_t)dirt[w] | ((uint64_t)dirt[w + 1] << 32);
   uint64_t v = lo >> s;
-  if (s) v |= (uint64_t)L.dirt[w + 2] << (64 - s);
+  if (s) v |= (uint64_t)dirt[w + 2] << (64 - s);
   const uint64_t pm = pbits >= 64 ? ~0ull : ((1ull << pbits) - 1ull);
   return ~v & pm;
 }
@@ -66,6 +98,24 @@ __device__ inline uint64_t dpp64_down(uint64_t v) {  // from lane+1
   uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x101, 0xF, 0xF, true);
   uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x101, 0xF, 0xF, true);
   return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// maximum over the 64 lanes, result in every lane: DPP butterfly inside the 16-lane rows, then across rows
+__device__ inline uint32_t wave_max(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
+  v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+  v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+  return v;
+}
+// OR over the 64 lanes of a value with at most 8 significant bits
+__device__ inline uint32_t wave_or8(uint32_t v) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int b = 0; b < 8; b++) r |= (__ballot((v >> b) & 1u) != 0 ? 1u : 0u) << b;
+  return r;
 }
 
 // helper_3D.py:396-406 calc_num_regions (6-neighbour components of AIR)
@@ -83,9 +133,11 @@ __device__ inline int m3_regions(const M3Ctx &c, uint64_t air) {
     if (b == 0) break;
     int fl = __builtin_ctzll(b);
     uint64_t f = c.lane == fl ? (remaining & (0ull - remaining)) : 0ull;
-    while (true) {
+    while (true) {  // two expansion rounds per trip (one ballot per two rounds)
       uint64_t d = ((f & notxl) << 1) | ((f & notx0) >> 1) | (f << c.X) | (f >> c.X) | dpp64_up(f) | dpp64_down(f);
-      uint64_t nf = d & remaining & ~f;
+      f |= d & remaining;
+      d = ((f & notxl) << 1) | ((f & notx0) >> 1) | (f << c.X) | (f >> c.X) | dpp64_up(f) | dpp64_down(f);
+      const uint64_t nf = d & remaining & ~f;
       if (__ballot(nf != 0) == 0) break;
       f |= nf;
     }
@@ -97,98 +149,122 @@ __device__ inline int m3_regions(const M3Ctx &c, uint64_t air) {
 
 __device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
 
-// One search of helper_3D.run_dijkstra from (sx,sy,sz).  Uniform over the wave; returns number of entries.
-// On overflow of the LDS queue sets *overflow.
+// One search of helper_3D.run_dijkstra from (sx,sy,sz).  Uniform over the wave; returns the number of queue entries.
+// On overflow of the LDS queue sets `overflow`.
 //
 // The reference pops one queue entry at a time.  Here up to 16 consecutive entries are taken per trip, lane 4*i + d
 // working on direction d of entry i, which is exact because:
-//   * whether entry i is accepted (:437-445) depends on earlier entries only through `best` of ITS OWN cell, so a trip is
-//     cut before the second accept candidate of one cell (slots are claimed with an LDS atomic-min; rare);
-//   * a successor is queued unless it would be a no-op when popped (cell without head-room, or `best` of its cell not
-//     longer).  `best` only ever decreases and every entry of this trip is popped before anything queued now, so testing
-//     against `best` AFTER the whole trip's accepts drops exactly entries the sequential run would reject later;
+//   * whether entry i is accepted (:437-445) depends on earlier entries only through `best` of ITS OWN cell.  Every
+//     popped entry registers its trip slot for its cell (an LDS min issued BEFORE the reads of the trip, so one round trip
+//     returns `best`, the columns and the first slot of the cell together); the trip is cut before an accept candidate
+//     that is not the first entry of its cell in the trip (rare), which then runs first in the next trip;
+//   * a successor is queued unless it is known to be a no-op when popped (cell without head-room, or `best` of its cell --
+//     as read at the start of the trip: `best` only decreases -- not longer).  Entries that turn out to be no-ops later are
+//     rejected when popped, like in the reference;
 //   * first-visit order and queue order are kept with prefix counts over the lanes (entry-major, direction-minor).
-__device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, bool &overflow) {
+// `best` entries carry the search's epoch, so nothing is cleared between searches.
+// mk: coordinate values of all reached cells (bit v set if some reached cell has x, y or z == v);  rs: read set (per
+// column byte: z bits) accumulated for the slot cache.
+__device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, uint32_t &mk, uint32_t *rs,
+                                bool &overflow) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
-  for (int i = c.lane; i < c.n_cells; i += 64) {
-    L.best[i] = NONE;
-    L.claim[i] = NONE;
+  uint32_t epoch = L.epoch + 1;  // (uniform: every lane reads the same word)
+  if (epoch > 255u) {            // wrapped: clear the table once
+    for (int i = c.lane; i < c.n_cells; i += 64) L.best[i] = 0;
+    epoch = 1;
   }
-  if (c.lane == 0) L.ent[0] = make_uint4((uint32_t)sx | ((uint32_t)sy << 8) | ((uint32_t)sz << 16) | ((uint32_t)M3_ROOT << 24), 1u, NONE, 0u);
+  if (c.lane == 0) {
+    L.epoch = epoch;
+    L.ent[0] = make_uint2((uint32_t)m3_cell(c, sx, sy, sz) | ((uint32_t)M3_ROOT << 9) | (M3_NOPARENT << 20), 1u);
+  }
   int head = 0, tail = 1;
   n_order = 0;
-  const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};  // helper_3D.py:220
   const int slot_i = c.lane >> 2, d = c.lane & 3;
-  const int dxl = DX[d], dyl = DY[d];
+  const int dxl = d == 0 ? 1 : (d == 2 ? -1 : 0), dyl = d == 1 ? 1 : (d == 3 ? -1 : 0);  // helper_3D.py:220
   const uint64_t lt = (1ull << c.lane) - 1ull;
+  const int YX = c.Y * c.X;
+  uint32_t mkl = 0;
   while (head < tail) {
     const int nb = min(16, tail - head);
     const bool live = slot_i < nb;
     const int id = head + (live ? slot_i : 0);
-    const uint4 e = L.ent[id];
-    const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255;
-    const int len = e.y & 0xFFFF, nj = e.y >> 16;
-    const int ci = m3_cell(c, x, y, z);
-    // everything that depends only on the entry is requested in one LDS round trip: its cell's `best`, its column and
-    // the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map)
+    const uint2 e = L.ent[id];
+    const int ci = e.x & 511, nj = (e.x >> 12) & 255, len = (int)e.y;
+    const int z = ci / YX, r0 = ci - z * YX, y = r0 / c.X, x = r0 - y * c.X;
+    if (live && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
+    // everything that depends only on the entry comes back in one LDS round trip: `best` and first slot of its cell, its
+    // column, the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map) and
+    // `best` of the six cells this lane could move to
     const int nx = x + dxl, ny = y + dyl, jx = x + 2 * dxl, jy = y + 2 * dyl;
     const bool n_in = nx >= 0 && ny >= 0 && nx < c.X && ny < c.Y, j_in = jx >= 0 && jy >= 0 && jx < c.X && jy < c.Y;
+    const int qn = n_in ? ny * c.X + nx : 0, qj = j_in ? jy * c.X + jx : 0, qc = y * c.X + x;
     const uint32_t b = L.best[ci];
-    const uint32_t cc = L.col[y * c.X + x];
-    const uint32_t cn = L.col[n_in ? ny * c.X + nx : 0];
-    const uint32_t cj = L.col[j_in ? jy * c.X + jx : 0];
-    bool accept = live;
-    if (b != NONE && (int)(b >> 16) <= len) accept = false;                     // :437-440
-    if (z + 1 == c.Z || !((cc >> (z + 1)) & 1u)) accept = false;                // :443-445 no head-room
-    // cut the trip before the second accept candidate of one cell (nothing to check for a single entry)
-    int nproc = nb;
-    if (nb > 1) {
-      if (accept && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
-      const bool dup = accept && L.claim[ci] != (uint32_t)slot_i;
-      const uint64_t dupb = __ballot(dup);
-      if (dupb) nproc = __builtin_ctzll(dupb) >> 2;  // >= 1: slot 0 always owns its cell
-      if (accept && d == 0) L.claim[ci] = NONE;
+    const uint32_t first_slot = L.claim[ci];
+    const uint32_t cc = L.col[qc], cn = L.col[qn], cj = L.col[qj];
+    uint32_t bn[3], bj[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int tz = min(max(z - 1 + k, 0), c.Z - 1);
+      bn[k] = L.best[tz * YX + qn];
+      bj[k] = L.best[tz * YX + qj];
     }
+    const bool seen = (b >> 24) == epoch;
+    bool accept = live;
+    if (seen && (int)((b >> 12) & 0xFFFu) <= len) accept = false;                 // :437-440
+    if (z + 1 == c.Z || !((cc >> (z + 1)) & 1u)) accept = false;                  // :443-445 no head-room
+    // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
+    const uint64_t dupb = __ballot(accept && d == 0 && first_slot != (uint32_t)slot_i);
+    const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
+    if (live && d == 0) L.claim[ci] = NONE;
     const bool doit = accept && slot_i < nproc;
-    const bool first = doit && d == 0 && b == NONE;
+    const bool first = doit && d == 0 && !seen;
     const uint64_t fb = __ballot(first);
     if (first) L.order[n_order + __popcll(fb & lt)] = (uint16_t)ci;
     n_order += __popcll(fb);
-    if (doit && d == 0) L.best[ci] = ((uint32_t)len << 16) | (uint32_t)id;
+    if (doit && d == 0) {
+      L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
+      mkl |= (x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z);
+    }
     // successors: direction d of entry slot_i (helper_3D.py:214-319)
     bool ok = false;
-    int tx = 0, ty = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
+    int tq = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
     uint32_t ct = 0;  // column mask of the target cell
     if (doit) {
+      // read set: the z window the move rules can look at, in this entry's column, the neighbour's and the landing's
+      const uint32_t zwin = ((0x3Fu << (z + 6)) >> 8) & ((1u << c.Z) - 1u);  // bits z-2 .. z+3
+      if (d == 0) atomicOr(&rs[qc >> 2], zwin << ((qc & 3) * 8));
+      if (n_in) atomicOr(&rs[qn >> 2], zwin << ((qn & 3) * 8));
+      if (j_in) atomicOr(&rs[qj >> 2], zwin << ((qj & 3) * 8));
       const int nz = z;
       if (n_in) {
         ct = cn;
         auto A = [&](uint32_t col, int k) -> bool { return (col >> k) & 1u; };
         if ((nz == 0 || !A(cn, nz - 1)) && A(cn, nz) && A(cn, nz + 1)) {
-          ok = true; tx = nx; ty = ny; tz = nz; kind = M3_WALK; add = 1;
+          ok = true; tq = qn; tz = nz; kind = M3_WALK; add = 1;
         } else if (nz >= 1 && (nz - 1 == 0 || !A(cn, nz - 2)) && A(cn, nz - 1) && A(cn, nz) && A(cn, nz + 1)) {
-          ok = true; tx = nx; ty = ny; tz = nz - 1; kind = M3_DOWN; add = 2;
+          ok = true; tq = qn; tz = nz - 1; kind = M3_DOWN; add = 2;
         } else if (nz + 2 < c.Z && !A(cn, nz) && A(cn, nz + 1) && A(cn, nz + 2) && A(cc, nz + 2)) {
-          ok = true; tx = nx; ty = ny; tz = nz + 1; kind = M3_UP; add = 2;
+          ok = true; tq = qn; tz = nz + 1; kind = M3_UP; add = 2;
         } else if (nz - 2 >= 0 && nz + 2 < c.Z && A(cn, nz + 2) && A(cn, nz + 1) && A(cn, nz) && A(cn, nz - 1) && A(cn, nz - 2) &&
                    A(cc, nz + 2) && j_in) {
           ct = cj;
           const int jz = z;
           if (A(cj, jz + 1) && A(cj, jz + 2) && A(cj, jz) && !A(cj, jz - 1)) {
-            ok = true; tx = jx; ty = jy; tz = jz; kind = M3_JFLAT; add = 2; nj2 = nj + 1;
+            ok = true; tq = qj; tz = jz; kind = M3_JFLAT; add = 2; nj2 = nj + 1;
           } else if (jz + 3 < c.Z && A(cj, jz + 3) && A(cj, jz + 2) && A(cj, jz + 1) && !A(cj, jz)) {
-            ok = true; tx = jx; ty = jy; tz = jz + 1; kind = M3_JUP; add = 3; nj2 = nj + 1;
+            ok = true; tq = qj; tz = jz + 1; kind = M3_JUP; add = 3; nj2 = nj + 1;
           } else if (A(cj, jz) && A(cj, jz + 1) && A(cj, jz - 1) && !A(cj, jz - 2)) {
-            ok = true; tx = jx; ty = jy; tz = jz - 1; kind = M3_JDOWN; add = 3; nj2 = nj + 1;
+            ok = true; tq = qj; tz = jz - 1; kind = M3_JDOWN; add = 3; nj2 = nj + 1;
           }
         }
       }
     }
-    if (ok) {  // never queue what would be a no-op when popped
+    if (ok) {  // never queue what is known to be a no-op when popped
       if (tz + 1 == c.Z || !((ct >> (tz + 1)) & 1u)) ok = false;
       if (ok) {
-        const uint32_t bt = L.best[m3_cell(c, tx, ty, tz)];
-        if (bt != NONE && (int)(bt >> 16) <= len + add) ok = false;
+        const int k = tz - (z - 1);  // 0 .. 2
+        const uint32_t bt = kind >= M3_JFLAT ? (k == 0 ? bj[0] : (k == 1 ? bj[1] : bj[2])) : (k == 0 ? bn[0] : (k == 1 ? bn[1] : bn[2]));
+        if ((bt >> 24) == epoch && (int)((bt >> 12) & 0xFFFu) <= len + add) ok = false;
       }
     }
     const uint64_t okb = __ballot(ok);
@@ -198,11 +274,12 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
       break;
     }
     if (ok)
-      L.ent[tail + __popcll(okb & lt)] = make_uint4((uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)tz << 16) | ((uint32_t)kind << 24),
-                                                    (uint32_t)(len + add) | ((uint32_t)nj2 << 16), (uint32_t)id, 0u);
+      L.ent[tail + __popcll(okb & lt)] = make_uint2((uint32_t)(tz * YX + tq) | ((uint32_t)kind << 9) | ((uint32_t)nj2 << 12) | ((uint32_t)id << 20),
+                                                    (uint32_t)(len + add));
     tail += npush;
     head += nproc;
   }
+  mk = wave_or8(mkl);
   return tail;
 }
 
@@ -210,116 +287,123 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
 __device__ inline int m3_farthest(const M3Lds &L, const M3Ctx &c, int n_order, int &entry) {
   uint32_t key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
   for (int k = c.lane; k < n_order; k += 64) {
-    uint32_t len = L.best[L.order[k]] >> 16;
-    uint32_t kk = (len << 16) | (uint32_t)(0xFFFF - k);
+    const uint32_t len = (L.best[L.order[k]] >> 12) & 0xFFFu;
+    const uint32_t kk = (len << 16) | (uint32_t)(0xFFFF - k);
     key = kk > key ? kk : key;
   }
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t other = (uint32_t)__shfl_xor((int)key, o, 64);
-    key = other > key ? other : key;
-  }
+  key = wave_max(key);
   const int k = 0xFFFF - (int)(key & 0xFFFF);
   const int cell = L.order[k];
-  entry = (int)(L.best[cell] & 0xFFFFu);
+  entry = (int)(L.best[cell] & 0xFFFu);
   return cell;
+}
+
+// The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s (result + read set).
+__device__ inline void m3_fill_slot(M3Lds &L, const M3Ctx &c, int s, int sx, int sy, int sz, bool &overflow) {
+  M3Slot &S = L.slot[s];
+  for (int i = c.lane; i < 16 + M3_MAXW; i += 64) (i < 16 ? S.rs[i] : S.pathm[i - 16]) = 0;
+  if (c.lane == 0) S.valid = 0;
+  int n_order = 0, e1 = 0, e2 = 0;
+  uint32_t mk = 0, mk2 = 0;
+  m3_search(L, c, sx, sy, sz, n_order, mk, S.rs, overflow);
+  if (overflow) return;
+  const int YX = c.Y * c.X;
+  const int far = m3_farthest(L, c, n_order, e1);
+  const int fz = far / YX, fr = far - fz * YX, fy = fr / c.X, fx = fr - fy * c.X;
+  m3_search(L, c, fx, fy, fz, n_order, mk2, S.rs, overflow);
+  if (overflow) return;
+  (void)m3_farthest(L, c, n_order, e2);
+  if (c.lane == 0) {
+    const uint2 fe = L.ent[e2];
+    S.start = (uint8_t)(sy * c.X + sx);
+    S.valid = 1;
+    S.max_dist = (uint16_t)fe.y;
+    S.n_jump = (uint16_t)((fe.x >> 12) & 255u);
+    S.mk = (uint16_t)(mk & ((1u << c.Z) - 1u));
+    // materialise the tiles of paths[(mx,my,mz)] into a bit mask (walk the parent chain)
+    int id = e2;
+    while (true) {
+      const uint2 e = L.ent[id];
+      const int ci = e.x & 511, kind = (e.x >> 9) & 7, par = (int)(e.x >> 20);
+      auto mark = [&](int cell) { S.pathm[cell >> 5] |= 1u << (cell & 31); };
+      mark(ci);
+      if (kind == M3_ROOT) break;
+      const int pc = L.ent[par].x & 511;
+      // intermediate tiles of the move (helper_3D.py:214-319) in cell-index arithmetic: +-YX = one plane up / down,
+      // `mid` = the jumped-over column at the parent's height
+      const int pz = pc / YX, z = ci / YX;
+      const int mid = ((pc - pz * YX) + (ci - z * YX)) / 2 + pz * YX;
+      switch (kind) {
+        case M3_DOWN: mark(ci + YX); break;                   // (nx, ny, nz): the target column at the parent's height
+        case M3_UP: mark(pc + YX); break;                     // (x, y, nz+1)
+        case M3_JFLAT: mark(mid); break;                      // (nx, ny, nz)
+        case M3_JUP: mark(mid); mark(mid + YX); break;        // (nx,ny,nz), (nx,ny,nz+1)
+        case M3_JDOWN: mark(mid); mark(mid - YX); break;      // (nx,ny,nz), (nx,ny,nz-1)
+        default: break;
+      }
+      id = par;
+    }
+  }
 }
 
 // helper_3D.calc_longest_path + remove_stacked_path_tiles + minecraft_3D_maze_prob.get_stats
 // air: this lane's plane (lanes < Z).  Results uniform over the wave.  L.over receives the new overlay mask.
-__device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t *st, bool &overflow PHASE_ARG) {
-  // per-(y,x) column masks for the move rules
-  if (c.lane < 64) {
-    for (int q = c.lane; q < c.Y * c.X; q += 64) {
-      uint32_t m = 0;
-      for (int z = 0; z < c.Z; z++) m |= (uint32_t)(!m3_dirt(L, z * c.Y * c.X + q)) << z;
-      L.col[q] = (uint8_t)m;
+// Slots that are still valid (see SLOT CACHE) are reused; pass fresh = true to ignore them (reset, caller-provided maps).
+__device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t *st, bool &overflow, bool fresh PHASE_ARG) {
+  const int YX = c.Y * c.X;
+  // per-(y,x) column masks for the move rules: lane q collects bit q of every plane
+  {
+    uint32_t m = 0;
+#pragma unroll
+    for (int z = 0; z < 8; z++) {
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)air, z, 64), hi = (uint32_t)__shfl((int)(uint32_t)(air >> 32), z, 64);
+      const uint64_t a = (uint64_t)lo | ((uint64_t)hi << 32);
+      if (z < c.Z) m |= (uint32_t)((a >> (c.lane & 63)) & 1ull) << z;
     }
+    L.col[c.lane] = c.lane < YX ? (uint8_t)m : (uint8_t)0;
   }
+  if (fresh && c.lane < M3_SLOTS) L.slot[c.lane].valid = 0;
   PHASE_MARK(2);  // column masks
   st[0] = m3_regions(c, air);
   PHASE_MARK(3);  // regions
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
   const uint64_t above = dpp64_down(air), below = dpp64_up(air);
-  uint64_t cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : 0ull;
+  const uint64_t cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : 0ull;
   uint32_t marked = 0;  // z-planes of final_visited_map that are fully set (the fancy-index bug, :531)
-  int final_value = 0, n_jump = 0;
-  for (int i = c.lane; i < c.nw + 2; i += 64) {
-    L.pathm[i] = 0;
-    L.over[i] = 0;
-  }
+  int final_value = 0, n_jump = 0, best_slot = -1;
   while (true) {
     const bool mine = c.lane < c.Z && cand != 0 && !((marked >> c.lane) & 1u);
     const uint64_t b = __ballot(mine);
     if (b == 0) break;
     const int sz = __builtin_ctzll(b);
     const int bit = (int)__shfl((int)__builtin_ctzll(cand | (1ull << 63)), sz, 64);
-    const int sy = bit / c.X, sx = bit - sy * c.X;
-    int n_order = 0, e1 = 0, e2 = 0;
-    m3_search(L, c, sx, sy, sz, n_order, overflow);
-    if (overflow) break;
-    // mark planes z = v for every coordinate value v of every reached cell
-    uint32_t mk = 0;
-    for (int k = c.lane; k < n_order; k += 64) {
-      int ci = L.order[k];
-      int x = ci % c.X, y = (ci / c.X) % c.Y, z = ci / (c.X * c.Y);
-      mk |= (1u << x) | (1u << y) | (1u << z);
+    const int s = sz - 1;
+    const M3Slot &S = L.slot[s];
+    if (!(S.valid && S.start == bit)) {
+      const int sy = bit / c.X, sx = bit - sy * c.X;
+      m3_fill_slot(L, c, s, sx, sy, sz, overflow);
+      if (overflow) break;
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) mk |= (uint32_t)__shfl_xor((int)mk, o, 64);
-    marked |= mk & ((1u << c.Z) - 1u);
-    const int far = m3_farthest(L, c, n_order, e1);
-    const int fx = far % c.X, fy = (far / c.X) % c.Y, fz = far / (c.X * c.Y);
-    m3_search(L, c, fx, fy, fz, n_order, overflow);
-    if (overflow) break;
-    (void)m3_farthest(L, c, n_order, e2);
-    const uint4 fe = L.ent[e2];
-    const int max_dist = fe.y & 0xFFFF;
-    n_jump = fe.y >> 16;  // :553 overwritten by every processed component
-    if (max_dist > final_value) {
-      final_value = max_dist;
-      // materialise the tiles of paths[(mx,my,mz)] into a bit mask (lane 0 walks the parent chain)
-      for (int i = c.lane; i < c.nw + 2; i += 64) L.pathm[i] = 0;
-      if (c.lane == 0) {
-        int id = e2;
-        while (true) {
-          const uint4 e = L.ent[id];
-          const int x = e.x & 255, y = (e.x >> 8) & 255, z = (e.x >> 16) & 255, kind = e.x >> 24;
-          auto mark = [&](int mx, int my, int mz) {
-            int ci = m3_cell(c, mx, my, mz);
-            L.pathm[ci >> 5] |= 1u << (ci & 31);
-          };
-          mark(x, y, z);
-          if (kind == M3_ROOT) break;
-          const uint4 pe = L.ent[e.z];
-          const int px = pe.x & 255, py = (pe.x >> 8) & 255, pz = (pe.x >> 16) & 255;
-          const int mxx = (px + x) >> 1, myy = (py + y) >> 1;  // the jumped-over column
-          switch (kind) {
-            case M3_DOWN: mark(x, y, pz); break;                              // [(nx, ny, nz)]
-            case M3_UP: mark(px, py, pz + 1); break;                          // [(x, y, nz+1)]
-            case M3_JFLAT: mark(mxx, myy, pz); break;                         // [(nx, ny, nz)]
-            case M3_JUP: mark(mxx, myy, pz); mark(mxx, myy, pz + 1); break;   // [(nx,ny,nz), (nx,ny,nz+1)]
-            case M3_JDOWN: mark(mxx, myy, pz); mark(mxx, myy, pz - 1); break; // [(nx,ny,nz), (nx,ny,nz-1)]
-            default: break;
-          }
-          id = (int)e.z;
-        }
-      }
+    marked |= S.mk;
+    n_jump = S.n_jump;  // :553 overwritten by every processed component
+    if ((int)S.max_dist > final_value) {
+      final_value = S.max_dist;
+      best_slot = s;
     }
   }
   PHASE_MARK(4);  // path searches
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
   // path tile (x,y,z) is drawn at array index [x][y][z]
-  const int pbits = c.Y * c.X;
+  for (int i = c.lane; i < c.nw + 2; i += 64) {
+    L.pathm[i] = (best_slot >= 0 && i < M3_MAXW) ? L.slot[best_slot < 0 ? 0 : best_slot].pathm[i] : 0u;
+    L.over[i] = 0;
+  }
   for (int ci = c.lane; ci < c.n_cells; ci += 64) {
-    bool in = (L.pathm[ci >> 5] >> (ci & 31)) & 1u;
-    if (in && ci >= pbits) {
-      int lo = ci - pbits;
-      if ((L.pathm[lo >> 5] >> (lo & 31)) & 1u) in = false;
-    }
+    bool in = m3_bit(L.pathm, ci);
+    if (in && ci >= YX && m3_bit(L.pathm, ci - YX)) in = false;
     if (in) {
-      int x = ci % c.X, y = (ci / c.X) % c.Y, z = ci / pbits;
-      int oi = (x * c.Y + y) * c.X + z;
+      const int z = ci / YX, r = ci - z * YX, y = r / c.X, x = r - y * c.X;
+      const int oi = (x * c.Y + y) * c.X + z;
       if (x < c.Z && y < c.Y && z < c.X) atomicOr(&L.over[oi >> 5], 1u << (oi & 31));
     }
   }
@@ -329,8 +413,8 @@ __device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t 
 }
 
 // observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay
-__device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Params &p, int env, const int *pos, bool show_path,
-                                     uint8_t *obs_base = nullptr) {
+__device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over, const M3Ctx &c, const Params &p, int env, const int *pos,
+                                     bool show_path, uint8_t *obs_base = nullptr) {
   if (p.obs == nullptr) return;
   if (obs_base == nullptr) obs_base = p.obs;
   const int o0 = p.cfg.obs_window[0], o1 = p.cfg.obs_window[1], o2 = p.cfg.obs_window[2];
@@ -353,8 +437,8 @@ __device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Param
       int v = 0;
       if ((unsigned)a < (unsigned)c.Z && (unsigned)b < (unsigned)c.Y && (unsigned)d < (unsigned)c.X) {
         const int ci = (a * c.Y + b) * c.X + d;
-        v = 1 + (int)m3_dirt(L, ci);
-        if (show_path && ((L.over[ci >> 5] >> (ci & 31)) & 1u)) v = 3;
+        v = 1 + (int)m3_bit(dirt, ci);
+        if (show_path && m3_bit(over, ci)) v = 3;
       }
       w[t] = 1u << (8 * v);
       if (++k == o2) {  // raster order carry
@@ -369,19 +453,16 @@ __device__ inline void m3_encode_obs(const M3Lds &L, const M3Ctx &c, const Param
   }
 }
 
-// reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order)
-__device__ inline void m3_reset_rng(M3Lds &L, const M3Ctx &c, const Params &p, int env, int cpl) {
-  Pcg rp, rr;
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // rollout kernel: the state stored by lane 0 at the previous reset of this wave
-  rp.load(p.rng[env].prob);
-  rr.load(p.rng[env].rep);
+// reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order) into `dirt`.
+// rp / rr: the env's streams (in registers); advanced.
+__device__ inline void m3_reset_rng(uint32_t *dirt, const M3Ctx &c, const Params &p, int cpl, Pcg &rp, Pcg &rr) {
   double p0 = rp.next_double(), p1 = rp.next_double();
   double total = 0.0;
   total += p0;
   total += p1;
   double c0 = p0 / total, c1 = c0 + p1 / total;
   c0 /= c1;  // cdf /= cdf[-1]
-  for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
+  for (int i = c.lane; i < c.nw + 2; i += 64) dirt[i] = 0;
   Pcg end = rr;
   end.jump(p.jump[64]);
   rr.jump(p.jump[c.lane]);
@@ -397,21 +478,35 @@ __device__ inline void m3_reset_rng(M3Lds &L, const M3Ctx &c, const Params &p, i
   }
   for (int k = 0; k < cpl; k++) {
     int ci = first + k;
-    if (ci < c.n_cells && ((bits >> k) & 1u)) atomicOr(&L.dirt[ci >> 5], 1u << (ci & 31));
+    if (ci < c.n_cells && ((bits >> k) & 1u)) atomicOr(&dirt[ci >> 5], 1u << (ci & 31));
   }
-  if (c.lane == 0) {
-    end.store(p.rng[env].rep);
-    rp.store(p.rng[env].prob);
-  }
-  __atomic_thread_fence(__ATOMIC_RELEASE);
+  rr = end;
 }
 
-// M3_ROLLOUT: pcgrl_rollout, p.n_steps steps per launch with the env state in LDS / registers (see rollout_kernel)
+// bytes -> bit string (caller-provided maps)
+__device__ inline void m3_load_bytes(uint32_t *dirt, const M3Ctx &c, const uint8_t *src) {
+  for (int i = c.lane; i < c.nw + 2; i += 64) dirt[i] = 0;
+  for (int ci = c.lane; ci < c.n_cells; ci += 64)
+    if (src[ci]) atomicOr(&dirt[ci >> 5], 1u << (ci & 31));
+}
+
+// M3_ROLLOUT: pcgrl_rollout, p.n_steps steps per launch with the env state in LDS / registers (one wave does both roles)
 enum M3Mode { M3_STEP = 0, M3_RESET = 1, M3_OBSERVE = 2, M3_STATS_FOR_GRIDS = 3, M3_GET_STATE = 4, M3_ROLLOUT = 5 };
 
+// narrow_rep.py:89-102 with Q1 (position of the NEXT edit from the pre-increment counter)
+__device__ inline void m3_advance_pos(const M3Ctx &c, int *pos, int &n_step) {
+  const int YX = c.Y * c.X;
+  const int idx = n_step % c.n_cells;
+  pos[0] = idx / YX;
+  pos[1] = (idx / c.X) % c.Y;
+  pos[2] = idx % c.X;
+  n_step++;
+}
+
 template <int MODE>
-__global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
+__global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p, int cpl) {
   __shared__ M3Lds L;
+  __shared__ M3ObsLds O;
   M3Ctx c;
   c.lane = (int)__lane_id();
   c.Z = p.cfg.dims[0];
@@ -424,17 +519,62 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
   PHASE_DECL();
   TRACE_DECL();
   uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * M3_MAXW;  // [dirt words | overlay words]
+  uint32_t *gslot = (uint32_t *)p.m3cache + (size_t)env * M3_SLOT_WORDS;
   EnvState *S = &p.st[env];
 
+  if constexpr (MODE == M3_STEP) {
+    // ------------------------------------------------------------------------------------------ observe wave
+    if (threadIdx.x >= 64) {
+      if (p.obs == nullptr) return;  // (the simulate wave skips the barrier in that case, too)
+      for (int i = c.lane; i < c.nw + 2; i += 64) {
+        O.dirt[i] = i < c.nw ? gd[i] : 0u;
+        O.over[i] = i < c.nw ? gd[M3_MAXW + i] : 0u;
+      }
+      int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
+      int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
+      const int action = p.actions[env];
+      const bool upd_only = p.update_only != 0;
+      // an auto-reset replays the env's RNG streams in both waves; this wave takes its copy before the barrier
+      Pcg rp, rr;
+      if (p.auto_reset != 0 && (iteration + 1 > p.cfg.max_iterations || p.cfg.max_changes >= 0)) {
+        rp.load(p.rng[env].prob);
+        rr.load(p.rng[env].rep);
+      }
+      __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
+      iteration += upd_only ? 0 : 1;
+      bool change = false;
+      if (action >= 0 && action < 2) {
+        const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
+        change = m3_bit(O.dirt, ci) != (action != 0);
+        if (change && c.lane == 0) O.dirt[ci >> 5] ^= 1u << (ci & 31);
+        m3_advance_pos(c, pos, n_step);
+      }
+      changes += (change && !upd_only) ? 1 : 0;
+      bool done = !upd_only && iteration > p.cfg.max_iterations;
+      if (p.cfg.max_changes >= 0) done = done || (!upd_only && changes > p.cfg.max_changes);
+      if (done && p.auto_reset != 0) {  // first observation of the new episode: no overlay (PcgrlEnv.reset)
+        m3_reset_rng(O.dirt, c, p, cpl, rp, rr);
+        pos[0] = pos[1] = pos[2] = 0;
+        m3_encode_obs(O.dirt, O.over, c, p, env, pos, false);
+      } else {
+        m3_encode_obs(O.dirt, O.over, c, p, env, pos, true);
+      }
+      TRACE_PUT(3, TRACE_NOW());
+      return;
+    }
+  }
+
   if constexpr (MODE == M3_STATS_FOR_GRIDS) {
-    for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
-    const uint8_t *src = p.init_grids + (size_t)env * c.n_cells;
-    for (int ci = c.lane; ci < c.n_cells; ci += 64)
-      if (src[ci]) atomicOr(&L.dirt[ci >> 5], 1u << (ci & 31));
-    uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
+    m3_load_bytes(L.dirt, c, p.init_grids + (size_t)env * c.n_cells);
+    for (int i = c.lane; i < c.n_cells; i += 64) {
+      L.best[i] = 0;
+      L.claim[i] = 0xFFFFFFFFu;
+    }
+    if (c.lane == 0) L.epoch = 0;
+    uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
     int32_t st[NS];
     bool ovf = false;
-    m3_stats(L, c, air, st, ovf PHASE_PASS);
+    m3_stats(L, c, air, st, ovf, true PHASE_PASS);
     if (ovf && c.lane == 0) atomicOr(p.err, 4);
     if (c.lane == 0)
       for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
@@ -460,7 +600,7 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     return;
   }
 
-  // load grid + overlay
+  // load grid + overlay (+ the slot cache) and prepare the search tables
   for (int i = c.lane; i < c.nw + 2; i += 64) {
     L.dirt[i] = i < c.nw ? gd[i] : 0u;
     L.over[i] = i < c.nw ? gd[M3_MAXW + i] : 0u;
@@ -469,27 +609,38 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
 
   if constexpr (MODE == M3_OBSERVE) {
     // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
-    m3_encode_obs(L, c, p, env, pos, false);
+    m3_encode_obs(L.dirt, L.over, c, p, env, pos, false);
     return;
   }
+  if constexpr (MODE != M3_RESET) {
+    for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) ((uint32_t *)L.slot)[i] = gslot[i];
+  }
+  for (int i = c.lane; i < c.n_cells; i += 64) {
+    L.best[i] = 0;
+    L.claim[i] = 0xFFFFFFFFu;
+  }
+  if (c.lane == 0) L.epoch = 0;
 
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   double last_loss = S->last_loss, ep_return = S->ep_return;
   int32_t st[NS];
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
-  bool ovf = false;
+  bool ovf = false, slots_dirty = false;
   EnvTargets<NS> trg;
   trg.load(p, env, false);
+  Pcg rp, rr;
 
   if constexpr (MODE == M3_RESET) {
     if (p.mask != nullptr && p.mask[env] == 0) return;
     if (p.refresh_only) {  // statistics (and the path overlay) of the current map, nothing else
-      uint64_t air0 = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-      m3_stats(L, c, air0, st, ovf PHASE_PASS);
+      uint64_t air0 = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
+      m3_stats(L, c, air0, st, ovf, true PHASE_PASS);
       if (ovf && c.lane == 0) atomicOr(p.err, 4);
       for (int i = c.lane; i < c.nw; i += 64) gd[M3_MAXW + i] = L.over[i];
+      for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) gslot[i] = ((uint32_t *)L.slot)[i];
       if (c.lane == 0) {
         S->last_loss = trg.loss(p.cfg, st);
+        S->flags = 0;
         for (int k = 0; k < NS; k++) {
           S->stats[k] = st[k];
           if (p.stats_out) p.stats_out[(size_t)env * NS + k] = st[k];
@@ -498,19 +649,23 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
       return;
     }
     if (p.init_grids) {
-      for (int i = c.lane; i < c.nw + 2; i += 64) L.dirt[i] = 0;
-      const uint8_t *src = p.init_grids + (size_t)env * c.n_cells;
-      for (int ci = c.lane; ci < c.n_cells; ci += 64)
-        if (src[ci]) atomicOr(&L.dirt[ci >> 5], 1u << (ci & 31));
+      m3_load_bytes(L.dirt, c, p.init_grids + (size_t)env * c.n_cells);
       pos[0] = pos[1] = pos[2] = 0;
       if (p.init_pos)
         for (int d = 0; d < 3; d++) pos[d] = p.init_pos[(size_t)env * 3 + d];
     } else {
-      m3_reset_rng(L, c, p, env, cpl);
+      rp.load(p.rng[env].prob);
+      rr.load(p.rng[env].rep);
+      m3_reset_rng(L.dirt, c, p, cpl, rp, rr);
+      if (c.lane == 0) {
+        rr.store(p.rng[env].rep);
+        rp.store(p.rng[env].prob);
+      }
       pos[0] = pos[1] = pos[2] = 0;
     }
-    uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-    m3_stats(L, c, air, st, ovf PHASE_PASS);
+    uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
+    m3_stats(L, c, air, st, ovf, true PHASE_PASS);
+    slots_dirty = true;
     n_step = iteration = changes = 0;
     ep_return = 0.0;
     if (p.set_state) {  // pcgrl_set_state: injected map, the caller's counters / return
@@ -526,11 +681,15 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
   } else {
    const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;
    const size_t N = (size_t)p.n_envs;
+   rp.load(p.rng[env].prob);  // (only advanced by an auto-reset)
+   rr.load(p.rng[env].rep);
+   bool any_reset = false;
+   if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();  // the observe wave has taken its copy of the old state
    for (int k = 0; k < K; k++) {
     const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
     uint8_t *obs_k = p.obs == nullptr ? nullptr
                      : (MODE == M3_ROLLOUT && !p.obs_last_only ? p.obs + (size_t)k * N * (size_t)p.obs_env_bytes : p.obs);
-    const bool want_obs = MODE != M3_ROLLOUT || !p.obs_last_only || k == K - 1;
+    const bool want_obs = MODE == M3_ROLLOUT && (!p.obs_last_only || k == K - 1);  // (M3_STEP: the observe wave)
     // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
     const int action = p.actions[o];
     const bool bad = action < 0 || action >= 2;
@@ -539,20 +698,23 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     bool change = false;
     if (!bad) {
       const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
-      const bool old = m3_dirt(L, ci);
+      const bool old = m3_bit(L.dirt, ci);
       change = old != (action != 0);
-      if (change && c.lane == 0) L.dirt[ci >> 5] ^= 1u << (ci & 31);
-      const int idx = n_step % c.n_cells;  // Q1
-      pos[0] = idx / (c.Y * c.X);
-      pos[1] = (idx / c.X) % c.Y;
-      pos[2] = idx % c.X;
-      n_step++;
+      if (change) {
+        if (c.lane == 0) L.dirt[ci >> 5] ^= 1u << (ci & 31);
+        // the edit invalidates exactly the cached slots whose searches read this cell
+        const int q = pos[1] * c.X + pos[2];
+        if (c.lane < M3_SLOTS && ((L.slot[c.lane].rs[q >> 2] >> ((q & 3) * 8 + pos[0])) & 1u)) L.slot[c.lane].valid = 0;
+        slots_dirty = true;
+      }
+      m3_advance_pos(c, pos, n_step);
     } else if (c.lane == 0) {
       atomicOr(p.err, 1);
     }
-    if (upd_only) {  // rep.update() only: map, position, observation (with the stale overlay)
-      m3_encode_obs(L, c, p, env, pos, true);
+    if (upd_only) {  // rep.update() only: map, position (the observe wave shows the stale overlay)
       for (int i = c.lane; i < c.nw; i += 64) gd[i] = L.dirt[i];
+      if (slots_dirty)
+        for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) gslot[i] = ((uint32_t *)L.slot)[i];
       if (c.lane == 0) {
         S->pos[0] = pos[0];
         S->pos[1] = pos[1];
@@ -568,11 +730,11 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
     // the previous stats update on the already edited map
     PHASE_MARK(0);  // loads + action
-    if (!do_reset && want_obs) m3_encode_obs(L, c, p, env, pos, true, obs_k);
+    if (!do_reset && want_obs) m3_encode_obs(L.dirt, L.over, c, p, env, pos, true, obs_k);
     PHASE_MARK(1);  // observation
     if (change) {
-      uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-      m3_stats(L, c, air, st, ovf PHASE_PASS);
+      uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
+      m3_stats(L, c, air, st, ovf, false PHASE_PASS);
     }
     const double loss = trg.loss(p.cfg, st);
     const double rew = loss - last_loss;
@@ -587,16 +749,22 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     }
     if (do_reset) {
       if (c.lane == 0) latch_episode<NS>(p, env, S, ep_return, iteration, st);
-      m3_reset_rng(L, c, p, env, cpl);
+      m3_reset_rng(L.dirt, c, p, cpl, rp, rr);
+      any_reset = true;
       pos[0] = pos[1] = pos[2] = 0;
-      uint64_t air = c.lane < c.Z ? m3_plane_air(L, c, c.lane) : 0ull;
-      m3_stats(L, c, air, st, ovf PHASE_PASS);
+      uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
+      m3_stats(L, c, air, st, ovf, true PHASE_PASS);
+      slots_dirty = true;
       n_step = iteration = changes = 0;
       ep_return = 0.0;
       trg.load(p, env, true);
       last_loss = trg.loss(p.cfg, st);
-      if (want_obs) m3_encode_obs(L, c, p, env, pos, false, obs_k);
+      if (want_obs) m3_encode_obs(L.dirt, L.over, c, p, env, pos, false, obs_k);
     }
+   }
+   if (any_reset && c.lane == 0) {
+     rr.store(p.rng[env].rep);
+     rp.store(p.rng[env].prob);
    }
   }
   if (ovf && c.lane == 0) atomicOr(p.err, 4);
@@ -605,6 +773,8 @@ __global__ __launch_bounds__(64) void m3_kernel(Params p, int cpl) {
     gd[i] = L.dirt[i];
     gd[M3_MAXW + i] = L.over[i];
   }
+  if (slots_dirty)
+    for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) gslot[i] = ((uint32_t *)L.slot)[i];
   if (c.lane == 0) {
     trg.write_ctrl_obs(p, env, st);
     trg.commit(p, env);
