@@ -21,8 +21,8 @@
 // SLOT CACHE.  calc_longest_path (:503-563) starts one pair of searches per start candidate, and its whole-plane visited
 // marking (:531) leaves at most ONE processed candidate per z-plane: the first candidate of the plane in (y, x) order.
 // Everything a plane's pair of searches produces -- the marks, max_dist, n_jump, the path tiles -- is a function of the
-// cells the searches READ.  The engine keeps, per env and plane, that result together with the read set (per column:
-// the z range the move rules looked at, a superset) in HBM.  A step edits one cell: slots whose read set contains it are
+// cells the searches READ.  The engine keeps, per env and plane, that result together with the read set (a superset: the
+// columns the move rules looked at and the range of heights, z-2 .. z+3 around every accepted cell) in HBM.  A step edits one cell: slots whose read set contains it are
 // dropped, every other slot is still exact, and the sequential candidate walk re-runs only the searches it actually
 // needs.  Under random edits most steps re-run no or one pair instead of all of them.
 #pragma once
@@ -45,15 +45,16 @@ struct alignas(8) M3Slot {
   uint8_t valid;
   uint16_t max_dist;
   uint16_t n_jump;
-  uint16_t mk;     // z-planes marked visited by the first search (the fancy-index bug, :531)
-  uint32_t rs[16];          // read set: byte q = z bits of column q = y*X + x the searches depended on
+  uint8_t mk;      // z-planes marked visited by the first search (the fancy-index bug, :531)
+  uint8_t zr;      // read set, heights: lowest | highest << 4 plane the move rules looked at
+  uint32_t rs[2];  // read set, columns: bit q = the searches looked at column q = y*X + x
   uint32_t pathm[M3_MAXW];  // tiles of paths[farthest] of the second search
 };
-static_assert(sizeof(M3Slot) == 136, "slot layout");
+static_assert(sizeof(M3Slot) == 80, "slot layout");
 constexpr int M3_SLOT_WORDS = (int)(sizeof(M3Slot) / 4) * M3_SLOTS;
 
 struct M3Lds {
-  uint2 ent[M3_ENT_CAP];        // cell | kind<<9 | njump<<12 | parent<<20 ; len
+  uint2 ent[M3_ENT_CAP];        // cell | kind<<9 | njump<<12 | parent<<20 ; len | x<<12 | y<<18 | z<<24 | direction<<28
   uint32_t best[M3_MAXCELLS];   // per cell: epoch<<24 | len<<12 | accepted entry id (the `paths` dict of the current search)
   uint16_t order[M3_MAXCELLS];  // cells in first-insertion order
   uint32_t claim[M3_MAXCELLS];  // scratch of m3_search: lowest trip slot popping a cell (0xFFFFFFFF between trips)
@@ -63,6 +64,9 @@ struct M3Lds {
   uint8_t col[64];              // per (y,x): AIR bits over z
   M3Slot slot[M3_SLOTS];
   uint32_t epoch;               // current search id in `best`
+#ifdef PCGRL_PHASE_TIMING
+  uint32_t dbg[8];              // development counters: trips, queue entries, searches, cycles of search 1 / farthest / search 2 / chain walk
+#endif
 };
 struct M3ObsLds {  // the observe wave's own copy
   uint32_t dirt[M3_MAXW + 2];
@@ -163,10 +167,10 @@ __device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z *
 //     rejected when popped, like in the reference;
 //   * first-visit order and queue order are kept with prefix counts over the lanes (entry-major, direction-minor).
 // `best` entries carry the search's epoch, so nothing is cleared between searches.
-// mk: coordinate values of all reached cells (bit v set if some reached cell has x, y or z == v);  rs: read set (per
-// column byte: z bits) accumulated for the slot cache.
-__device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, uint32_t &mk, uint32_t *rs,
-                                bool &overflow) {
+// mk: coordinate values of all reached cells (bit v set if some reached cell has x, y or z == v);  rs: read set (one bit
+// per column) accumulated PER LANE for the slot cache (the caller ORs the lanes together).
+__device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, uint32_t &mk, uint64_t &rs,
+                                int &zlo, int &zhi, bool &overflow) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
   uint32_t epoch = L.epoch + 1;  // (uniform: every lane reads the same word)
   if (epoch > 255u) {            // wrapped: clear the table once
@@ -175,43 +179,43 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
   }
   if (c.lane == 0) {
     L.epoch = epoch;
-    L.ent[0] = make_uint2((uint32_t)m3_cell(c, sx, sy, sz) | ((uint32_t)M3_ROOT << 9) | (M3_NOPARENT << 20), 1u);
+    L.ent[0] = make_uint2((uint32_t)m3_cell(c, sx, sy, sz) | ((uint32_t)M3_ROOT << 9) | (M3_NOPARENT << 20),
+                          1u | ((uint32_t)sx << 12) | ((uint32_t)sy << 18) | ((uint32_t)sz << 24));
   }
   int head = 0, tail = 1;
   n_order = 0;
   const int slot_i = c.lane >> 2, d = c.lane & 3;
   const int dxl = d == 0 ? 1 : (d == 2 ? -1 : 0), dyl = d == 1 ? 1 : (d == 3 ? -1 : 0);  // helper_3D.py:220
+  const int dq = dyl * c.X + dxl;  // column-index step of this lane's direction
   const uint64_t lt = (1ull << c.lane) - 1ull;
   const int YX = c.Y * c.X;
   uint32_t mkl = 0;
+#ifdef PCGRL_PHASE_TIMING
+  int dbg_trips = 0;
+#endif
   while (head < tail) {
+#ifdef PCGRL_PHASE_TIMING
+    dbg_trips++;
+#endif
     const int nb = min(16, tail - head);
     const bool live = slot_i < nb;
     const int id = head + (live ? slot_i : 0);
     const uint2 e = L.ent[id];
-    const int ci = e.x & 511, nj = (e.x >> 12) & 255, len = (int)e.y;
-    const int z = ci / YX, r0 = ci - z * YX, y = r0 / c.X, x = r0 - y * c.X;
+    const int ci = e.x & 511, nj = (e.x >> 12) & 255, len = (int)(e.y & 0xFFFu);
+    const int x = (e.y >> 12) & 63, y = (e.y >> 18) & 63, z = (int)((e.y >> 24) & 15u);
     if (live && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
     // everything that depends only on the entry comes back in one LDS round trip: `best` and first slot of its cell, its
-    // column, the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map) and
-    // `best` of the six cells this lane could move to
-    const int nx = x + dxl, ny = y + dyl, jx = x + 2 * dxl, jy = y + 2 * dyl;
-    const bool n_in = nx >= 0 && ny >= 0 && nx < c.X && ny < c.Y, j_in = jx >= 0 && jy >= 0 && jx < c.X && jy < c.Y;
-    const int qn = n_in ? ny * c.X + nx : 0, qj = j_in ? jy * c.X + jx : 0, qc = y * c.X + x;
+    // column and the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map)
+    const int nx = x + dxl, ny = y + dyl, jx = nx + dxl, jy = ny + dyl;
+    const bool n_in = (unsigned)nx < (unsigned)c.X && (unsigned)ny < (unsigned)c.Y;
+    const bool j_in = (unsigned)jx < (unsigned)c.X && (unsigned)jy < (unsigned)c.Y;
+    const int qc = ci - z * YX, qn = n_in ? qc + dq : 0, qj = j_in ? qc + 2 * dq : 0;
     const uint32_t b = L.best[ci];
     const uint32_t first_slot = L.claim[ci];
     const uint32_t cc = L.col[qc], cn = L.col[qn], cj = L.col[qj];
-    uint32_t bn[3], bj[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int tz = min(max(z - 1 + k, 0), c.Z - 1);
-      bn[k] = L.best[tz * YX + qn];
-      bj[k] = L.best[tz * YX + qj];
-    }
     const bool seen = (b >> 24) == epoch;
-    bool accept = live;
-    if (seen && (int)((b >> 12) & 0xFFFu) <= len) accept = false;                 // :437-440
-    if (z + 1 == c.Z || !((cc >> (z + 1)) & 1u)) accept = false;                  // :443-445 no head-room
+    // :437-440 (an entry that is not shorter is dropped) and :443-445 (no head-room); cells >= Z read as not-AIR
+    const bool accept = live && !(seen && (int)((b >> 12) & 0xFFFu) <= len) && ((cc >> (z + 1)) & 1u);
     // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
     const uint64_t dupb = __ballot(accept && d == 0 && first_slot != (uint32_t)slot_i);
     const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
@@ -221,52 +225,34 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const uint64_t fb = __ballot(first);
     if (first) L.order[n_order + __popcll(fb & lt)] = (uint16_t)ci;
     n_order += __popcll(fb);
-    if (doit && d == 0) {
-      L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
-      mkl |= (x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z);
-    }
-    // successors: direction d of entry slot_i (helper_3D.py:214-319)
-    bool ok = false;
-    int tq = 0, tz = 0, kind = 0, add = 0, nj2 = nj;
-    uint32_t ct = 0;  // column mask of the target cell
-    if (doit) {
-      // read set: the z window the move rules can look at, in this entry's column, the neighbour's and the landing's
-      const uint32_t zwin = ((0x3Fu << (z + 6)) >> 8) & ((1u << c.Z) - 1u);  // bits z-2 .. z+3
-      if (d == 0) atomicOr(&rs[qc >> 2], zwin << ((qc & 3) * 8));
-      if (n_in) atomicOr(&rs[qn >> 2], zwin << ((qn & 3) * 8));
-      if (j_in) atomicOr(&rs[qj >> 2], zwin << ((qj & 3) * 8));
-      const int nz = z;
-      if (n_in) {
-        ct = cn;
-        auto A = [&](uint32_t col, int k) -> bool { return (col >> k) & 1u; };
-        if ((nz == 0 || !A(cn, nz - 1)) && A(cn, nz) && A(cn, nz + 1)) {
-          ok = true; tq = qn; tz = nz; kind = M3_WALK; add = 1;
-        } else if (nz >= 1 && (nz - 1 == 0 || !A(cn, nz - 2)) && A(cn, nz - 1) && A(cn, nz) && A(cn, nz + 1)) {
-          ok = true; tq = qn; tz = nz - 1; kind = M3_DOWN; add = 2;
-        } else if (nz + 2 < c.Z && !A(cn, nz) && A(cn, nz + 1) && A(cn, nz + 2) && A(cc, nz + 2)) {
-          ok = true; tq = qn; tz = nz + 1; kind = M3_UP; add = 2;
-        } else if (nz - 2 >= 0 && nz + 2 < c.Z && A(cn, nz + 2) && A(cn, nz + 1) && A(cn, nz) && A(cn, nz - 1) && A(cn, nz - 2) &&
-                   A(cc, nz + 2) && j_in) {
-          ct = cj;
-          const int jz = z;
-          if (A(cj, jz + 1) && A(cj, jz + 2) && A(cj, jz) && !A(cj, jz - 1)) {
-            ok = true; tq = qj; tz = jz; kind = M3_JFLAT; add = 2; nj2 = nj + 1;
-          } else if (jz + 3 < c.Z && A(cj, jz + 3) && A(cj, jz + 2) && A(cj, jz + 1) && !A(cj, jz)) {
-            ok = true; tq = qj; tz = jz + 1; kind = M3_JUP; add = 3; nj2 = nj + 1;
-          } else if (A(cj, jz) && A(cj, jz + 1) && A(cj, jz - 1) && !A(cj, jz - 2)) {
-            ok = true; tq = qj; tz = jz - 1; kind = M3_JDOWN; add = 3; nj2 = nj + 1;
-          }
-        }
-      }
-    }
-    if (ok) {  // never queue what is known to be a no-op when popped
-      if (tz + 1 == c.Z || !((ct >> (tz + 1)) & 1u)) ok = false;
-      if (ok) {
-        const int k = tz - (z - 1);  // 0 .. 2
-        const uint32_t bt = kind >= M3_JFLAT ? (k == 0 ? bj[0] : (k == 1 ? bj[1] : bj[2])) : (k == 0 ? bn[0] : (k == 1 ? bn[1] : bn[2]));
-        if ((bt >> 24) == epoch && (int)((bt >> 12) & 0xFFFu) <= len + add) ok = false;
-      }
-    }
+    const bool acc0 = doit && d == 0;
+    if (acc0) L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
+    mkl |= acc0 ? ((x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z)) : 0u;
+    // Successor in direction d (helper_3D._passable :214-319), branch-free on 6-bit windows of the columns: bit i of
+    // a window = AIR at height z-2+i (below the floor and above the ceiling read as not-AIR, which is what every rule's
+    // explicit bounds check amounts to).  The six rules are mutually exclusive.
+    const uint32_t wn = ((cn << 2) >> z) & 0x3Fu, wj = ((cj << 2) >> z) & 0x3Fu, c4 = (cc >> (z + 2)) & 1u;
+    const bool walk = (wn & 0x0Eu) == 0x0Cu;                      // stands at z: !n[z-1], n[z], n[z+1]
+    const bool down = z >= 1 && (wn & 0x0Fu) == 0x0Eu;            // stands at z-1: !n[z-2], n[z-1], n[z], n[z+1]
+    const bool up = (wn & 0x1Cu) == 0x18u && c4;                  // stands at z+1: !n[z], n[z+1], n[z+2], own z+2 free
+    const bool gap = z >= 2 && (wn & 0x1Fu) == 0x1Fu && c4 && j_in;  // n[z-2..z+2] all AIR: a gap to jump over
+    const bool jflat = gap && (wj & 0x1Eu) == 0x1Cu;              // !j[z-1], j[z], j[z+1], j[z+2]
+    const bool jup = gap && (wj & 0x3Cu) == 0x38u;                // !j[z], j[z+1], j[z+2], j[z+3]
+    const bool jdown = gap && (wj & 0x0Fu) == 0x0Eu;              // !j[z-2], j[z-1], j[z], j[z+1]
+    const bool jump = jflat || jup || jdown;
+    bool ok = doit && n_in && (walk || down || up || jump);
+    const int kind = walk ? M3_WALK : (down ? M3_DOWN : (up ? M3_UP : (jflat ? M3_JFLAT : (jup ? M3_JUP : M3_JDOWN))));
+    const int add = walk ? 1 : ((jup || jdown) ? 3 : 2);
+    const int tz = z + ((up || jup) ? 1 : 0) - ((down || jdown) ? 1 : 0);
+    const int tq = jump ? qj : qn, tx = jump ? jx : nx, ty = jump ? jy : ny;
+    const int tcell = tz * YX + tq;
+    // read set: this entry's column, the neighbour's and the landing's
+    rs |= doit ? ((1ull << qc) | (n_in ? 1ull << qn : 0ull) | (j_in ? 1ull << qj : 0ull)) : 0ull;
+    zlo = doit ? min(zlo, z) : zlo;
+    zhi = doit ? max(zhi, z) : zhi;
+    // never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it)
+    const uint32_t bt = L.best[ok ? tcell : 0];
+    if ((bt >> 24) == epoch && (int)((bt >> 12) & 0xFFFu) <= len + add) ok = false;
     const uint64_t okb = __ballot(ok);
     const int npush = __popcll(okb);
     if (tail + npush > M3_ENT_CAP) {
@@ -274,12 +260,20 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
       break;
     }
     if (ok)
-      L.ent[tail + __popcll(okb & lt)] = make_uint2((uint32_t)(tz * YX + tq) | ((uint32_t)kind << 9) | ((uint32_t)nj2 << 12) | ((uint32_t)id << 20),
-                                                    (uint32_t)(len + add));
+      L.ent[tail + __popcll(okb & lt)] =
+          make_uint2((uint32_t)tcell | ((uint32_t)kind << 9) | ((uint32_t)(nj + (jump ? 1 : 0)) << 12) | ((uint32_t)id << 20),
+                     (uint32_t)(len + add) | ((uint32_t)tx << 12) | ((uint32_t)ty << 18) | ((uint32_t)tz << 24) | ((uint32_t)d << 28));
     tail += npush;
     head += nproc;
   }
   mk = wave_or8(mkl);
+#ifdef PCGRL_PHASE_TIMING
+  if (c.lane == 0) {
+    L.dbg[0] += (uint32_t)dbg_trips;
+    L.dbg[1] += (uint32_t)tail;
+    L.dbg[2] += 1;
+  }
+#endif
   return tail;
 }
 
@@ -301,49 +295,91 @@ __device__ inline int m3_farthest(const M3Lds &L, const M3Ctx &c, int n_order, i
 // The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s (result + read set).
 __device__ inline void m3_fill_slot(M3Lds &L, const M3Ctx &c, int s, int sx, int sy, int sz, bool &overflow) {
   M3Slot &S = L.slot[s];
-  for (int i = c.lane; i < 16 + M3_MAXW; i += 64) (i < 16 ? S.rs[i] : S.pathm[i - 16]) = 0;
   if (c.lane == 0) S.valid = 0;
   int n_order = 0, e1 = 0, e2 = 0;
   uint32_t mk = 0, mk2 = 0;
-  m3_search(L, c, sx, sy, sz, n_order, mk, S.rs, overflow);
+  uint64_t rs = 0;
+  int zlo = 15, zhi = 0;
+#ifdef PCGRL_PHASE_TIMING
+  uint64_t t0_ = __builtin_readcyclecounter();
+#define M3_T(i)                                                     \
+  do {                                                              \
+    uint64_t t1_ = __builtin_readcyclecounter();                    \
+    if (c.lane == 0) L.dbg[i] += (uint32_t)(t1_ - t0_);             \
+    t0_ = t1_;                                                      \
+  } while (0)
+#else
+#define M3_T(i) \
+  do {          \
+  } while (0)
+#endif
+  m3_search(L, c, sx, sy, sz, n_order, mk, rs, zlo, zhi, overflow);
+  M3_T(3);
   if (overflow) return;
   const int YX = c.Y * c.X;
-  const int far = m3_farthest(L, c, n_order, e1);
-  const int fz = far / YX, fr = far - fz * YX, fy = fr / c.X, fx = fr - fy * c.X;
-  m3_search(L, c, fx, fy, fz, n_order, mk2, S.rs, overflow);
+  (void)m3_farthest(L, c, n_order, e1);
+  const uint32_t f1 = L.ent[e1].y;
+  M3_T(4);
+  m3_search(L, c, (int)((f1 >> 12) & 63u), (int)((f1 >> 18) & 63u), (int)((f1 >> 24) & 15u), n_order, mk2, rs, zlo, zhi, overflow);
+  M3_T(5);
   if (overflow) return;
   (void)m3_farthest(L, c, n_order, e2);
+  // OR of the lanes' read sets (DPP inside the 16-lane rows, then across); min / max of the heights ride along as a
+  // unary mask of the planes seen
+  uint32_t lo = (uint32_t)rs, hi = (uint32_t)(rs >> 32), zm = zlo <= zhi ? ((2u << zhi) - (1u << zlo)) : 0u;
+#define M3_DPP_OR(ctl)                                                                 \
+  lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, ctl, 0xF, 0xF, true);         \
+  hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, ctl, 0xF, 0xF, true);         \
+  zm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)zm, ctl, 0xF, 0xF, true)
+  M3_DPP_OR(0xB1);
+  M3_DPP_OR(0x4E);
+  M3_DPP_OR(0x141);
+  M3_DPP_OR(0x140);
+#undef M3_DPP_OR
+  lo |= (uint32_t)__shfl_xor((int)lo, 16, 64);
+  hi |= (uint32_t)__shfl_xor((int)hi, 16, 64);
+  zm |= (uint32_t)__shfl_xor((int)zm, 16, 64);
+  lo |= (uint32_t)__shfl_xor((int)lo, 32, 64);
+  hi |= (uint32_t)__shfl_xor((int)hi, 32, 64);
+  zm |= (uint32_t)__shfl_xor((int)zm, 32, 64);
+  // The tiles of paths[(mx,my,mz)] as a bit mask: every lane walks the parent chain (uniform reads), lane w keeps word
+  // w of the mask.  An entry knows its move kind and direction, so the parent's cell and the intermediate tiles of the
+  // move (helper_3D.py:214-319) follow without reading the parent: +-YX = one plane up / down.
+  uint32_t my = 0;
+  auto mark = [&](int cell) { my |= (cell >> 5) == c.lane ? 1u << (cell & 31) : 0u; };
+  int id = e2;
+  const uint2 fe = L.ent[e2];
+  while (true) {
+    const uint2 e = L.ent[id];
+    const int ci = e.x & 511, kind = (e.x >> 9) & 7, d = (int)(e.y >> 28);
+    mark(ci);
+    if (kind == M3_ROOT) break;
+    const int dq = (d == 0 ? 1 : (d == 2 ? -1 : 0)) + (d == 1 ? c.X : (d == 3 ? -c.X : 0));  // column step of the move
+    const int mid = ci - dq;  // jumps: the jumped-over column, at the landing's height
+    switch (kind) {
+      case M3_DOWN: mark(ci + YX); break;                          // the target column at the parent's height
+      case M3_UP: mark(ci - dq); break;                            // above the parent: (x, y, nz+1)
+      case M3_JFLAT: mark(mid); break;                             // (nx, ny, nz)
+      case M3_JUP: mark(mid - YX); mark(mid); break;               // (nx,ny,nz), (nx,ny,nz+1): landing is one higher
+      case M3_JDOWN: mark(mid + YX); mark(mid); break;             // (nx,ny,nz), (nx,ny,nz-1): landing is one lower
+      default: break;
+    }
+    id = (int)(e.x >> 20);
+  }
+  if (c.lane < M3_MAXW) S.pathm[c.lane] = my;
   if (c.lane == 0) {
-    const uint2 fe = L.ent[e2];
     S.start = (uint8_t)(sy * c.X + sx);
     S.valid = 1;
-    S.max_dist = (uint16_t)fe.y;
+    S.max_dist = (uint16_t)(fe.y & 0xFFFu);
     S.n_jump = (uint16_t)((fe.x >> 12) & 255u);
-    S.mk = (uint16_t)(mk & ((1u << c.Z) - 1u));
-    // materialise the tiles of paths[(mx,my,mz)] into a bit mask (walk the parent chain)
-    int id = e2;
-    while (true) {
-      const uint2 e = L.ent[id];
-      const int ci = e.x & 511, kind = (e.x >> 9) & 7, par = (int)(e.x >> 20);
-      auto mark = [&](int cell) { S.pathm[cell >> 5] |= 1u << (cell & 31); };
-      mark(ci);
-      if (kind == M3_ROOT) break;
-      const int pc = L.ent[par].x & 511;
-      // intermediate tiles of the move (helper_3D.py:214-319) in cell-index arithmetic: +-YX = one plane up / down,
-      // `mid` = the jumped-over column at the parent's height
-      const int pz = pc / YX, z = ci / YX;
-      const int mid = ((pc - pz * YX) + (ci - z * YX)) / 2 + pz * YX;
-      switch (kind) {
-        case M3_DOWN: mark(ci + YX); break;                   // (nx, ny, nz): the target column at the parent's height
-        case M3_UP: mark(pc + YX); break;                     // (x, y, nz+1)
-        case M3_JFLAT: mark(mid); break;                      // (nx, ny, nz)
-        case M3_JUP: mark(mid); mark(mid + YX); break;        // (nx,ny,nz), (nx,ny,nz+1)
-        case M3_JDOWN: mark(mid); mark(mid - YX); break;      // (nx,ny,nz), (nx,ny,nz-1)
-        default: break;
-      }
-      id = par;
-    }
+    S.mk = (uint8_t)(mk & ((1u << c.Z) - 1u));
+    zm &= 0xFFu;
+    S.zr = (uint8_t)((zm ? __builtin_ctz(zm) : 15) | ((zm ? 31 - __builtin_clz(zm) : 0) << 4));
+    S.rs[0] = lo;
+    S.rs[1] = hi;
   }
+  M3_T(6);
+#undef M3_T
 }
 
 // helper_3D.calc_longest_path + remove_stacked_path_tiles + minecraft_3D_maze_prob.get_stats
@@ -398,13 +434,15 @@ __device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t 
     L.pathm[i] = (best_slot >= 0 && i < M3_MAXW) ? L.slot[best_slot < 0 ? 0 : best_slot].pathm[i] : 0u;
     L.over[i] = 0;
   }
-  for (int ci = c.lane; ci < c.n_cells; ci += 64) {
-    bool in = m3_bit(L.pathm, ci);
-    if (in && ci >= YX && m3_bit(L.pathm, ci - YX)) in = false;
-    if (in) {
-      const int z = ci / YX, r = ci - z * YX, y = r / c.X, x = r - y * c.X;
-      const int oi = (x * c.Y + y) * c.X + z;
-      if (x < c.Z && y < c.Y && z < c.X) atomicOr(&L.over[oi >> 5], 1u << (oi & 31));
+  {
+    const int q = c.lane, y = q / c.X, x = q - y * c.X;  // this lane's column (lanes < YX)
+    for (int z = 0; z < c.Z; z++) {
+      const int ci = z * YX + q;
+      const bool in = q < YX && m3_bit(L.pathm, ci) && !(z > 0 && m3_bit(L.pathm, ci - YX));
+      if (in && x < c.Z && z < c.X) {
+        const int oi = (x * c.Y + y) * c.X + z;
+        atomicOr(&L.over[oi >> 5], 1u << (oi & 31));
+      }
     }
   }
   st[1] = final_value;
@@ -620,6 +658,9 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     L.claim[i] = 0xFFFFFFFFu;
   }
   if (c.lane == 0) L.epoch = 0;
+#ifdef PCGRL_PHASE_TIMING
+  if (c.lane < 8) L.dbg[c.lane] = 0;
+#endif
 
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   double last_loss = S->last_loss, ep_return = S->ep_return;
@@ -704,7 +745,11 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
         if (c.lane == 0) L.dirt[ci >> 5] ^= 1u << (ci & 31);
         // the edit invalidates exactly the cached slots whose searches read this cell
         const int q = pos[1] * c.X + pos[2];
-        if (c.lane < M3_SLOTS && ((L.slot[c.lane].rs[q >> 2] >> ((q & 3) * 8 + pos[0])) & 1u)) L.slot[c.lane].valid = 0;
+        if (c.lane < M3_SLOTS) {
+          const M3Slot &T = L.slot[c.lane];
+          const int zr = T.zr;
+          if (((T.rs[q >> 5] >> (q & 31)) & 1u) && pos[0] >= (zr & 15) - 2 && pos[0] <= (zr >> 4) + 3) L.slot[c.lane].valid = 0;
+        }
         slots_dirty = true;
       }
       m3_advance_pos(c, pos, n_step);
@@ -790,6 +835,14 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
   }
   PHASE_MARK(6);
+#ifdef PCGRL_PHASE_TIMING
+  _ph[0] = L.dbg[0];  // (development: trips / queue entries / searches of this launch replace the first phases)
+  _ph[1] = L.dbg[6];  // (farthest 2 + path materialisation)
+  _ph[2] = L.dbg[2];
+  _ph[3] = L.dbg[3];  // cycles: first search, farthest, second search, farthest + path materialisation
+  _ph[5] = L.dbg[4];
+  _ph[6] = L.dbg[5];
+#endif
   PHASE_FLUSH();
   TRACE_PUT(0, _tr0);
   TRACE_PUT(1, TRACE_NOW());

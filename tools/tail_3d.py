@@ -14,18 +14,22 @@ g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
 out = np.zeros(8 * n, np.uint64)
-names = ["loads", "obs", "cols", "regions", "searches", "overlay", "rest", "wall(10ns)"]
+names = ["trips", "cyc_far2+chain", "n_searches", "cyc_search1", "searches", "cyc_far1", "cyc_search2", "wall"]
 rows = []
 for k in range(700):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
     if k >= 500:
         env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * n)
         a = out.reshape(n, 8).astype(np.float64)
-        tot = a[:, :7].sum(1)
+        tot = a[:, 4]
         i = int(tot.argmax())
-        rows.append((tot.mean(), tot.max(), a[i, :7]))
+        rows.append((tot.mean(), tot.max(), a[i, :8]))
     elif k == 499:
         env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * n)
 m = np.array([r[0] for r in rows]); mx = np.array([r[1] for r in rows]); ph = np.array([r[2] for r in rows])
 print("mean wave cycles %.0f, mean of per-launch max %.0f (x%.1f)" % (m.mean(), mx.mean(), mx.mean() / m.mean()))
-print("phases of the slowest wave (mean over launches):", dict(zip(names[:7], ph.mean(0).round().tolist())))
+print("phases of the slowest wave (mean over launches):", dict(zip(names[:8], ph.mean(0).round().tolist())))
+
+# distribution of the search work per launch (all waves)
+print("per-wave means over the last launch: trips %.1f entries %.1f searches %.2f; max trips %d entries %d searches %d" % (
+    a[:, 0].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 0].max(), a[:, 1].max(), a[:, 2].max()))
