@@ -6,16 +6,26 @@
 //                         a 16x16 binary map is 16 consecutive 32-bit words and a group of 16 lanes loads its env with
 //                         one coalesced 64-byte access per plane.  binary: planes 1, 2 = fars / best (incremental
 //                         path-length state), plane 3 = pre-flooded component of the next edit cell (PREFLOOD).
-//   st      EnvState[N]   128-byte record of per-env scalars (one cache line).
+//   st      EnvState[N]   256-byte record: one hot 128-byte line of per-env scalars + the finished-episode totals.
 //   rng     RngState[N]   two PCG64 streams (representation, problem), numpy-compatible.
 //   xplanes M[N][1+NB][H] only with static tiles / action patches: static mask + lagging bordered-map planes
 //   xstate  u32[N][4]     flags and the spare half of the representation RNG's last 64-bit draw (Generator.integers)
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/pcgrl_amd.h"
 
 namespace pcgrl {
+
+// Per-env totals over the episodes finished since the last pcgrl_reduce_episodes (written only at an env's reset, summed
+// in a fixed order by the reduction kernel: no atomics, deterministic).  rl/callbacks.py:91-117 reads the same values.
+struct alignas(8) EpAcc {
+  double sum_return;
+  int64_t sum_len;
+  int64_t n;
+  int64_t sum_stats[PCGRL_MAX_STATS];
+};
 
 struct alignas(16) EnvState {
   int32_t pos[3];
@@ -30,8 +40,13 @@ struct alignas(16) EnvState {
   int64_t n_episodes;
   int32_t stats[PCGRL_MAX_STATS];
   int32_t final_stats[PCGRL_MAX_STATS];
+  // second 128-byte line: only touched when an episode ends (same base address as the hot line: no extra address registers
+  // in the step kernel, whose occupancy at large batches hangs on a handful of VGPRs)
+  EpAcc acc;
+  uint8_t pad_[40];
 };
-static_assert(sizeof(EnvState) == 128, "EnvState must be one 128-byte line");
+static_assert(sizeof(EnvState) == 256, "EnvState must be two 128-byte lines");
+static_assert(offsetof(EnvState, acc) == 128, "the episode totals start the second line");
 
 // EnvState::flags
 //   ENV_STATS_DIRTY  pcgrl_update changed the map and the statistics (and the binary fars / best masks) have not been
@@ -39,14 +54,7 @@ static_assert(sizeof(EnvState) == 128, "EnvState must be one 128-byte line");
 //                    get_stats (pcgrl_env.py:314-323); cleared by that step, pcgrl_refresh_stats and every reset.
 constexpr int32_t ENV_STATS_DIRTY = 1;
 
-// Per-env totals over the episodes finished since the last pcgrl_reduce_episodes (written only at an env's reset, summed
-// in a fixed order by the reduction kernel: no atomics, deterministic).  rl/callbacks.py:91-117 reads the same values.
-struct alignas(8) EpAcc {
-  double sum_return;
-  int64_t sum_len;
-  int64_t n;
-  int64_t sum_stats[PCGRL_MAX_STATS];
-};
+
 
 struct alignas(16) RngState {
   uint64_t rep[4];   // state_hi, state_lo, inc_hi, inc_lo
@@ -69,7 +77,6 @@ struct Params {
   RngState *rng;
   const JumpEntry *jump;  // [H+1]: skip by row*W draws; entry H = H*W draws
   int32_t *err;           // device error word
-  EpAcc *ep_acc;          // [N] finished-episode totals (pcgrl_reduce_episodes)
   void *soko;             // SokoPool* (sokoban solver workspace), else null
   void *m3cache;          // M3Slot[N][M3_SLOTS]: cached path-search results per start plane (3-D maze), else null
   // per-call I/O

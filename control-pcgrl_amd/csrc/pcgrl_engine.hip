@@ -283,7 +283,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_episodes_kernel(Params p, 
   int64_t v[RED_W - 1];
   for (int k = 0; k < RED_W - 1; k++) v[k] = 0;
   for (int e = lo + (int)threadIdx.x; e < hi; e += RED_THREADS) {  // fixed env -> thread assignment
-    EpAcc *A = &p.ep_acc[e];
+    EpAcc *A = &p.st[e].acc;
     ret += A->sum_return;
     v[0] += A->sum_len;
     v[1] += A->n;
@@ -391,7 +391,8 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   p.ext = (!is3d && (cfg->static_tiles || cfg->act_window[0] > 0)) ? 1 : 0;
   p.n_act = (!is3d && cfg->act_window[0] > 0) ? cfg->act_window[0] * cfg->act_window[1] : 1;
   // one padded observation row per lane + the OOB row (+ 2 rows per env of the wave with the static_builds plane)
-  e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * (65 + (cfg->static_tiles ? 16 : 0));
+  // (+ 64 bytes per env of the wave: the observe wave's copy of the RNG streams, see step_kernel)
+  e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * (65 + (cfg->static_tiles ? 16 : 0)) + 64 * 8;
   p.lds_pair_bytes = (int32_t)e->lds_bytes;
   e->cpl = is3d ? (p.n_cells + 63) / 64 : 0;
   const int H = cfg->dims[0], W = cfg->dims[1];
@@ -418,7 +419,6 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
-  CREATE_CHK(dalloc((void **)&p.ep_acc, (size_t)n_envs * sizeof(EpAcc)));
   CREATE_CHK(dalloc((void **)&e->red, sizeof(RedScratch)));
   // [0..3] error flags; from int 64 on: per-workgroup phase-timing accumulators (PCGRL_PHASE_TIMING builds)
   CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 64 + sizeof(uint64_t) * 8 * (size_t)(n_envs + 64)));

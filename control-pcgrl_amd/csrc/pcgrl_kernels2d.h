@@ -1430,21 +1430,28 @@ __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, 
 }
 
 // Episode end (auto-reset): what RLlib's callbacks read at that point (rl/callbacks.py:91-117) is latched in the env
-// record (pcgrl_get_last_episode) and added to the env's running totals (pcgrl_reduce_episodes).  One lane per env.
+// record (pcgrl_get_last_episode).  One lane per env.
 template <int NS>
 __device__ inline void latch_episode(const Params &p, int e, EnvState *S, double ep_return, int ep_len, const int32_t *st) {
+  (void)p;
+  (void)e;
   S->last_ep_return = ep_return;
   S->last_ep_len = ep_len;
   S->n_episodes += 1;
-  EpAcc *A = &p.ep_acc[e];
-  A->sum_return += ep_return;
-  A->sum_len += ep_len;
+#pragma unroll
+  for (int k = 0; k < NS; k++) S->final_stats[k] = st[k];
+}
+// ... and added to the env's running totals (pcgrl_reduce_episodes).  Called at the END of the kernel by the lane that
+// latched, from the latched values: at that point the searches are over and the adds cost no registers where it matters
+// (the step kernel's occupancy at large batches hangs on a handful of VGPRs).
+template <int NS>
+__device__ inline void accumulate_episode(EnvState *S) {
+  EpAcc *A = &S->acc;
+  A->sum_return += S->last_ep_return;
+  A->sum_len += S->last_ep_len;
   A->n += 1;
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
-    S->final_stats[k] = st[k];
-    A->sum_stats[k] += st[k];
-  }
+  for (int k = 0; k < NS; k++) A->sum_stats[k] += S->final_stats[k];
 }
 
 // One workgroup = two specialised wavefronts over the same 64/LPE envs:
@@ -1500,12 +1507,10 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   const int action = active ? p.actions[e] : 0;
   // An auto-reset of this step replays the env's RNG streams in BOTH waves; the simulate wave stores the advanced
   // streams at the end of the launch, so the observe wave takes its copy before the barrier (like every other piece
-  // of old state).
-  Pcg obs_rp, obs_rr;
-  if (observer && p.auto_reset != 0 && (iteration + 1 > p.cfg.max_iterations || p.cfg.max_changes >= 0)) {
-    obs_rp.load(p.rng[e].prob);
-    obs_rr.load(p.rng[e].rep);
-  }
+  // of old state).  The copy waits in LDS (behind the pair's observation rows) so that it costs no registers meanwhile.
+  uint64_t *rng_stash = (uint64_t *)(lds + p.lds_pair_bytes - 64 * EPW) + 8 * (g.lane / LPE);
+  if (observer && p.auto_reset != 0 && (iteration + 1 > p.cfg.max_iterations || p.cfg.max_changes >= 0) && g.row < 8)
+    rng_stash[g.row] = ((const uint64_t *)&p.rng[e])[g.row];  // rep[4], prob[4]
   // both waves have read the old state before wave 0 may overwrite it
   if (p.obs != nullptr) __syncthreads();
   PHASE_MARK(0);  // loads + barrier
@@ -1531,8 +1536,12 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   const bool do_reset = active && done && p.auto_reset != 0;
 
   if (observer) {
-    if (__ballot(do_reset) != 0)
+    if (__ballot(do_reset) != 0) {
+      Pcg obs_rp, obs_rr;
+      obs_rr.load(rng_stash);
+      obs_rp.load(rng_stash + 4);
       reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/false, ext ? &X : nullptr, &obs_rp, &obs_rr);
+    }
     if (ext && p.cfg.static_tiles)
       encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds);
     else
@@ -1654,6 +1663,7 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     S->ep_return = ep_return;
 #pragma unroll
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
+    if (do_reset) accumulate_episode<NS>(S);
   }
   PHASE_MARK(6);  // loss, outputs, write-back
   PHASE_FLUSH();
@@ -1751,7 +1761,10 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         }
       }
       if (__ballot(do_reset) != 0) {
-        if (do_reset && g.row == 0) latch_episode<NS>(p, e, S, ep_return, iteration, st);
+        if (do_reset && g.row == 0) {
+          latch_episode<NS>(p, e, S, ep_return, iteration, st);
+          accumulate_episode<NS>(S);
+        }
         reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, true, nullptr, &rp, &rr);
         int32_t ns[NS];
         compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);

@@ -793,7 +793,10 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
         for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
     }
     if (do_reset) {
-      if (c.lane == 0) latch_episode<NS>(p, env, S, ep_return, iteration, st);
+      if (c.lane == 0) {
+        latch_episode<NS>(p, env, S, ep_return, iteration, st);
+        accumulate_episode<NS>(S);
+      }
       m3_reset_rng(L.dirt, c, p, cpl, rp, rr);
       any_reset = true;
       pos[0] = pos[1] = pos[2] = 0;
