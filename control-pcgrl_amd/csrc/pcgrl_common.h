@@ -87,6 +87,7 @@ struct Params {
   int32_t *stats_out;
   int32_t auto_reset;
   int32_t update_only;   // pcgrl_update: representation update + observation only (no counters, stats, reward)
+  int32_t no_fast;       // stale statistics may exist (after pcgrl_update): step / rollout use the general kernels
   int32_t refresh_only;  // pcgrl_refresh_stats: recompute the stats of the current maps (reset kernel without a new map)
   const uint8_t *mask;
   const uint8_t *init_grids;

@@ -53,9 +53,11 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
   // compile-time specialised 16x16 kernels: cropped 32x32 window (reference default obs_window = 2 * map), or the
   // wide representation's whole-map observation
   const bool m16 = p.cfg.dims[0] == 16 && p.cfg.dims[1] == 16 && !p.ext;
-  const bool fast = m16 && (p.cfg.representation == PCGRL_REP_WIDE
-                                ? true
-                                : (p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32));
+  const bool fast_cfg = m16 && (p.cfg.representation == PCGRL_REP_WIDE
+                                    ? true
+                                    : (p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32));
+  // stale statistics (after pcgrl_update) are only handled by the general step / rollout kernels
+  const bool fast = fast_cfg && !(p.no_fast && (id == K_STEP || id == K_ROLLOUT) && !p.update_only);
   hipError_t e = hipSuccess;
   switch (id) {
     case K_STEP:

@@ -43,6 +43,7 @@ struct pcgrl_engine {
   int lpe = 16;
   size_t lds_bytes = 0;
   int cpl = 0;  // 3-D: cells per lane of the reset RNG split
+  bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
   int obs_ndim = 0;
   int32_t obs_shape[4] = {0, 0, 0, 0};
@@ -489,6 +490,7 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
   p.init_grids = d_init_grids;
   p.init_pos = d_init_pos;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  if (d_mask == nullptr) h->maybe_stale = false;
   return PCGRL_OK;
 }
 
@@ -497,6 +499,7 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step: bad arguments");
   ON_DEVICE(h->device);
   Params p = h->p;
+  p.no_fast = h->maybe_stale ? 1 : 0;
   p.actions = d_actions;
   p.auto_reset = auto_reset;
   p.obs = d_obs;
@@ -513,6 +516,7 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   ON_DEVICE(h->device);
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_step_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   Params p = h->p;
+  p.no_fast = h->maybe_stale ? 1 : 0;
   p.actions = d_actions;
   p.auto_reset = auto_reset;
   p.obs = d_obs;
@@ -532,6 +536,7 @@ int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int
   if (h->p.ext || h->p.cfg.n_ctrl > 0)
     return fail(PCGRL_EUNSUPPORTED, "pcgrl_rollout: plain mode only (no controls, no representation wrappers)");
   Params p = h->p;
+  p.no_fast = h->maybe_stale ? 1 : 0;
   p.actions = d_actions;
   p.n_steps = n_steps;
   p.auto_reset = auto_reset;
@@ -552,6 +557,7 @@ int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void 
   p.actions = d_actions;
   p.obs = d_obs;
   p.update_only = 1;
+  h->maybe_stale = true;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
@@ -563,6 +569,7 @@ int pcgrl_refresh_stats(pcgrl_handle h, int32_t *d_stats, void *stream) {
   p.refresh_only = 1;
   p.stats_out = d_stats;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  h->maybe_stale = false;
   return PCGRL_OK;
 }
 
@@ -753,6 +760,7 @@ int pcgrl_set_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_grid
   p.in_ep_return = d_ep_return;
   p.set_state = 1;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  if (d_mask == nullptr) h->maybe_stale = false;
   return PCGRL_OK;
 }
 

@@ -1584,8 +1584,14 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
     return;
   }
   // the statistics can only move if the map did (with static tiles a build may have been undone: change without edit)
-  const bool stale = (flags & ENV_STATS_DIRTY) != 0 && change && map_changed;  // after pcgrl_update: from scratch
-  if (__ballot(stale) != 0) {
+  // After pcgrl_update the statistics are stale (ENV_STATS_DIRTY): from scratch.  The compile-time 16x16 kernels carry
+  // no code for it (it costs them 4 % at large batches): while stale envs may exist the host launches the general kernel
+  // (Params::no_fast), which also drops the PREFLOOD plane it does not maintain.
+  const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change && map_changed;
+  if constexpr (PROB == PCGRL_PROB_BINARY && !FAST) {
+    if (p.no_fast && rowok) *pre_word = M(0);
+  }
+  if (!FAST && __ballot(stale) != 0) {
     int32_t ns[NS];
     compute_stats<PROB, LPE, M>(g, p, e, stale && active, b, colmask, ns);
     if (stale) {
@@ -1736,8 +1742,8 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds,
                                        p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes));
     } else {
-      const bool stale = (flags & ENV_STATS_DIRTY) != 0 && change;  // first changing step after pcgrl_update
-      if (__ballot(stale) != 0) {
+      const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change;  // first changing step after pcgrl_update
+      if (!FAST && __ballot(stale) != 0) {
         int32_t ns[NS];
         compute_stats<PROB, LPE, M>(g, p, e, stale && active, b, colmask, ns);
         if (stale) {

@@ -1,14 +1,22 @@
-// pcgrl_sokoban.h -- device-side Sokoban solver cascade (rare path of sokoban's get_stats).
+// pcgrl_sokoban.h -- device-side Sokoban solver cascade (sokoban's get_stats when a level is "playable").
 //
 // Reference: envs/probs/sokoban/sokoban_prob.py:99-148 (_run_game: BFS, then A* with balance 1, 0.5, 0, each
 // limited to `solver_power` iterations) and envs/probs/sokoban/sokoban/engine.py (Node :4-50, BFSAgent :56-74,
 // AStarAgent :96-119, State :121-363).  It only runs when a map has exactly one player, as many crates as targets
 // (> 0) and a single region (sokoban_prob.py:172-177) -- never under random actions, often under a trained policy.
 //
-// The search is inherently sequential and order dependent (FIFO queue; CPython heapq sift order with
-// Node.__lt__ = h + balance*depth; visited keyed on player + ordered crate list), so one lane per env walks it,
-// with its node pool / visited table / queue in an HBM workspace slot taken from a small lock-protected pool.
-// The other lanes of the wavefront idle meanwhile; other wavefronts are unaffected.
+// The search itself is sequential and order dependent (FIFO queue; CPython heapq sift order with
+// Node.__lt__ = h + balance*depth; visited keyed on player + ORDERED crate list), so nodes are expanded one at a
+// time -- but every per-node operation is spread over the wavefront that owns the env:
+//   lane k holds crate k (and k + 64) of the node being expanded: "which crate stands at (x, y)", the win test,
+//   the dead-cell count, the visited-set hash and key comparison, and the copy into a child node are one or two
+//   ballots / coalesced accesses each instead of loops over the crate list;
+//   lane t holds target t (and t + 64) for the greedy heuristic (engine.py:282-296): per crate one broadcast, one
+//   distance per lane and one wave arg-min, in list order (the order decides the matching);
+//   lane r holds level row r (then column r) while the dead-cell table is built (engine.py:203-246).
+// The open list stores (2h + 2*balance*depth) << 16 | node, so CPython's sift comparisons read no node records.
+// Node pool / visited table / open list live in an HBM workspace slot taken from a lock-protected pool sized to the
+// batch; a wavefront holds at most one slot at a time (no lock cycles however many envs need solving at once).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,16 +30,16 @@ namespace pcgrl {
 constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
 constexpr int SK_MAXDIM = 34;    // bordered level side (W+2, H+2 <= 34)
 constexpr int SK_VCAP = 1 << 15; // visited table slots (>= 2 x iterations per stage)
-constexpr int SK_MAX_POWER = SK_VCAP / 2;  // cfg.solver_power accepted by pcgrl_create
+constexpr int SK_MAX_POWER = 16000;  // cfg.solver_power accepted by pcgrl_create: node ids (<= 4 * power + 8) fit 16 bits
+constexpr uint32_t SK_NOCRATE = 0xFFFFu;
 
-struct SokoLevel {
+struct SokoLevel {  // LDS, one per workgroup (one solve at a time per simulate wave)
   int32_t w, h, ncr, ntg;
-  int32_t use_order, n_dead_cur;  // heuristic via the per-cell target order table; crates of the expanded node on dead cells
-  uint64_t solid[SK_MAXDIM], dead[SK_MAXDIM], tgt[SK_MAXDIM];
-  uint64_t occ[SK_MAXDIM];        // crate occupancy of the node being expanded
-  uint8_t tx[SK_MAXC], ty[SK_MAXC];
+  uint64_t solid[SK_MAXDIM + 2], dead[SK_MAXDIM + 2], tgt[SK_MAXDIM + 2];
+  uint16_t root[SK_MAXC];     // crates of the level in row-major order: x | y << 8 (engine.py:170-188)
+  uint16_t target[SK_MAXC];   // targets, same encoding
 };
-struct SokoNode {
+struct alignas(16) SokoNode {
   int32_t parent;
   int16_t depth, h;
   uint8_t px, py, pad[6];
@@ -49,441 +57,439 @@ struct SokoPool {  // lives in Params-reachable global memory
 struct SokoCtx {
   SokoLevel *lv;
   SokoNode *nodes;
-  uint8_t *crates;  // [max_nodes][2*SK_MAXC]
-  uint32_t *vis;    // [SK_VCAP]  (epoch << 17) | (node + 1)
-  int32_t *q;       // [max_nodes] BFS queue / A* heap / scratch
-  uint8_t *order;   // [SK_MAXDIM * SK_MAXDIM][SK_MAXC] targets sorted by (Manhattan distance, index) per cell
+  uint16_t *crates;  // [max_nodes][SK_MAXC]  x | y << 8 per crate
+  uint32_t *vis;     // [SK_VCAP]  (epoch << 17) | (node + 1)
+  uint32_t *q;       // [max_nodes] BFS queue (node) / A* heap (key << 16 | node)
   int32_t n_nodes, max_nodes, ncr;
   uint32_t epoch;
+  int lane;
+  bool pool_full;
 };
 
-__device__ inline uint8_t *sk_crates(const SokoCtx &c, int n) { return c.crates + (size_t)n * (2 * SK_MAXC); }
 __device__ inline bool sk_bit(const uint64_t *rows, int x, int y) { return (rows[y] >> x) & 1ull; }
 
-__device__ inline int sk_crate_at(const SokoCtx &c, const uint8_t *cr, int x, int y) {  // engine.py:263-267
-  for (int i = 0; i < c.ncr; i++)
-    if (cr[2 * i] == x && cr[2 * i + 1] == y) return i;
-  return -1;
+// minimum over the 64 lanes (result uniform): DPP butterfly inside the 16-lane rows, the four rows through SGPRs
+__device__ inline uint32_t sk_wave_min(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
 }
-__device__ inline bool sk_movable(const SokoCtx &c, const uint8_t *cr, int x, int y) {  // engine.py:254-255, :269-270
-  if (x < 0 || y < 0 || x > c.lv->w - 1 || y > c.lv->h - 1) return false;
-  if (sk_bit(c.lv->solid, x, y)) return false;
-  return sk_crate_at(c, cr, x, y) < 0;
-}
-__device__ inline bool sk_win(const SokoCtx &c, const uint8_t *cr) {  // engine.py:272-280
-  if (c.lv->ntg != c.ncr || c.ncr == 0) return false;
-  for (int t = 0; t < c.lv->ntg; t++)
-    if (sk_crate_at(c, cr, c.lv->tx[t], c.lv->ty[t]) < 0) return false;
-  return true;
-}
-// engine.py:282-296 getHeuristic: crates in list order greedily take the nearest remaining target (first minimum in
-// list order).  With many targets the scan over all targets per crate dominates the whole search, so levels with more
-// than 8 targets use a per-cell table of the targets sorted by (distance, index): the nearest REMAINING target is the
-// first unused entry of the crate cell's row -- the same choice, found without computing all distances.
-__device__ inline void sk_build_order(SokoCtx &c) {
-  SokoLevel *lv = c.lv;
-  const int nt = lv->ntg, maxd = lv->w + lv->h;
-  int32_t *cnt = c.q;  // scratch: maxd + 2 counters
-  for (int y = 1; y < lv->h - 1; y++)
-    for (int x = 1; x < lv->w - 1; x++) {
-      uint8_t *row = c.order + (size_t)(y * SK_MAXDIM + x) * SK_MAXC;
-      for (int d = 0; d <= maxd + 1; d++) cnt[d] = 0;
-      for (int t = 0; t < nt; t++) cnt[abs(x - (int)lv->tx[t]) + abs(y - (int)lv->ty[t]) + 1]++;
-      for (int d = 1; d <= maxd + 1; d++) cnt[d] += cnt[d - 1];
-      for (int t = 0; t < nt; t++) {  // stable: equal distances keep index order
-        int d = abs(x - (int)lv->tx[t]) + abs(y - (int)lv->ty[t]);
-        row[cnt[d]++] = (uint8_t)t;
-      }
-    }
+// xor over the 64 lanes (result uniform)
+__device__ inline uint32_t sk_wave_xor(uint32_t v) {
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-__device__ inline int sk_heuristic(const SokoCtx &c, const uint8_t *cr) {
-  uint64_t used0 = 0, used1 = 0;  // targets already matched (the reference deletes them from a list: order is preserved)
-  int distance = 0;
-  const int nt = c.lv->ntg;
-  if (c.lv->use_order) {
-    for (int k = 0; k < c.ncr; k++) {
-      const int cx = cr[2 * k], cy = cr[2 * k + 1];
-      const uint8_t *row = c.order + (size_t)(cy * SK_MAXDIM + cx) * SK_MAXC;
-      int r = 0, t = row[0];
-      while (((t < 64 ? used0 : used1) >> (t & 63)) & 1ull) t = row[++r];  // ncr == ntg: an unused target always exists
-      distance += abs((int)c.lv->tx[t] - cx) + abs((int)c.lv->ty[t] - cy);
-      if (t < 64) used0 |= 1ull << t; else used1 |= 1ull << (t & 63);
-    }
-    return distance;
+// The crate list of one node, spread over the wave: lane k holds crate k in c0 and crate k + 64 in c1.
+struct SkCrates {
+  uint32_t c0, c1;  // x | y << 8, SK_NOCRATE beyond the list
+  __device__ inline void load(const SokoCtx &c, int n) {
+    const uint16_t *src = c.crates + (size_t)n * SK_MAXC;
+    c0 = c.lane < c.ncr ? src[c.lane] : SK_NOCRATE;
+    c1 = c.lane + 64 < c.ncr ? src[c.lane + 64] : SK_NOCRATE;
   }
+  __device__ inline void store(const SokoCtx &c, int n) const {
+    uint16_t *dst = c.crates + (size_t)n * SK_MAXC;
+    if (c.lane < c.ncr) dst[c.lane] = (uint16_t)c0;
+    if (c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
+  }
+  // index of the crate standing at (x, y), -1 if none (engine.py:263-267)
+  __device__ inline int at(int x, int y) const {
+    const uint32_t key = (uint32_t)x | ((uint32_t)y << 8);
+    const uint64_t b0 = __ballot(c0 == key), b1 = __ballot(c1 == key);
+    return b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : -1);
+  }
+  // number of crates whose cell has its bit set in `rows`
+  __device__ inline int count_on(const uint64_t *rows) const {
+    const bool h0 = c0 != SK_NOCRATE && sk_bit(rows, c0 & 255, c0 >> 8), h1 = c1 != SK_NOCRATE && sk_bit(rows, c1 & 255, c1 >> 8);
+    return __popcll(__ballot(h0)) + __popcll(__ballot(h1));
+  }
+  __device__ inline uint32_t hash(int lane, int px, int py) const {
+    // position-dependent mix per crate, xor-combined over the wave (any function of the key will do: internal table)
+    uint32_t a = (c0 + 0x9E3779B9u * (uint32_t)(lane + 1)) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    uint32_t b = (c1 + 0x9E3779B9u * (uint32_t)(lane + 65)) * 0xC2B2AE35u;
+    b ^= b >> 13;
+    uint32_t h = sk_wave_xor(a ^ b);
+    h = (h ^ (uint32_t)px) * 16777619u;
+    h = (h ^ (uint32_t)py) * 16777619u;
+    return h ^ (h >> 16);
+  }
+  __device__ inline bool same(const SkCrates &o) const { return __ballot(c0 != o.c0 || c1 != o.c1) == 0; }
+};
+
+__device__ inline bool sk_free_cell(const SokoCtx &c, const SkCrates &cr, int x, int y) {  // checkMovableLocation :269-270
+  if (x < 0 || y < 0 || x > c.lv->w - 1 || y > c.lv->h - 1) return false;
+  return !sk_bit(c.lv->solid, x, y) && cr.at(x, y) < 0;
+}
+
+// engine.py:282-296 getHeuristic: crates in list order greedily take the nearest remaining target (first minimum in
+// list order).  Lane t holds targets t and t + 64; per crate: broadcast its cell, one distance per lane, wave arg-min.
+__device__ inline int sk_heuristic(const SokoCtx &c, const SkCrates &cr) {
+  const int nt = c.lv->ntg;
+  const uint32_t t0 = c.lane < nt ? c.lv->target[c.lane] : SK_NOCRATE, t1 = c.lane + 64 < nt ? c.lv->target[c.lane + 64] : SK_NOCRATE;
+  bool u0 = t0 == SK_NOCRATE, u1 = t1 == SK_NOCRATE;  // "used" (absent targets never match)
+  int distance = 0;
   for (int k = 0; k < c.ncr; k++) {
-    int best = c.lv->w + c.lv->h, match = -1, first_free = -1;
-    for (int i = 0; i < nt; i++) {
-      if (((i < 64 ? used0 : used1) >> (i & 63)) & 1ull) continue;
-      if (first_free < 0) first_free = i;
-      int d = abs((int)cr[2 * k] - (int)c.lv->tx[i]) + abs((int)cr[2 * k + 1] - (int)c.lv->ty[i]);
-      if (best > d) {
-        match = i;
-        best = d;
-      }
-    }
-    if (match < 0) match = first_free;  // bestMatch = 0 default: first remaining target
-    distance += abs((int)c.lv->tx[match] - (int)cr[2 * k]) + abs((int)c.lv->ty[match] - (int)cr[2 * k + 1]);
-    if (match < 64) used0 |= 1ull << match; else used1 |= 1ull << (match & 63);
+    const uint32_t ck = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, k) : (uint32_t)__builtin_amdgcn_readlane((int)cr.c1, k - 64);
+    const int cx = ck & 255, cy = ck >> 8;
+    const uint32_t d0 = u0 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t0 & 255)) + abs(cy - (int)(t0 >> 8)));
+    const uint32_t d1 = u1 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t1 & 255)) + abs(cy - (int)(t1 >> 8)));
+    const uint32_t k0 = (d0 << 8) | (uint32_t)c.lane, k1 = (d1 << 8) | (uint32_t)(c.lane + 64);
+    const uint32_t best = sk_wave_min(min(k0, k1));  // smallest distance, then smallest index: the first minimum
+    distance += (int)(best >> 8);  // (ncr == ntg: an unused target always exists; the distance is < w + h)
+    const int t = best & 255;
+    u0 = u0 || t == c.lane;
+    u1 = u1 || t == c.lane + 64;
   }
   return distance;
 }
-__device__ inline bool sk_deadlock(const SokoCtx &c, const uint8_t *cr) {  // engine.py:248-252
-  for (int k = 0; k < c.ncr; k++)
-    if (sk_bit(c.lv->dead, cr[2 * k], cr[2 * k + 1])) return true;
-  return false;
-}
 
-// engine.py:203-246 intializeDeadlocks (corner list kept in the queue scratch)
+// engine.py:203-246 intializeDeadlocks.  A free, non-target cell in a corner of walls is dead; so is every cell strictly
+// between two such corners of one row (column) when all cells between them are free, non-target and walled on at
+// least one side -- i.e. inside a maximal run of such cells (corners are such cells themselves) everything between the
+// first and the last corner is dead.  Lane r owns row r, then column r: shifts and scans in registers.
 __device__ inline void sk_init_deadlocks(SokoCtx &c) {
   SokoLevel *lv = c.lv;
-  const int w = lv->w, h = lv->h;
-  int nc = 0;
-  for (int y = 0; y < h; y++) lv->dead[y] = 0;
-#define SOL(x, y) sk_bit(lv->solid, (x), (y))
-#define TGT(x, y) sk_bit(lv->tgt, (x), (y))
-  for (int y = 0; y < h; y++)
-    for (int x = 0; x < w; x++) {
-      if (x == 0 || y == 0 || x == w - 1 || y == h - 1 || SOL(x, y)) continue;
-      if ((SOL(x, y - 1) && SOL(x - 1, y)) || (SOL(x, y - 1) && SOL(x + 1, y)) || (SOL(x, y + 1) && SOL(x - 1, y)) ||
-          (SOL(x, y + 1) && SOL(x + 1, y))) {
-        if (!TGT(x, y)) {
-          c.q[nc++] = x | (y << 8);
-          lv->dead[y] |= 1ull << x;
-        }
+  const int w = lv->w, h = lv->h, r = c.lane;
+  const bool inner = r >= 1 && r < h - 1;
+  // between(E, C): for every maximal run of set bits of E, the bits from the run's first to its last C bit
+  auto between = [](uint64_t E, uint64_t C, int n) -> uint64_t {
+    uint64_t out = 0, span = 0;
+    bool open = false;  // a corner was seen in the current run
+    for (int x = 0; x < n; x++) {
+      const uint64_t bit = 1ull << x;
+      if (!(E & bit)) {
+        open = false;
+        span = 0;
+        continue;
       }
-    }
-  for (int a = 0; a < nc; a++)
-    for (int b = 0; b < nc; b++) {
-      int ax = c.q[a] & 255, ay = c.q[a] >> 8, bx = c.q[b] & 255, by = c.q[b] >> 8;
-      int dx = (ax > bx) - (ax < bx), dy = (ay > by) - (ay < by);
-      if ((dx == 0 && dy == 0) || (dx != 0 && dy != 0)) continue;
-      int x = bx, y = by;
-      bool ok = true;
-      if (dx != 0) {
-        for (x += dx; x != ax; x += dx)
-          if (TGT(x, y) || SOL(x, y) || (!SOL(x, y - 1) && !SOL(x, y + 1))) {
-            ok = false;
-            break;
-          }
-        if (ok)
-          for (x = bx + dx; x != ax; x += dx) lv->dead[y] |= 1ull << x;
-      } else {
-        for (y += dy; y != ay; y += dy)
-          if (TGT(x, y) || SOL(x, y) || (!SOL(x - 1, y) && !SOL(x + 1, y))) {
-            ok = false;
-            break;
-          }
-        if (ok)
-          for (y = by + dy; y != ay; y += dy) lv->dead[y] |= 1ull << x;
+      if (C & bit) {
+        if (open) out |= span | bit;
+        open = true;
+        span = 0;
       }
+      span |= open ? bit : 0ull;
     }
-#undef SOL
-#undef TGT
+    return out;
+  };
+  // rows
+  const uint64_t sol = inner ? lv->solid[r] : ~0ull, up = inner ? lv->solid[r - 1] : ~0ull, dn = inner ? lv->solid[r + 1] : ~0ull;
+  const uint64_t tg = inner ? lv->tgt[r] : 0ull;
+  const uint64_t lf = sol << 1, rt = sol >> 1;  // wall to the left / right of each cell
+  const uint64_t colmask = ((1ull << (w - 1)) - 1ull) & ~1ull;  // inner columns 1 .. w-2
+  const uint64_t corner = inner ? (~sol & ~tg & ((up & lf) | (up & rt) | (dn & lf) | (dn & rt)) & colmask) : 0ull;
+  const uint64_t Eh = inner ? (~sol & ~tg & (up | dn) & colmask) : 0ull;
+  uint64_t dead = corner | between(Eh, corner, w);
+  // columns: lane x gathers column x of the masks (bit y = row y)
+  uint64_t csol = 0, ctg = 0, ccor = 0, csl = 0, csr = 0;
+  for (int y = 0; y < h; y++) {
+    const uint64_t s = lv->solid[y], t = lv->tgt[y];
+    const uint32_t clo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)corner, y), chi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(corner >> 32), y);
+    const uint64_t cr = (uint64_t)clo | ((uint64_t)chi << 32);
+    const int x = r;
+    csol |= ((s >> x) & 1ull) << y;
+    ctg |= ((t >> x) & 1ull) << y;
+    ccor |= ((cr >> x) & 1ull) << y;
+    csl |= (x >= 1 ? (s >> (x - 1)) & 1ull : 1ull) << y;  // wall in column x-1 / x+1 at this row
+    csr |= (x < 63 ? (s >> (x + 1)) & 1ull : 0ull) << y;
+  }
+  const bool innerc = r >= 1 && r < w - 1;
+  const uint64_t rowmask = ((1ull << (h - 1)) - 1ull) & ~1ull;
+  const uint64_t Ev = innerc ? (~csol & ~ctg & (csl | csr) & rowmask) : 0ull;
+  const uint64_t vspan = innerc ? between(Ev, ccor, h) : 0ull;
+  // transpose the column spans back into row masks
+  for (int y = 0; y < h; y++) {
+    const uint64_t rowbits = __ballot((vspan >> y) & 1ull);
+    if (r == y) dead |= rowbits;
+  }
+  if (r < h) lv->dead[r] = dead;
 }
 
-__device__ inline uint32_t sk_hash(const SokoCtx &c, int n) {
-  const uint8_t *cr = sk_crates(c, n);
-  uint32_t h = 2166136261u;
-  h = (h ^ c.nodes[n].px) * 16777619u;
-  h = (h ^ c.nodes[n].py) * 16777619u;
-  // 8 bytes at a time: the crate lists are 256-byte aligned and zero-padded to a multiple of 8 bytes (root: see
-  // sokoban_solve; children copy whole words), so equal keys hash and compare equal word by word
-  const uint64_t *w = (const uint64_t *)cr;
-  for (int i = 0; i < (2 * c.ncr + 7) / 8; i++) {
-    const uint64_t v = w[i];
-    h = (h ^ (uint32_t)v) * 16777619u;
-    h = (h ^ (uint32_t)(v >> 32)) * 16777619u;
-  }
-  return h;
-}
-__device__ inline bool sk_same_key(const SokoCtx &c, int a, int b) {  // State.getKey engine.py:330-336
-  if (c.nodes[a].px != c.nodes[b].px || c.nodes[a].py != c.nodes[b].py) return false;
-  const uint64_t *ca = (const uint64_t *)sk_crates(c, a), *cb = (const uint64_t *)sk_crates(c, b);
-  for (int i = 0; i < (2 * c.ncr + 7) / 8; i++)
-    if (ca[i] != cb[i]) return false;
-  return true;
-}
-// returns true if node n's key was already in the visited set; inserts it otherwise
-__device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n) {
-  uint32_t i = sk_hash(c, n) & (SK_VCAP - 1);
+// returns true if the state (px, py, cr) was already in the visited set; inserts node n otherwise
+__device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py, const SkCrates &cr) {
+  uint32_t i = cr.hash(c.lane, px, py) & (SK_VCAP - 1);
   while (true) {
-    uint32_t e = c.vis[i];
+    const uint32_t e = c.vis[i];
     if ((e >> 17) != c.epoch || (e & 0x1FFFFu) == 0) {
-      c.vis[i] = (c.epoch << 17) | (uint32_t)(n + 1);
+      if (c.lane == 0) c.vis[i] = (c.epoch << 17) | (uint32_t)(n + 1);
       return false;
     }
-    if (sk_same_key(c, (int)(e & 0x1FFFFu) - 1, n)) return true;
+    const int m = (int)(e & 0x1FFFFu) - 1;
+    if (c.nodes[m].px == px && c.nodes[m].py == py) {  // State.getKey engine.py:330-336
+      SkCrates o;
+      o.load(c, m);
+      if (cr.same(o)) return true;
+    }
     i = (i + 1) & (SK_VCAP - 1);
   }
 }
 
-// crate occupancy of node n as row bit masks, and how many of its crates stand on dead cells
-__device__ inline void sk_load_occupancy(SokoCtx &c, int n) {
-  SokoLevel *lv = c.lv;
-  for (int y = 0; y < lv->h; y++) lv->occ[y] = 0;
-  const uint8_t *cr = sk_crates(c, n);
-  int nd = 0;
-  for (int k = 0; k < c.ncr; k++) {
-    lv->occ[cr[2 * k + 1]] |= 1ull << cr[2 * k];
-    nd += sk_bit(lv->dead, cr[2 * k], cr[2 * k + 1]) ? 1 : 0;
-  }
-  lv->n_dead_cur = nd;
-}
-__device__ inline bool sk_win_occ(const SokoCtx &c) {  // engine.py:272-280 on the occupancy masks
-  if (c.lv->ntg != c.ncr || c.ncr == 0) return false;
-  for (int y = 0; y < c.lv->h; y++)
-    if (c.lv->tgt[y] & ~c.lv->occ[y]) return false;
-  return true;
-}
-
-// Node.getChildren engine.py:14-25 + State.update :298-328 (the expanded node's occupancy is loaded)
-__device__ inline int sk_children(SokoCtx &c, int n, int *out) {
-  const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
-  const SokoLevel *lv = c.lv;
-  int cnt = 0;
-  const uint8_t *cr = sk_crates(c, n);
-  const int px = c.nodes[n].px, py = c.nodes[n].py;
-  auto free_cell = [&](int x, int y) {  // checkMovableLocation :269-270
-    if (x < 0 || y < 0 || x > lv->w - 1 || y > lv->h - 1) return false;
-    return !sk_bit(lv->solid, x, y) && !sk_bit(lv->occ, x, y);
-  };
-  for (int d = 0; d < 4; d++) {
-    int nx = px + DX[d], ny = py + DY[d];
-    int moved = -1;
-    if (!free_cell(nx, ny)) {
-      if (nx < 0 || ny < 0 || nx > lv->w - 1 || ny > lv->h - 1 || !sk_bit(lv->occ, nx, ny)) continue;
-      if (!free_cell(nx + DX[d], ny + DY[d])) continue;
-      moved = sk_crate_at(c, cr, nx, ny);
-    }
-    if (c.n_nodes >= c.max_nodes) continue;  // cannot happen: <= 1 + 4 * iterations nodes per stage
-    if (moved >= 0) {  // engine.py:22-23 checkDeadlock over all crates of the child
-      int nd = lv->n_dead_cur - (sk_bit(lv->dead, nx, ny) ? 1 : 0) + (sk_bit(lv->dead, nx + DX[d], ny + DY[d]) ? 1 : 0);
-      if (nd > 0) continue;
-    }
-    int k = c.n_nodes++;
-    uint8_t *ncr = sk_crates(c, k);
-    for (int i = 0; i < (2 * c.ncr + 7) / 8; i++) ((uint64_t *)ncr)[i] = ((const uint64_t *)cr)[i];
-    if (moved >= 0) {
-      ncr[2 * moved] = (uint8_t)(nx + DX[d]);
-      ncr[2 * moved + 1] = (uint8_t)(ny + DY[d]);
-    }
-    c.nodes[k].parent = n;
-    c.nodes[k].depth = (int16_t)(c.nodes[n].depth + 1);
-    c.nodes[k].px = (uint8_t)nx;
-    c.nodes[k].py = (uint8_t)ny;
-    c.nodes[k].h = moved >= 0 ? (int16_t)sk_heuristic(c, ncr) : c.nodes[n].h;  // h depends on the crates only
-    out[cnt++] = k;
-  }
-  return cnt;
-}
-
-__device__ inline bool sk_better(const SokoCtx &c, int cur, int best) {  // engine.py:66-69
-  if (best < 0) return true;
-  if (c.nodes[cur].h < c.nodes[best].h) return true;
-  return c.nodes[cur].h == c.nodes[best].h && c.nodes[cur].depth < c.nodes[best].depth;
-}
-
-// stage: balance < 0 -> BFSAgent (engine.py:56-74); else AStarAgent with that balance (engine.py:96-119)
-__device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, double balance, int max_iter, int &res_h, int &res_depth,
+// stage: b2 < 0 -> BFSAgent (engine.py:56-74); else AStarAgent with balance b2 / 2 (engine.py:96-119).  Uniform over
+// the wave.  Node 0 = root, already filled by the caller.
+__device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
                                 bool *exhausted = nullptr) {
-  c.epoch = (atomicAdd(&pool.epochs[slot], 1u) + 1u) & 0x7FFFu;
-  if (c.epoch == 0) {  // wrapped: start over with a clean table
-    for (int i = 0; i < SK_VCAP; i++) c.vis[i] = 0;
-    c.epoch = (atomicAdd(&pool.epochs[slot], 1u) + 1u) & 0x7FFFu;
+  uint32_t ep = 0;
+  if (c.lane == 0) ep = (atomicAdd(&pool.epochs[slot], 1u) + 1u) & 0x7FFFu;
+  ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+  if (ep == 0) {  // wrapped: start over with a clean table
+    for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = 0;
+    if (c.lane == 0) ep = (atomicAdd(&pool.epochs[slot], 1u) + 1u) & 0x7FFFu;
+    ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
   }
-  c.n_nodes = 1;  // node 0 = root, already filled by the caller
-  int head = 0, tail = 0, best = -1, iters = 0;
-  auto lt = [&](int a, int b) {  // Node.__lt__ engine.py:49-50
-    return (double)c.nodes[a].h + balance * (double)c.nodes[a].depth < (double)c.nodes[b].h + balance * (double)c.nodes[b].depth;
-  };
-  auto siftdown = [&](int startpos, int pos) {  // heapq._siftdown
-    int item = c.q[pos];
+  c.epoch = ep;
+  c.n_nodes = 1;
+  const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
+  int head = 0, tail = 0, best = -1, best_h = 0, best_depth = 0, iters = 0;
+  // Node.__lt__ engine.py:49-50 on the keys kept in the heap entries: h + balance*depth <=> 2h + b2*depth
+  auto lt = [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); };
+  auto siftdown = [&](int startpos, int pos, uint32_t item) {  // heapq._siftdown of `item` placed at `pos`
     while (pos > startpos) {
-      int pp = (pos - 1) >> 1, parent = c.q[pp];
+      const int pp = (pos - 1) >> 1;
+      const uint32_t parent = c.q[pp];
       if (lt(item, parent)) {
-        c.q[pos] = parent;
+        if (c.lane == 0) c.q[pos] = parent;
         pos = pp;
         continue;
       }
       break;
     }
-    c.q[pos] = item;
+    if (c.lane == 0) c.q[pos] = item;
   };
-  c.q[tail++] = 0;
+  const int h_root = c.nodes[0].h;
+  if (c.lane == 0) c.q[0] = b2 < 0 ? 0u : ((uint32_t)(2 * h_root) << 16);
+  tail = 1;
   while (iters < max_iter && head < tail) {
     iters++;
     int cur;
-    if (balance < 0) {
-      cur = c.q[head++];  // queue.pop(0)
-    } else {              // heapq.heappop
-      int last = c.q[--tail];
+    if (b2 < 0) {
+      cur = (int)c.q[head++];  // queue.pop(0)
+    } else {                   // heapq.heappop
+      const uint32_t last = c.q[--tail];
       if (tail > 0) {
-        cur = c.q[0];
-        c.q[0] = last;
+        cur = (int)(c.q[0] & 0xFFFFu);
         int pos = 0, child = 1;
         while (child < tail) {
-          int right = child + 1;
-          if (right < tail && !lt(c.q[child], c.q[right])) child = right;
-          c.q[pos] = c.q[child];
+          const int right = child + 1;
+          const uint32_t lc = c.q[child];
+          uint32_t pick = lc;
+          if (right < tail) {
+            const uint32_t rc = c.q[right];
+            if (!lt(lc, rc)) {
+              child = right;
+              pick = rc;
+            }
+          }
+          if (c.lane == 0) c.q[pos] = pick;
           pos = child;
           child = 2 * pos + 1;
         }
-        c.q[pos] = last;
-        siftdown(0, pos);
+        siftdown(0, pos, last);
       } else {
-        cur = last;
+        cur = (int)(last & 0xFFFFu);
       }
     }
-    sk_load_occupancy(c, cur);
-    if (sk_win_occ(c)) {
-      res_h = c.nodes[cur].h;
-      res_depth = c.nodes[cur].depth;
+    const SokoNode nd = c.nodes[cur];
+    const int px = nd.px, py = nd.py;
+    SkCrates cr;
+    cr.load(c, cur);
+    if (c.lv->ntg == c.ncr && c.ncr > 0 && cr.count_on(c.lv->tgt) == c.ncr) {  // checkWin engine.py:272-280
+      res_h = nd.h;
+      res_depth = nd.depth;
       return true;
     }
-    if (!sk_visited_test_and_set(c, cur)) {
-      if (sk_better(c, cur, best)) best = cur;
-      int ch[4];
-      int nc = sk_children(c, cur, ch);
-      for (int i = 0; i < nc; i++) {
-        c.q[tail++] = ch[i];
-        if (balance >= 0) siftdown(0, tail - 1);  // heapq.heappush
+    if (!sk_visited_test_and_set(c, cur, px, py, cr)) {
+      if (best < 0 || nd.h < best_h || (nd.h == best_h && nd.depth < best_depth)) {  // engine.py:66-69
+        best = cur;
+        best_h = nd.h;
+        best_depth = nd.depth;
+      }
+      const int n_dead = cr.count_on(c.lv->dead);
+      // Node.getChildren engine.py:14-25 + State.update :298-328
+      for (int d = 0; d < 4; d++) {
+        const int nx = px + DX[d], ny = py + DY[d];
+        if (nx < 0 || ny < 0 || nx > c.lv->w - 1 || ny > c.lv->h - 1 || sk_bit(c.lv->solid, nx, ny)) continue;
+        const int moved = cr.at(nx, ny);
+        SkCrates ch = cr;
+        int h = nd.h;  // the heuristic depends on the crates only
+        if (moved >= 0) {
+          const int bx = nx + DX[d], by = ny + DY[d];
+          if (!sk_free_cell(c, cr, bx, by)) continue;
+          // engine.py:22-23 checkDeadlock over all crates of the child
+          const int ndead = n_dead - (sk_bit(c.lv->dead, nx, ny) ? 1 : 0) + (sk_bit(c.lv->dead, bx, by) ? 1 : 0);
+          if (ndead > 0) continue;
+          const uint32_t np = (uint32_t)bx | ((uint32_t)by << 8);
+          if (moved < 64) ch.c0 = c.lane == moved ? np : ch.c0;
+          else ch.c1 = c.lane == moved - 64 ? np : ch.c1;
+          h = sk_heuristic(c, ch);
+        }
+        if (c.n_nodes >= c.max_nodes) {  // cannot happen (<= 1 + 4 * iterations nodes per stage); reported if it does
+          c.pool_full = true;
+          continue;
+        }
+        const int k = c.n_nodes++;
+        ch.store(c, k);
+        if (c.lane == 0) {
+          SokoNode nn;
+          nn.parent = cur;
+          nn.depth = (int16_t)(nd.depth + 1);
+          nn.h = (int16_t)h;
+          nn.px = (uint8_t)nx;
+          nn.py = (uint8_t)ny;
+          c.nodes[k] = nn;
+        }
+        const uint32_t item = b2 < 0 ? (uint32_t)k : (((uint32_t)(2 * h + b2 * (nd.depth + 1)) << 16) | (uint32_t)k);
+        if (b2 < 0) {
+          if (c.lane == 0) c.q[tail] = item;
+          tail++;
+        } else {
+          tail++;
+          siftdown(0, tail - 1, item);  // heapq.heappush
+        }
       }
     }
   }
-  res_h = c.nodes[best].h;
-  res_depth = c.nodes[best].depth;
+  res_h = best_h;
+  res_depth = best_depth;
   if (exhausted) *exhausted = head >= tail;  // the open list ran dry: every reachable state was expanded
   return false;
 }
 
 // Called by every lane of the wave in uniform control flow; `need` is uniform per group.  Groups that need the
-// solver are served one after the other, so a wavefront holds at most one workspace slot at a time and never waits
-// for a slot while holding one (no lock cycles however many envs need solving at once).
+// solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
+// and never waits for a slot while holding one.
 template <int LPE>
-__device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
-                              uint32_t crate, uint32_t target, int &dist_win, int &sol_len) {
+__device__ __attribute__((noinline)) void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid,
+                                                        uint32_t player, uint32_t crate, uint32_t target, int &dist_win, int &sol_len) {
   (void)env;
   const SokoPool &pool = *(const SokoPool *)p.soko;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   constexpr int EPW = 64 / LPE;
-  // one simulate wave per workgroup calls the solver, and it serves its groups one after the other
   __shared__ SokoLevel s_level;
   for (int gi = 0; gi < EPW; gi++) {
     const bool mine = need && (g.lane / LPE) == gi;
     if (__ballot(mine) == 0) continue;
-    const bool leader = mine && g.row == 0;
-    int slot = -1;
     SokoCtx c;
-    c.lv = nullptr;
-    if (leader) {
+    c.lv = &s_level;
+    c.lane = g.lane;
+    c.pool_full = false;
+    // take a workspace slot (lane 0; the slot index is broadcast)
+    int slot = 0;
+    if (g.lane == 0) {
       int s = (int)((blockIdx.x * 7u + gi) % (unsigned)pool.n_slots);
       while (atomicCAS(&pool.locks[s], 0, 1) != 0) {
         s = (s + 1) % pool.n_slots;
         __builtin_amdgcn_s_sleep(8);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       slot = s;
+    }
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
       uint8_t *b = pool.base + (size_t)slot * pool.slot_bytes;
       c.max_nodes = pool.max_nodes;
-      c.lv = &s_level;  // the level description (wall / dead / target / occupancy rows) is the hottest data: LDS
-      b += (sizeof(SokoLevel) + 15) & ~(size_t)15;
       c.nodes = (SokoNode *)b;
       b += sizeof(SokoNode) * (size_t)c.max_nodes;
-      c.crates = b;
-      b += (size_t)c.max_nodes * 2 * SK_MAXC;
+      c.crates = (uint16_t *)b;
+      b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
       c.vis = (uint32_t *)b;
       b += sizeof(uint32_t) * SK_VCAP;
-      c.q = (int32_t *)b;
-      b += sizeof(int32_t) * (size_t)c.max_nodes;
-      c.order = b;
-      c.lv->w = W + 2;
-      c.lv->h = H + 2;
-      const uint64_t full = (1ull << (W + 2)) - 1ull;
-      c.lv->solid[0] = full;  // sokoban_prob.py:107-124: one-tile solid border around the map
-      c.lv->solid[H + 1] = full;
-      c.lv->tgt[0] = 0;
-      c.lv->tgt[H + 1] = 0;
+      c.q = (uint32_t *)b;
     }
-    // gather the rows from their lanes (uniform control flow); level coords = map coords + 1
+    // the level: the group's rows are broadcast to the wave; level coords = map coords + 1 (sokoban_prob.py:107-124:
+    // one-tile solid border around the map); crates / targets are listed in row-major order (engine.py:170-188)
+    const uint64_t full = (1ull << (W + 2)) - 1ull;
     int px = 0, py = 0, ncr = 0, ntg = 0;
-    bool too_big = false;
+    if (g.lane == 0) {
+      s_level.w = W + 2;
+      s_level.h = H + 2;
+      s_level.solid[0] = full;
+      s_level.solid[H + 1] = full;
+      s_level.tgt[0] = 0;
+      s_level.tgt[H + 1] = 0;
+    }
     for (int r = 0; r < H; r++) {
-      uint32_t sm = g.gbcast(solid, r), pl = g.gbcast(player, r), cr = g.gbcast(crate, r), tg = g.gbcast(target, r);
-      if (leader) {
-        c.lv->solid[r + 1] = ((uint64_t)sm << 1) | 1ull | (1ull << (W + 1));
-        c.lv->tgt[r + 1] = (uint64_t)tg << 1;
-        if (pl) {
-          px = __builtin_ctz(pl) + 1;
-          py = r + 1;
-        }
-        while (cr) {  // crates / targets are listed in row-major order (engine.py:170-188)
-          int x = __builtin_ctz(cr);
-          cr &= cr - 1;
-          if (ncr < SK_MAXC) {
-            c.crates[2 * ncr] = (uint8_t)(x + 1);  // node 0 = root
-            c.crates[2 * ncr + 1] = (uint8_t)(r + 1);
-          } else {
-            too_big = true;
-          }
-          ncr++;
-        }
-        while (tg) {
-          int x = __builtin_ctz(tg);
-          tg &= tg - 1;
-          if (ntg < SK_MAXC) {
-            c.lv->tx[ntg] = (uint8_t)(x + 1);
-            c.lv->ty[ntg] = (uint8_t)(r + 1);
-          }
-          ntg++;
-        }
+      const int src = gi * LPE + r;
+      const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)solid, src), pl = (uint32_t)__builtin_amdgcn_readlane((int)player, src);
+      const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crate, src), tg = (uint32_t)__builtin_amdgcn_readlane((int)target, src);
+      if (g.lane == 0) {
+        s_level.solid[r + 1] = ((uint64_t)sm << 1) | 1ull | (1ull << (W + 1));
+        s_level.tgt[r + 1] = (uint64_t)tg << 1;
       }
+      if (pl) {
+        px = __builtin_ctz(pl) + 1;
+        py = r + 1;
+      }
+      // lane j (< 32) owns bit j of the row: list entry = count so far + rank of the bit
+      const uint32_t below = g.lane < 32 ? ((1u << g.lane) - 1u) : 0u;
+      if (g.lane < 32 && ((cr >> g.lane) & 1u)) {
+        const int k = ncr + __popc(cr & below);
+        if (k < SK_MAXC) s_level.root[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
+      }
+      if (g.lane < 32 && ((tg >> g.lane) & 1u)) {
+        const int k = ntg + __popc(tg & below);
+        if (k < SK_MAXC) s_level.target[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
+      }
+      ncr += __popc(cr);
+      ntg += __popc(tg);
     }
     int dw = dist_win, sl = sol_len;
-    if (leader) {
-      if (too_big || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {
-        atomicOr(p.err, 2);  // beyond the device solver's limits: reported by pcgrl_poll_error
-      } else {
-        c.ncr = ncr;
-        for (int i = 2 * ncr; i < ((2 * ncr + 7) / 8) * 8; i++) c.crates[i] = 0;  // zero padding of the root's crate list
-        c.lv->ncr = ncr;
-        c.lv->ntg = ntg;
-        sk_init_deadlocks(c);
-        c.lv->use_order = ntg > 8 ? 1 : 0;
-        if (c.lv->use_order) sk_build_order(c);
-        c.nodes[0].parent = -1;
-        c.nodes[0].depth = 0;
-        c.nodes[0].px = (uint8_t)px;
-        c.nodes[0].py = (uint8_t)py;
-        c.nodes[0].h = (int16_t)sk_heuristic(c, sk_crates(c, 0));
-        int h = 0, depth = 0;
-        const int power = p.cfg.solver_power;
-        // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
-        // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
-        // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
-        // three A* stages is therefore exact (pinned by tests/golden/stats_sokoban_solver.npz against the reference).
-        bool exhausted = false;
-        bool won = sk_stage(c, pool, slot, -1.0, power, h, depth, &exhausted);
-        if (!won && !exhausted)
-          won = sk_stage(c, pool, slot, 1.0, power, h, depth) || sk_stage(c, pool, slot, 0.5, power, h, depth) ||
-                sk_stage(c, pool, slot, 0.0, power, h, depth);
-        if (won) {
-          dw = 0;
-          sl = depth;
-        } else {
-          dw = h;  // heuristic of the last stage's best node (sokoban_prob.py:147)
-          sl = 0;
-        }
+    if (ncr > SK_MAXC || ntg > SK_MAXC || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {
+      if (g.lane == 0) atomicOr(p.err, 2);  // beyond the device solver's limits: reported by pcgrl_poll_error
+    } else {
+      c.ncr = ncr;
+      if (g.lane == 0) {
+        s_level.ncr = ncr;
+        s_level.ntg = ntg;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      atomicExch(&pool.locks[slot], 0);
+      sk_init_deadlocks(c);
+      SkCrates root;
+      root.c0 = g.lane < ncr ? s_level.root[g.lane] : SK_NOCRATE;
+      root.c1 = g.lane + 64 < ncr ? s_level.root[g.lane + 64] : SK_NOCRATE;
+      root.store(c, 0);
+      const int h0 = sk_heuristic(c, root);
+      if (g.lane == 0) {
+        SokoNode n0;
+        n0.parent = -1;
+        n0.depth = 0;
+        n0.h = (int16_t)h0;
+        n0.px = (uint8_t)px;
+        n0.py = (uint8_t)py;
+        c.nodes[0] = n0;
+      }
+      int h = 0, depth = 0;
+      const int power = p.cfg.solver_power;
+      // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
+      // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
+      // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
+      // three A* stages is therefore exact (pinned by tests/golden/stats_sokoban_solver.npz against the reference).
+      bool exhausted = false;
+      bool won = sk_stage(c, pool, slot, -1, power, h, depth, &exhausted);
+      if (!won && !exhausted)
+        won = sk_stage(c, pool, slot, 2, power, h, depth) || sk_stage(c, pool, slot, 1, power, h, depth) ||
+              sk_stage(c, pool, slot, 0, power, h, depth);
+      if (won) {
+        dw = 0;
+        sl = depth;
+      } else {
+        dw = h;  // heuristic of the last stage's best node (sokoban_prob.py:147)
+        sl = 0;
+      }
+      if (c.pool_full && g.lane == 0) atomicOr(p.err, 2);
     }
-    // hand the leader's result to its group
-    int bdw = (int)g.gbcast((uint32_t)dw, 0), bsl = (int)g.gbcast((uint32_t)sl, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (g.lane == 0) atomicExch(&pool.locks[slot], 0);
     if (mine) {
-      dist_win = bdw;
-      sol_len = bsl;
+      dist_win = dw;
+      sol_len = sl;
     }
   }
 }
@@ -491,19 +497,20 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
 // ---------------------------------------------------------------------------------------------- host side
 static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs) {
   SokoPool pool;
-  pool.n_slots = p.n_envs < 64 ? p.n_envs : 64;
+  // one workspace slot per env of the batch up to 256 (a slot is ~11 MB at the default solver_power: the 288 GB of HBM are
+  // there to be used); never fewer than 64 (pcgrl_stats_for_grids_h serves any number of maps from a small engine)
+  pool.n_slots = p.n_envs < 64 ? 64 : (p.n_envs > 256 ? 256 : p.n_envs);
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
-  if (pool.max_nodes > 0x1FFFE) pool.max_nodes = 0x1FFFE;  // 17-bit node ids in the visited table
-  size_t sz = (sizeof(SokoLevel) + 15) & ~(size_t)15;
-  sz += sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * 2 * SK_MAXC;
-  sz += sizeof(uint32_t) * SK_VCAP + sizeof(int32_t) * (size_t)pool.max_nodes;
-  sz += (size_t)SK_MAXDIM * SK_MAXDIM * SK_MAXC;  // per-cell target order table
+  const size_t vis_off = sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
+  size_t sz = vis_off + sizeof(uint32_t) * SK_VCAP + sizeof(uint32_t) * (size_t)pool.max_nodes;
   pool.slot_bytes = (sz + 255) & ~(size_t)255;
   hipError_t e;
   void *base = nullptr, *locks = nullptr, *epochs = nullptr, *dpool = nullptr;
   if ((e = hipMalloc(&base, pool.slot_bytes * pool.n_slots)) != hipSuccess) return e;
   allocs.push_back(base);
-  if ((e = hipMemset(base, 0, pool.slot_bytes * pool.n_slots)) != hipSuccess) return e;
+  // only the visited tables need a defined start (entries carry the epoch of the stage that wrote them; 0 = empty)
+  for (int s = 0; s < pool.n_slots; s++)
+    if ((e = hipMemsetAsync((uint8_t *)base + (size_t)s * pool.slot_bytes + vis_off, 0, sizeof(uint32_t) * SK_VCAP, 0)) != hipSuccess) return e;
   if ((e = hipMalloc(&locks, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
   allocs.push_back(locks);
   if ((e = hipMemset(locks, 0, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
@@ -516,6 +523,7 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs) {
   if ((e = hipMalloc(&dpool, sizeof(SokoPool))) != hipSuccess) return e;
   allocs.push_back(dpool);
   if ((e = hipMemcpy(dpool, &pool, sizeof(pool), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
   p.soko = dpool;
   return hipSuccess;
 }
