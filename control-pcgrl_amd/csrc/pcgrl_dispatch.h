@@ -114,7 +114,9 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
     case K_LAST_EPISODE:
       hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
       break;
-    case K_STATS_FOR_GRIDS: hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
+    case K_STATS_FOR_GRIDS:  // (sokoban: one map per wavefront, see the kernel)
+      hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), PROB == PCGRL_PROB_SOKOBAN ? dim3(p.n_envs) : grid, block, 0, s, p);
+      break;
   }
   return hipGetLastError();
 }

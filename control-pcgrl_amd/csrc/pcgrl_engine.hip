@@ -439,7 +439,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     CREATE_CHK(hipMemcpy(djb, jb.data(), jb.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
     p.jump_b = djb;
   }
-  if (cfg->problem == PCGRL_PROB_SOKOBAN) CREATE_CHK(sokoban_alloc(p, e->allocs));
+  if (cfg->problem == PCGRL_PROB_SOKOBAN) CREATE_CHK(sokoban_alloc(p, e->allocs, 64 / lpe));
   if (cfg->n_ctrl > 0) {  // controllable mode: per-env targets, initialised with the static ones
     std::vector<double> init((size_t)n_envs * PCGRL_MAX_STATS * 2, 0.0);
     for (int i = 0; i < n_envs; i++)

@@ -2016,8 +2016,11 @@ __global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
   Grp<LPE> g;
   g.init();
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
-  const int env = blockIdx.x * EPW + (g.lane / LPE);
-  const bool active = env < p.n_envs;
+  // sokoban: one map per wavefront (its first lane group) -- a wave runs the solver for one of its maps at a time, so
+  // spreading the maps over waves lets all of them search concurrently
+  constexpr bool ONE = PROB == PCGRL_PROB_SOKOBAN;
+  const int env = ONE ? (int)blockIdx.x : blockIdx.x * EPW + (g.lane / LPE);
+  const bool active = env < p.n_envs && (!ONE || g.lane < LPE);
   const int e = active ? env : 0;
   const bool rowok = active && g.row < H;
   const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);

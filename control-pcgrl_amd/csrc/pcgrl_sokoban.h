@@ -495,11 +495,13 @@ __device__ __attribute__((noinline)) void sokoban_solve(const Grp<LPE> &g, const
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs) {
+static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int envs_per_wave) {
   SokoPool pool;
-  // one workspace slot per env of the batch up to 256 (a slot is ~11 MB at the default solver_power: the 288 GB of HBM are
-  // there to be used); never fewer than 64 (pcgrl_stats_for_grids_h serves any number of maps from a small engine)
-  pool.n_slots = p.n_envs < 64 ? 64 : (p.n_envs > 256 ? 256 : p.n_envs);
+  // one workspace slot per simulate wavefront of the batch (a wave runs one search at a time), between 64 (so that
+  // pcgrl_stats_for_grids_h can serve many maps from a small engine) and 1024 (~11 MB each at the default solver_power:
+  // the 288 GB of HBM are there to be used)
+  const int waves = (p.n_envs + envs_per_wave - 1) / envs_per_wave;
+  pool.n_slots = waves < 64 ? 64 : (waves > 1024 ? 1024 : waves);
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
   const size_t vis_off = sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
   size_t sz = vis_off + sizeof(uint32_t) * SK_VCAP + sizeof(uint32_t) * (size_t)pool.max_nodes;

@@ -1020,3 +1020,63 @@ def test_rllib_vector_env_adapter_matches_golden(name):
     with pytest.raises(IndexError):
         env.vector_step([0, 10 ** 6, 0])
     env.close()
+
+
+def _solvable_rooms(n, seed, shape=(16, 16)):
+    """sokoban maps that meet the solver's precondition (sokoban_prob.py:172-177): one small room carved into solid with
+    one player and k crates / k targets -- what a trained generator produces most of the time."""
+    rng = np.random.default_rng(seed)
+    H, W = shape
+    g = np.ones((n, H, W), np.uint8)
+    for i in range(n):
+        h, w = int(rng.integers(2, 6)), int(rng.integers(3, 7))
+        y0, x0 = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+        g[i, y0:y0 + h, x0:x0 + w] = 0
+        k = int(rng.integers(1, 4)) if h * w >= 8 else 1
+        cells = rng.permutation(h * w)[:1 + 2 * k]
+        for c, t in zip(cells, [2] + [3] * k + [4] * k):
+            g[i, y0 + c // w, x0 + c % w] = t
+    return g
+
+
+def test_sokoban_wide_2048_envs_solver_inside_episodes_vs_oracle():
+    """BASELINE configs[3] at its batch size with the solver FIRING inside step launches: playable levels are injected,
+    the agent edits floor / wall cells, and dist-win / sol-length move the reward; hundreds of waves hold workspace slots
+    at the same time.  Every step's stats, reward and done against the oracle."""
+    n, power = 2048, 400
+    env = _vec("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True, solver_power=power)
+    orc = po.OracleVecEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), threads=16, solver_power=power)
+    maps = _solvable_rooms(n, 5)
+    env.reset(init_grids=torch.as_tensor(maps))
+    orc.reset(init_grids=maps)
+    st0 = env.get_state().stats.cpu().numpy()
+    assert np.array_equal(st0, orc.get_state()["stats"])
+    assert (st0[:, 4] != 8192).all() and (st0[:, 5] > 0).mean() > 0.15, "every injected level runs the solver, a fifth is solvable"
+    rng = np.random.default_rng(9)
+    active = solved = 0
+    for t in range(24):
+        # a generator-like edit that keeps most levels playable: grow the room by one floor cell next to it (a floor cell
+        # anywhere else would be a second region), or drop a wall / crate / target somewhere
+        grids = orc.get_state()["grids"].reshape(n, 16, 16)
+        open_ = np.pad(grids != 1, ((0, 0), (1, 1), (1, 1)))
+        near = (open_[:, :-2, 1:-1] | open_[:, 2:, 1:-1] | open_[:, 1:-1, :-2] | open_[:, 1:-1, 2:]) & (grids == 1)
+        cell = rng.integers(0, 256, n)
+        tile = rng.choice([1, 1, 3, 4], n)
+        for i in np.nonzero(rng.random(n) < 0.6)[0]:
+            cand = np.flatnonzero(near[i])
+            if len(cand):
+                r, c_ = divmod(int(rng.choice(cand)), 16)
+                cell[i], tile[i] = c_ * 16 + r, 0  # the wide action's cell index is column-major (wide_rep.py:40-45)
+        a = (cell * 5 + tile).astype(np.int32)
+        obs, rew, done, _, info = env.step(torch.as_tensor(a).to(env.device))
+        oobs, orew, odone, ostats = orc.step(a, auto_reset=True, want_obs=(t % 8 == 7))
+        got = info["stats"].cpu().numpy()
+        assert np.array_equal(got, ostats), f"stats @ {t}: {np.nonzero((got != ostats).any(1))[0][:5]}"
+        assert np.max(np.abs(rew.cpu().numpy() - orew)) <= REW_TOL, f"reward @ {t}"
+        assert np.array_equal(done.cpu().numpy(), odone)
+        if t % 8 == 7:
+            assert np.array_equal(obs.cpu().numpy(), oobs)
+        active += int((got[:, 4] != 8192).sum())
+        solved += int((got[:, 5] > 0).sum())
+    assert active > 0.12 * 24 * n and solved > 0.03 * 24 * n, (active, solved)  # thousands of searches inside step launches
+    env.check_errors()
