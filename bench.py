@@ -42,14 +42,18 @@ ALGO_BYTES = {"binary-narrow": 4 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               "binary-narrow-patch3x3": 36 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               # SURVEY 8(d) "BFS-active" variant: maps with exactly one player / key / door, actions restricted to moves
               # and {empty, solid, enemy} placements, so both single-source searches run on every change
-              "zelda-turtle-bfs": 4 + 257 + 32 * 32 * 9 + (4 + 1 + 28 + 2)}
+              "zelda-turtle-bfs": 4 + 257 + 32 * 32 * 9 + (4 + 1 + 28 + 2),
+              # "solver-active" sokoban: playable levels (one player, k crates / targets, one region) so that the device
+              # solver (engine.py BFS / A* cascade) runs inside the step launches
+              "sokoban-wide-solver": 4 + 257 + 16 * 16 * 5 + (4 + 1 + 28 + 0)}
 # BASELINE.json configs: (problem, representation, map_shape, envs per GPU)
 WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtle": ("zelda", "turtle", (16, 16), 4096),
              "sokoban-wide": ("sokoban", "wide", (16, 16), 2048),
              "minecraft_3D_maze-narrow": ("minecraft_3D_maze", "narrow", (7, 7, 7), 1024),
              "binary-narrow-static": ("binary", "narrow", (16, 16), 4096, dict(static_prob=0.3, n_static_walls=3)),
              "binary-narrow-patch3x3": ("binary", "narrow", (16, 16), 4096, dict(act_window=[3, 3])),
-             "zelda-turtle-bfs": ("zelda", "turtle", (16, 16), 4096)}
+             "zelda-turtle-bfs": ("zelda", "turtle", (16, 16), 4096),
+             "sokoban-wide-solver": ("sokoban", "wide", (16, 16), 2048)}
 BFS_ACTIONS = [0, 1, 2, 3, 4 + 0, 4 + 1, 4 + 5, 4 + 6, 4 + 7]  # turtle moves, then empty / solid / bat / scorpion / spider
 
 
@@ -62,6 +66,41 @@ def bfs_active_maps(n, seed):
         c = rng.choice(256, size=3, replace=False)
         g[i, c[0]], g[i, c[1]], g[i, c[2]] = 2, 3, 4
     return g.reshape(n, 16, 16)
+
+def solver_active_maps(n, seed):
+    """sokoban maps that meet the solver's precondition (sokoban_prob.py:172-177): one small room carved into solid with
+    one player and k crates / k targets; plus, per env, the cells an edit may touch without (usually) splitting the room:
+    the room and its 4-neighbourhood.  Returns (maps uint8 [n,16,16], cells: list of int arrays in the wide action's
+    column-major cell index)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    g = np.ones((n, 16, 16), np.uint8)
+    cells = []
+    for i in range(n):
+        h, w = int(rng.integers(3, 6)), int(rng.integers(3, 7))
+        y0, x0 = int(rng.integers(1, 16 - h)), int(rng.integers(1, 16 - w))
+        g[i, y0:y0 + h, x0:x0 + w] = 0
+        k = int(rng.integers(1, 4))
+        pick = rng.permutation(h * w)[:1 + 2 * k]
+        for c, t in zip(pick, [2] + [3] * k + [4] * k):
+            g[i, y0 + c // w, x0 + c % w] = t
+        m = np.zeros((16, 16), bool)
+        m[y0:y0 + h, x0 - 1:x0 + w + 1] = True
+        m[y0 - 1:y0 + h + 1, x0:x0 + w] = True
+        r, c = np.nonzero(m)
+        cells.append((c * 16 + r).astype(np.int32))  # wide_rep.py:40-45: x = row, y = column
+    return g, cells
+
+
+def solver_active_actions(cells, pool, seed):
+    """int32 [pool, n]: floor or wall (never a player / crate / target) on one of the env's candidate cells"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    a = np.empty((pool, len(cells)), np.int32)
+    for i, c in enumerate(cells):
+        a[:, i] = c[rng.integers(0, len(c), pool)] * 5 + rng.integers(0, 2, pool)
+    return a
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -139,21 +178,30 @@ def main():
     wkw = WORKLOADS[args.workload][4] if len(WORKLOADS[args.workload]) > 4 else {}
     N, K, W = (args.envs or default_envs), args.steps, args.warmup
     total_envs = N * world
-    bfs_active = args.workload == "zelda-turtle-bfs"
+    solver_active = args.workload == "sokoban-wide-solver"
+    bfs_active = args.workload == "zelda-turtle-bfs" or solver_active  # "injected maps" workloads
     env = VecPcgrlEnv(problem, rep, shape, N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world),
                       auto_reset=not bfs_active, **wkw)
     inject = None
-    if bfs_active:  # no auto-reset: a reset would draw maps with ~10 players, which switch the searches off
+    if solver_active:
+        sa_maps, sa_cells = solver_active_maps(N, 77 + rank)
+        inject = torch.as_tensor(sa_maps, device=dev).contiguous()
+        env.reset(init_grids=inject)
+    elif bfs_active:  # no auto-reset: a reset would draw maps with ~10 players, which switch the searches off
         inject = torch.as_tensor(bfs_active_maps(N, 77 + rank), device=dev).contiguous()
         env.reset(init_grids=inject)
     else:
         env.reset()
-    REINJECT = 128  # bfs-active: the turtle eventually overwrites the player / key / door, so the maps are re-injected
+    # bfs-active: the turtle eventually overwrites the player / key / door, so the maps are re-injected; solver-active:
+    # the edits wear the rooms down (a wall on a crate ends playability), so they come back every few steps
+    REINJECT = 8 if solver_active else 128
     # synthetic input: uniform random actions, generated on device before the timed region (seed 1234 + rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     POOL = 1024
     actions = torch.randint(0, env.num_actions, (POOL, N * env.action_entries), generator=g, device=dev, dtype=torch.int32)
-    if bfs_active:
+    if solver_active:
+        actions = torch.as_tensor(solver_active_actions(sa_cells, POOL, 1234 + rank), device=dev).contiguous()
+    elif bfs_active:
         actions = torch.tensor(BFS_ACTIONS, dtype=torch.int32, device=dev)[
             torch.randint(0, len(BFS_ACTIONS), (POOL, N), generator=g, device=dev)].contiguous()
     stream = torch.cuda.current_stream(dev)
@@ -303,7 +351,9 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, "
-                                   + ("injected maps with one player / key / door, random moves and empty / solid / enemy "
+                                   + ("playable levels (one player, 1-3 crates / targets, one room) re-injected every 8 steps, floor / "
+                                      "wall edits in and around the room, no auto-reset, " if solver_active else
+                                      "injected maps with one player / key / door, random moves and empty / solid / enemy "
                                       "placements, no auto-reset, " if bfs_active else "uniform random actions, auto-reset, ")
                                    + "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
@@ -322,7 +372,12 @@ def main():
         }
         if world > 1:
             out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "episodes": per_rank_eps}
-        if bfs_active:
+        if solver_active:
+            st = env.get_state().stats
+            out["solver_active"] = {"reinject_every": REINJECT, "solver_power": int(env.cfg.solver_power),
+                                    "envs_with_solver_result_at_end": (st[:, 4] != 8192).float().mean().item(),
+                                    "envs_solved_at_end": (st[:, 5] > 0).float().mean().item()}
+        elif bfs_active:
             st = env.get_state().stats
             both = ((st[:, 0] == 1) & (st[:, 1] == 1) & (st[:, 2] == 1)).float().mean().item()
             out["bfs_active"] = {"reinject_every": REINJECT, "envs_with_both_searches_at_end": both,
@@ -330,7 +385,7 @@ def main():
         if rollout is not None:
             out["open_loop_rollout"] = rollout
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active)
+            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -375,7 +430,7 @@ def profiled_traffic(workload, n_envs):
     return best
 
 
-def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=False):
+def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=False, solver_active=False, reinject=128):
     """The oracle (a C port of the reference's algorithm, OpenMP over envs) on the host cores of this box:
     same workload, bounded sample."""
     import numpy as np
@@ -397,8 +452,9 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
     def rate(threads, seconds):
         orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads,
                               **(wkw or {}))
-        if bfs_active:
-            orc.reset(init_grids=bfs_active_maps(n_envs, 77))
+        maps = sa_maps if solver_active else (bfs_active_maps(n_envs, 77) if bfs_active else None)
+        if maps is not None:
+            orc.reset(init_grids=maps)
         else:
             orc.reset()
         for k in range(2):
@@ -406,6 +462,8 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
         t0 = time.perf_counter()
         steps = 0
         while True:
+            if maps is not None and steps % reinject == 0:
+                orc.reset(init_grids=maps)
             orc.step(acts[steps % 64], auto_reset=not bfs_active)
             steps += 1
             if steps >= 5 and time.perf_counter() - t0 > seconds:
@@ -418,7 +476,11 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
              "wide": int(np.prod(shape)) * po.N_TILES[problem]}[rep]
     entries = int(np.prod(wkw["act_window"])) if wkw and wkw.get("act_window") else 1
     acts = rng.integers(0, n_act, size=(64, n_envs * entries), dtype=np.int32)
-    if bfs_active:
+    sa_maps = None
+    if solver_active:
+        sa_maps, sa_cells = solver_active_maps(n_envs, 77)
+        acts = solver_active_actions(sa_cells, 64, 1234)
+    elif bfs_active:
         acts = np.array(BFS_ACTIONS, np.int32)[rng.integers(0, len(BFS_ACTIONS), size=(64, n_envs))]
     # pick the thread count that this box actually rewards (short calibration), then time the sample
     cands = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)})

@@ -164,3 +164,20 @@ def test_bench_launches_its_own_ranks_dry_run():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_bench_solver_active_maps_are_playable():
+    """bench.py's "solver-active" sokoban workload: every injected level meets the solver's precondition (one player,
+    crates == targets > 0, one region), and the action pool only places floor / wall on cells in and around the room"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    maps, cells = bench.solver_active_maps(96, 5)
+    st = po.stats_for_grids("sokoban", maps, solver_power=300)
+    assert (st[:, 0] == 1).all() and (st[:, 1] == st[:, 2]).all() and (st[:, 1] > 0).all() and (st[:, 3] == 1).all()
+    assert (st[:, 4] != 8192).all() and (st[:, 5] > 0).any()
+    a = bench.solver_active_actions(cells, 32, 1)
+    assert a.shape == (32, 96) and (a % 5 <= 1).all() and a.min() >= 0 and a.max() < 1280
+    for i in range(96):
+        assert set((a[:, i] // 5).tolist()) <= set(cells[i].tolist())
