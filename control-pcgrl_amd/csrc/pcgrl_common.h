@@ -78,6 +78,8 @@ struct Params {
   const JumpEntry *jump;  // [H+1]: skip by row*W draws; entry H = H*W draws
   int32_t *err;           // device error word
   void *soko;             // SokoPool* (sokoban solver workspace), else null
+  int32_t *solver_seen;   // host-mapped counter of device solver runs (sokoban), else null
+  int32_t spread;         // sokoban step: one env per wave pair (see step_kernel)
   void *m3cache;          // M3Slot[N][M3_SLOTS]: cached path-search results per start plane (3-D maze), else null
   // per-call I/O
   const int32_t *actions;

@@ -48,7 +48,7 @@ static hipError_t allow_lds(K kernel, size_t lds) {
 
 template <int PROB, int LPE, typename M>
 static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_t s) {
-  const int epw = 64 / LPE;
+  const int epw = (id == K_STEP && p.spread) ? 1 : 64 / LPE;
   dim3 grid((p.n_envs + epw - 1) / epw), block(64);
   // compile-time specialised 16x16 kernels: cropped 32x32 window (reference default obs_window = 2 * map), or the
   // wide representation's whole-map observation

@@ -43,6 +43,8 @@ struct pcgrl_engine {
   int lpe = 16;
   size_t lds_bytes = 0;
   int cpl = 0;  // 3-D: cells per lane of the reset RNG split
+  int32_t *seen_host = nullptr;  // sokoban: host-mapped counter of device solver runs
+  int32_t seen_last = 0, spread_left = 0;
   bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
   int obs_ndim = 0;
@@ -361,6 +363,22 @@ __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, 
 
 }  // namespace pcgrl
 
+// sokoban: while the device solver has been running in recent launches, step with one env per wavefront (every search gets
+// a wave of its own); otherwise 64 / LPE envs share a wave.  The counter lives in host-mapped memory: reading it costs
+// nothing and may lag a launch or two, which only delays the switch.
+static void choose_spread(pcgrl_engine *h, Params &p) {
+  if (!h->seen_host || h->p.ext) return;
+  const int32_t seen = *(volatile int32_t *)h->seen_host;
+  if (seen != h->seen_last) {
+    h->seen_last = seen;
+    h->spread_left = 64;
+  }
+  if (h->spread_left > 0) {
+    h->spread_left--;
+    p.spread = 1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -439,7 +457,12 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     CREATE_CHK(hipMemcpy(djb, jb.data(), jb.size() * sizeof(JumpEntry), hipMemcpyHostToDevice));
     p.jump_b = djb;
   }
-  if (cfg->problem == PCGRL_PROB_SOKOBAN) CREATE_CHK(sokoban_alloc(p, e->allocs, 64 / lpe));
+  if (cfg->problem == PCGRL_PROB_SOKOBAN) {
+    CREATE_CHK(sokoban_alloc(p, e->allocs, 64 / lpe));
+    CREATE_CHK(hipHostMalloc((void **)&e->seen_host, sizeof(int32_t), hipHostMallocMapped));
+    *e->seen_host = 0;
+    CREATE_CHK(hipHostGetDevicePointer((void **)&p.solver_seen, e->seen_host, 0));
+  }
   if (cfg->n_ctrl > 0) {  // controllable mode: per-env targets, initialised with the static ones
     std::vector<double> init((size_t)n_envs * PCGRL_MAX_STATS * 2, 0.0);
     for (int i = 0; i < n_envs; i++)
@@ -463,6 +486,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
 void pcgrl_destroy(pcgrl_handle h) {
   if (!h) return;
   DeviceGuard guard(h->device);
+  if (h->seen_host) (void)hipHostFree(h->seen_host);
   for (void *a : h->allocs) (void)hipFree(a);
   delete h;
 }
@@ -500,6 +524,7 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   ON_DEVICE(h->device);
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
+  choose_spread(h, p);
   p.actions = d_actions;
   p.auto_reset = auto_reset;
   p.obs = d_obs;
@@ -517,6 +542,7 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_step_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
+  choose_spread(h, p);
   p.actions = d_actions;
   p.auto_reset = auto_reset;
   p.obs = d_obs;

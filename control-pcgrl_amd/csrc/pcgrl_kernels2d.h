@@ -1476,8 +1476,10 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
   PHASE_DECL();
   TRACE_DECL();
   const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
-  const int env = (blockIdx.x * PAIRS + pair) * EPW + (g.lane / LPE);
-  const bool active = env < p.n_envs;
+  // p.spread (sokoban while its solver is busy): one env per wave pair instead of 64 / LPE, so that every env's search
+  // has a wavefront of its own (a wave runs one search at a time)
+  const int env = p.spread ? (int)(blockIdx.x * PAIRS + pair) : (int)((blockIdx.x * PAIRS + pair) * EPW + (g.lane / LPE));
+  const bool active = env < p.n_envs && (!p.spread || g.lane < LPE);
   const bool rowok = active && g.row < H;
   const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
   const int e = active ? env : 0;

@@ -393,6 +393,8 @@ __device__ __attribute__((noinline)) void sokoban_solve(const Grp<LPE> &g, const
     }
     slot = __builtin_amdgcn_readfirstlane(slot);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // tell the host that searches are running: it then launches the step kernel with one env per wavefront
+    if (g.lane == 0 && p.solver_seen != nullptr) __hip_atomic_fetch_add(p.solver_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     {
       uint8_t *b = pool.base + (size_t)slot * pool.slot_bytes;
       c.max_nodes = pool.max_nodes;
@@ -497,11 +499,11 @@ __device__ __attribute__((noinline)) void sokoban_solve(const Grp<LPE> &g, const
 // ---------------------------------------------------------------------------------------------- host side
 static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int envs_per_wave) {
   SokoPool pool;
-  // one workspace slot per simulate wavefront of the batch (a wave runs one search at a time), between 64 (so that
-  // pcgrl_stats_for_grids_h can serve many maps from a small engine) and 1024 (~11 MB each at the default solver_power:
-  // the 288 GB of HBM are there to be used)
-  const int waves = (p.n_envs + envs_per_wave - 1) / envs_per_wave;
-  pool.n_slots = waves < 64 ? 64 : (waves > 1024 ? 1024 : waves);
+  // one workspace slot per env of the batch (in spread mode every env's search runs on its own wavefront), between 64 (so
+  // that pcgrl_stats_for_grids_h can serve many maps from a small engine) and 2048 (~11 MB each at the default
+  // solver_power, 23 GB in all: the 288 GB of HBM are there to be used)
+  (void)envs_per_wave;
+  pool.n_slots = p.n_envs < 64 ? 64 : (p.n_envs > 2048 ? 2048 : p.n_envs);
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
   const size_t vis_off = sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
   size_t sz = vis_off + sizeof(uint32_t) * SK_VCAP + sizeof(uint32_t) * (size_t)pool.max_nodes;
