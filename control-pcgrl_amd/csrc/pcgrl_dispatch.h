@@ -89,16 +89,26 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
         hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128), lds, s, p);
       }
       break;
-    case K_ROLLOUT:
+    case K_ROLLOUT: {
+      const bool ctrl = p.trg || p.reward64;
       if constexpr (LPE == 16 && sizeof(M) == 4) {
         if (fast) {
-          hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true>), grid, dim3(128), lds, s, p);
+          if (ctrl)
+            hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true, true>), grid, dim3(128), lds, s, p);
+          else
+            hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true, false>), grid, dim3(128), lds, s, p);
           break;
         }
       }
-      if ((e = allow_lds(rollout_kernel<PROB, LPE, M, false>, lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, false>), grid, dim3(128), lds, s, p);
+      if (ctrl) {
+        if ((e = allow_lds(rollout_kernel<PROB, LPE, M, false, true>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, false, true>), grid, dim3(128), lds, s, p);
+      } else {
+        if ((e = allow_lds(rollout_kernel<PROB, LPE, M, false, false>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, false, false>), grid, dim3(128), lds, s, p);
+      }
       break;
+    }
     case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
     case K_OBSERVE:
       if constexpr (LPE == 16 && sizeof(M) == 4) {

@@ -555,12 +555,12 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   return PCGRL_OK;
 }
 
-int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
-                  int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream) {
+int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
+                     int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs,
+                     void *stream) {
   if (!h || !d_actions || n_steps < 1) return fail(PCGRL_EINVAL, "pcgrl_rollout: bad arguments");
+  if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_rollout_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   ON_DEVICE(h->device);
-  if (h->p.ext || h->p.cfg.n_ctrl > 0)
-    return fail(PCGRL_EUNSUPPORTED, "pcgrl_rollout: plain mode only (no controls, no representation wrappers)");
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
   p.actions = d_actions;
@@ -570,10 +570,17 @@ int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int
   p.obs_last_only = obs_last_only;
   p.obs_env_bytes = h->obs_bytes;
   p.reward = d_reward;
+  p.reward64 = d_reward64;
   p.done = d_done;
   p.stats_out = d_stats;
+  p.ctrl_obs = d_ctrl_obs;
   HIPCHK(launch(K_ROLLOUT, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
+}
+
+int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
+                  int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream) {
+  return pcgrl_rollout_ex(h, d_actions, n_steps, auto_reset, d_obs, obs_last_only, d_reward, nullptr, d_done, d_stats, nullptr, stream);
 }
 
 int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void *stream) {

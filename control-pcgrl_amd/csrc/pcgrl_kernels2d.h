@@ -1204,7 +1204,7 @@ __device__ inline bool rep_update(const Grp<LPE> &g, const Params &p, bool activ
 template <int PROB, int LPE, typename M>
 __device__ inline bool rep_update_ext(const Grp<LPE> &g, const Params &p, int env, bool active, int action, M *b, int *pos,
                                       int &n_step, bool &bad_action, ExtRow<ProbTraits<PROB>::NB, M> &X,
-                                      bool &map_changed, bool &multi) {
+                                      bool &map_changed, bool &multi, const int32_t *act_base = nullptr) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   M pre[NB];
@@ -1225,7 +1225,7 @@ __device__ inline bool rep_update_ext(const Grp<LPE> &g, const Params &p, int en
     const int l0 = (ah - 1) / 2, l1 = (aw - 1) / 2;
     const int a_row = g.row - (pos[0] - l0), left = pos[1] - l1;
     const bool mine = active && a_row >= 0 && a_row < ah;
-    const int32_t *src = p.actions + (size_t)env * p.n_act + (mine ? a_row * aw : 0);
+    const int32_t *src = (act_base ? act_base : p.actions) + (size_t)env * p.n_act + (mine ? a_row * aw : 0);
     bool badl = false;
     if (mine)
       for (int j = 0; j < aw; j++) badl = badl || src[j] < 0 || src[j] >= NT;
@@ -1312,7 +1312,7 @@ __device__ inline void build_obs_row_static4(uint8_t *row, const Params &p, int 
 
 template <int PROB, int LPE, typename M>
 __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
-                                         M prot, uint8_t *lds) {
+                                         M prot, uint8_t *lds, uint8_t *obs_base = nullptr) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
   if (p.obs == nullptr) return;
   const int H = p.cfg.dims[0], OH = p.cfg.obs_window[0], OW = p.cfg.obs_window[1];
@@ -1341,7 +1341,7 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
     if (g.lane == 0) build_obs_row_static<NB, M>(oob_row, p, C, H + 2, 0, none, M(0));
   }
   if (active) {
-    uint8_t *base = p.obs + (size_t)env * OH * RB;
+    uint8_t *base = (obs_base ? obs_base : p.obs) + (size_t)env * OH * RB;
     const int total = OH * CH;
     if (RB & 15) {
       const int gb = g.gbase;
@@ -1682,8 +1682,9 @@ __global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
 // Open-loop rollout: p.n_steps consecutive steps of every env in ONE launch (pcgrl_rollout).  Same two specialised waves
 // as step_kernel; the whole env state, including the two RNG streams, stays in registers between steps, so there is no
 // per-step kernel boundary, no per-step state traffic, and waves advance independently (a launch no longer waits for
-// its slowest env at every step).  Plain mode only (no control targets, no representation wrappers).
-template <int PROB, int LPE, typename M, bool FAST>
+// its slowest env at every step).  CTRL: controllable mode (per-env targets, float64 rewards); the general (non-FAST)
+// kernels also run the representation wrappers (static tiles / action patches, Params::ext).
+template <int PROB, int LPE, typename M, bool FAST, bool CTRL = false>
 __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;
@@ -1707,6 +1708,12 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
     load_planes<NB, M, FAST>(p, e, g.row, rowok, b);
   else
     load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
+  ExtRow<NB, M> X;
+  bool ext = false;
+  if constexpr (!FAST) {
+    ext = p.ext != 0;
+    if (ext) X.load(p, e, g.row, rowok);
+  }
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
@@ -1715,23 +1722,35 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   int32_t st[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+  EnvTargets<CTRL ? NS : 1> trg;
+  if constexpr (CTRL) {
+    if (!observer) trg.load(p, e, false);
+  }
   Pcg rp, rr;
   rp.load(p.rng[e].prob);
   rr.load(p.rng[e].rep);
-  int action = active ? p.actions[e] : 0;
+  const size_t astride = N * (size_t)p.n_act;  // action entries per step
+  int action = (active && p.n_act == 1) ? p.actions[e] : 0;
   if (p.obs != nullptr) __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
   bool any_change = false, any_reset = false, bad_any = false;
 
   for (int k = 0; k < K; k++) {
-    // the next step's action is requested now and consumed one iteration later
-    const int next_action = (k + 1 < K && active) ? p.actions[(size_t)(k + 1) * N + e] : 0;
+    // the next step's action is requested now and consumed one iteration later (action patches are read in place)
+    const int next_action = (k + 1 < K && active && p.n_act == 1) ? p.actions[(size_t)(k + 1) * N + e] : 0;
     const M tile0_old = b[0];
     M pre[NB];
 #pragma unroll
     for (int i = 0; i < NB; i++) pre[i] = b[i];
     bool bad = false;
     iteration++;
-    const bool change = rep_update<PROB, LPE, M, FAST>(g, p, active, action, b, pos, n_step, bad);
+    bool change, map_changed, multi = false;
+    if (ext) {
+      change = rep_update_ext<PROB, LPE, M>(g, p, e, active, action, b, pos, n_step, bad, X, map_changed, multi,
+                                            p.actions + (size_t)k * astride);
+    } else {
+      change = rep_update<PROB, LPE, M, FAST>(g, p, active, action, b, pos, n_step, bad);
+      map_changed = change;
+    }
     changes += change ? 1 : 0;
     bool done = iteration > p.cfg.max_iterations;
     if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
@@ -1739,12 +1758,17 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
     bad_any = bad_any || bad;
 
     if (observer) {
-      if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, false, nullptr, &rp, &rr);
-      if (!p.obs_last_only || k == K - 1)
-        encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds,
-                                       p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes));
+      if (__ballot(do_reset) != 0) reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, false, ext ? &X : nullptr, &rp, &rr);
+      if (!p.obs_last_only || k == K - 1) {
+        uint8_t *obs_k = p.obs + (p.obs_last_only ? (size_t)0 : (size_t)k * N * (size_t)p.obs_env_bytes);
+        if (ext && p.cfg.static_tiles)
+          encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds, obs_k);
+        else
+          encode_obs<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds, obs_k);
+      }
     } else {
-      const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change;  // first changing step after pcgrl_update
+      const bool restat = change && map_changed;
+      const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && restat;  // first changing step after pcgrl_update
       if (!FAST && __ballot(stale) != 0) {
         int32_t ns[NS];
         compute_stats<PROB, LPE, M>(g, p, e, stale && active, b, colmask, ns);
@@ -1754,14 +1778,19 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
           flags &= ~ENV_STATS_DIRTY;
         }
       }
-      refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && !stale, false, tile0_old, pre, b, colmask, st PHASE_PASS);
-      const double loss = get_loss<NS>(p.cfg, st);
+      refresh_stats<PROB, LPE, M, FAST>(g, p, e, restat && !stale, multi, tile0_old, pre, b, colmask, st PHASE_PASS);
+      double loss;
+      if constexpr (!CTRL) loss = get_loss<NS>(p.cfg, st);
+      else loss = trg.loss(p.cfg, st);
       const double rew = loss - last_loss;
       last_loss = loss;
       ep_return += rew;
       if (active && g.row == 0) {
         const size_t o = (size_t)k * N + (size_t)e;
         if (p.reward) p.reward[o] = (float)rew;
+        if constexpr (CTRL) {
+          if (p.reward64) p.reward64[o] = rew;
+        }
         if (p.done) p.done[o] = done ? 1 : 0;
         if (p.stats_out) {
 #pragma unroll
@@ -1773,7 +1802,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
           latch_episode<NS>(p, e, S, ep_return, iteration, st);
           accumulate_episode<NS>(S);
         }
-        reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, true, nullptr, &rp, &rr);
+        reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, true, ext ? &X : nullptr, &rp, &rr);
         int32_t ns[NS];
         compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
         if (do_reset) {
@@ -1781,7 +1810,13 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
           for (int i = 0; i < NS; i++) st[i] = ns[i];
           flags = 0;
           ep_return = 0.0;
-          last_loss = get_loss<NS>(p.cfg, st);
+          if constexpr (!CTRL) {
+            last_loss = get_loss<NS>(p.cfg, st);
+          } else {
+            trg.load(p, e, true);  // queued control targets take effect with the new episode ...
+            last_loss = trg.loss(p.cfg, st);
+            if (g.row == 0) trg.commit(p, e);  // ... and are the active ones from here on
+          }
         }
       }
       any_change = any_change || change;
@@ -1800,7 +1835,9 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   if constexpr (PROB == PCGRL_PROB_BINARY) {  // PREFLOOD plane: stale after a rollout
     if (rowok) ((M *)p.planes)[((size_t)e * ROW_WORDS + PRE_PLANE) * H + g.row] = M(0);
   }
+  if (ext) X.store(p, e, g.row, rowok, active && g.row == 0, any_reset);
   if (active && g.row == 0) {
+    if constexpr (CTRL) trg.write_ctrl_obs(p, e, st);  // control observation after the last step
     S->pos[0] = pos[0];
     S->pos[1] = pos[1];
     S->n_step = n_step;

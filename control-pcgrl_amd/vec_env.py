@@ -251,14 +251,16 @@ class VecPcgrlEnv:
                                   self._ptrs[2], self._ptrs[3], stream)
 
     def rollout(self, actions, want_obs="all"):
-        """Open-loop rollout: `actions` int32 [K, N]; K steps in one launch (pcgrl_rollout).  Returns
-        (obs, reward [K, N], done [K, N], stats [K, N, n_stats]); obs is [K, N, ...] for want_obs="all", [N, ...]
-        (after the last step) for "last", None for "none".  Fresh tensors, not the env's step buffers."""
+        """Open-loop rollout: `actions` int32 [K, N] (or [K, N, prod(act_window)] with an action patch); K steps in one
+        launch (pcgrl_rollout / pcgrl_rollout_ex).  Returns (obs, reward [K, N], done [K, N], stats [K, N, n_stats]); obs
+        is [K, N, ...] for want_obs="all", [N, ...] (after the last step) for "last", None for "none".  Fresh tensors, not
+        the env's step buffers.  Controllable mode: rewards are float64 and `self.ctrl_obs` holds the control observation
+        after the last step."""
         K = int(actions.shape[0])
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
-        if actions.numel() != K * self.num_envs:
-            raise ValueError(f"actions must be [K, {self.num_envs}]")
+        if actions.numel() != K * self.num_envs * self.action_entries:
+            raise ValueError(f"actions must be [K, {self.num_envs}" + (f", {self.action_entries}]" if self.action_entries > 1 else "]"))
         N, dev = self.num_envs, self.device
         obs = None
         if want_obs == "all":
@@ -266,12 +268,20 @@ class VecPcgrlEnv:
         elif want_obs == "last":
             obs = torch.empty((N,) + self.obs_shape, dtype=torch.uint8, device=dev)
         rew = torch.empty((K, N), dtype=torch.float32, device=dev)
+        rew64 = torch.empty((K, N), dtype=torch.float64, device=dev) if self._reward64 is not None else None
         done = torch.empty((K, N), dtype=torch.uint8, device=dev)
         stats = torch.empty((K, N, self.n_stats), dtype=torch.int32, device=dev)
-        _lib.check(self._L.pcgrl_rollout(self._h, actions.data_ptr(), K, 1 if self.auto_reset else 0,
-                                         obs.data_ptr() if obs is not None else None, 1 if want_obs == "last" else 0,
-                                         rew.data_ptr(), done.data_ptr(), stats.data_ptr(), self._stream()), "pcgrl_rollout")
-        return obs, rew, done.view(torch.bool), stats
+        _lib.check(self._L.pcgrl_rollout_ex(self._h, actions.data_ptr(), K, 1 if self.auto_reset else 0,
+                                            obs.data_ptr() if obs is not None else None, 1 if want_obs == "last" else 0,
+                                            rew.data_ptr(), rew64.data_ptr() if rew64 is not None else None, done.data_ptr(),
+                                            stats.data_ptr(), self._ctrl_obs.data_ptr() if self._ctrl_obs is not None else None,
+                                            self._stream()), "pcgrl_rollout_ex")
+        return obs, (rew64 if rew64 is not None else rew), done.view(torch.bool), stats
+
+    @property
+    def ctrl_obs(self):
+        """float32 [N, 2 * len(controls)]: (target / range, metric / range) per control metric, as of the last step"""
+        return self._ctrl_obs
 
     # -- evolution-driver pattern (evo/evolve.py:1083-1120): rep.update() many times, get_stats() once ---------------
     def update(self, actions, want_obs=True):

@@ -123,9 +123,15 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
  *   d_actions int32 [n_steps][N]          d_reward float [n_steps][N]      d_done uint8 [n_steps][N]
  *   d_stats   int32 [n_steps][N][n_stats] d_obs uint8 [n_steps][N][obs_bytes], or [N][obs_bytes] (the observation
  *             after the last step only) when obs_last_only != 0.  Any output pointer may be NULL.
- * Plain mode only (no cfg.controls, no representation wrappers). */
+ * With cfg.act_window the actions are int32 [n_steps][N][prod(act_window)].
+ * pcgrl_rollout_ex adds the outputs of the controllable mode: d_reward64 double [n_steps][N], d_ctrl_obs float
+ * [N][2*n_ctrl] (the control observation after the LAST step); queued targets take effect at the resets inside the
+ * launch exactly as with pcgrl_step_ex. */
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
+int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
+                     int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats,
+                     float *d_ctrl_obs, void *stream);
 
 /* ControlWrapper.set_trgs (control_wrappers.py:168-172): queue per-env targets; they replace the env's targets at its
  * next reset (explicit or automatic), exactly like the reference's _ctrl_trg_queue (:174-178).

@@ -744,16 +744,64 @@ def test_steps_without_observation_output_and_mixed_call_sequences(rep):
     env.check_errors()
 
 
-def test_rollout_rejects_modes_it_does_not_cover():
-    a = torch.zeros((2, 4), dtype=torch.int32)
-    env = _vec("binary", "narrow", (16, 16), 4, controls=["regions"], reward_dtype=torch.float64)
-    env.reset()
-    with pytest.raises(NotImplementedError):
-        env.rollout(a.to(env.device))
-    env2 = _vec("binary", "narrow", (16, 16), 4, static_prob=0.2)
-    env2.reset()
-    with pytest.raises(NotImplementedError):
-        env2.rollout(a.to(env2.device))
+@pytest.mark.parametrize("problem,rep,shape,kw", [
+    ("binary", "narrow", (16, 16), dict(controls=["regions", "path-length"])),
+    ("zelda", "turtle", (16, 16), dict(controls=["nearest-enemy", "path-length"])),
+    ("sokoban", "wide", (16, 16), dict(controls=["crate"])),
+    ("binary", "narrow", (12, 20), dict(controls=["path-length"])),
+    ("binary", "narrow", (16, 16), dict(static_prob=0.3, n_static_walls=3)),
+    ("zelda", "turtle", (16, 16), dict(static_prob=0.2, n_static_walls=2)),
+    ("binary", "narrow", (16, 16), dict(act_window=(3, 3))),
+    ("zelda", "narrow", (16, 16), dict(act_window=(2, 2), static_prob=0.1, n_static_walls=3)),
+    ("minecraft_3D_maze", "narrow", (5, 5, 5), dict(controls=["path-length"])),
+])
+def test_rollout_kernel_controllable_and_rep_wrappers_equal_stepwise(problem, rep, shape, kw):
+    """pcgrl_rollout_ex in the controllable mode (queued per-env targets taken at the resets inside the launch, float64
+    rewards, control observation) and with the representation wrappers (static tiles, action patches) == the same steps
+    through pcgrl_step_ex, including auto-resets; the step-wise path itself is pinned against the reference fixtures."""
+    n, K = 96, 130
+    ctrl = "controls" in kw
+    mk = lambda: _vec(problem, rep, shape, n, seeds=300 + np.arange(n), auto_reset=True, change_percentage=0.08,
+                      reward_dtype=torch.float64 if ctrl else torch.float32, **kw)
+    a, b = mk(), mk()
+    if ctrl:
+        for env in (a, b):
+            env.sample_uniform_targets(generator=torch.Generator(device=env.device).manual_seed(4))
+    a.reset(); b.reset()
+    g = torch.Generator().manual_seed(12)
+    shape_a = (K, n, a.action_entries) if a.action_entries > 1 else (K, n)
+    hi = a.spec.n_tiles if a.action_entries > 1 else a.num_actions
+    acts = torch.randint(0, hi, shape_a, generator=g, dtype=torch.int32).to(a.device)
+    if ctrl:  # new targets are queued before the run: they must apply at each env's next reset in both paths
+        for env in (a, b):
+            env.sample_uniform_targets(generator=torch.Generator(device=env.device).manual_seed(5))
+    obs_r, rew_r, done_r, stats_r = a.rollout(acts, want_obs="all")
+    n_done = 0
+    for k in range(K):
+        obs, rew, done, _, info = b.step(acts[k])
+        assert torch.equal(info["stats"], stats_r[k]), f"stats @ {k}"
+        assert torch.equal(done, done_r[k]), f"done @ {k}"
+        assert float((rew.double() - rew_r[k].double()).abs().max()) <= (1e-9 if ctrl else 0.0), f"reward @ {k}"
+        assert torch.equal(obs, obs_r[k]), f"obs @ {k}"
+        n_done += int(done.sum())
+    assert n_done > n // 2
+    if ctrl:
+        assert torch.equal(a.ctrl_obs, info["ctrl_obs"])
+    sa, sb = a.get_state(), b.get_state()
+    assert torch.equal(sa.grids, sb.grids) and torch.equal(sa.counters, sb.counters) and torch.equal(sa.stats, sb.stats)
+    assert torch.equal(a.get_rng_state(), b.get_rng_state())
+    if a.static_tiles:
+        assert torch.equal(a.get_static(), b.get_static())
+    # ... and continuing step-wise after the rollout stays identical
+    more = torch.randint(0, hi, (20,) + tuple(shape_a[1:]), generator=g, dtype=torch.int32).to(a.device)
+    for k in range(20):
+        oa, ra, da, _, ia = a.step(more[k])
+        ob, rb, db, _, ib = b.step(more[k])
+        assert torch.equal(oa, ob) and torch.equal(ia["stats"], ib["stats"]) and torch.equal(da, db)
+    a.check_errors(); b.check_errors()
+
+
+def test_rollout_rejects_malformed_actions():
     with pytest.raises(ValueError):
         _vec("binary", "narrow", (16, 16), 4).rollout(torch.zeros((2, 5), dtype=torch.int32))
 
