@@ -1,11 +1,17 @@
-"""Import alias: the package sources live in ``control-pcgrl_amd/`` (a hyphen is not importable).
+"""control_pcgrl_amd -- MI355X-native batched PCGRL environment engine (host side).
 
-``import control_pcgrl_amd`` resolves sub-modules from that directory and executes its ``__init__``.
+Drop-in for the reference's env hot path only (control_pcgrl/rl/envs.py:make_env and what it builds):
+  make_env(cfg)            single-env adapter with the reference's reset()/step() tuple shapes
+  make_vec_env(cfg, n)     batched engine: torch tensors in/out, one HIP launch per step for all envs
+  VecPcgrlEnv              the batched env class
+  PcgrlVectorEnv           the same batch behind ray.rllib's VectorEnv call shape (vector_step / reset_at ...)
+The compute lives in csrc/libpcgrl_amd.so (hand-written HIP for gfx950) behind the C ABI of
+include/pcgrl_amd.h; this package fails loudly if that library is missing -- there is no CPU fallback.
 """
-import os as _os
+from .problems import PROBLEMS, REPRESENTATIONS, ProblemSpec, problem_spec  # noqa: F401
+from .vec_env import VecPcgrlEnv, make_vec_env  # noqa: F401
+from .envs import make_env, PcgrlGymEnv  # noqa: F401
+from .rllib_env import PcgrlVectorEnv  # noqa: F401
+from .dist import EpisodeStatsReducer, shard_env_range  # noqa: F401
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "control-pcgrl_amd")
-__path__[:] = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f, _os
+__version__ = "0.1.0"

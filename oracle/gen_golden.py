@@ -10,7 +10,7 @@ Two kinds of fixture:
                              and observations (CRC32 of every uint8 one-hot obs + a few full tensors).
   stats_<problem>.npz        known-answer sets for Problem.get_stats() on hand-built and random grids.
 
-Stat order per problem (the engine's canonical order, see control-pcgrl_amd/problems.py):
+Stat order per problem (the engine's canonical order, see control_pcgrl_amd/problems.py):
   binary   regions, path-length
   zelda    player, key, door, enemies, regions, nearest-enemy, path-length
   sokoban  player, crate, target, regions, dist-win, sol-length, ratio

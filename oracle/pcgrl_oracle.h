@@ -2,7 +2,7 @@
  * pcgrl_oracle.h -- CPU restatement of control-pcgrl's env hot path.
  *
  * TEST INFRASTRUCTURE ONLY.  This library is the parity checker for the HIP engine and the timed
- * `cpu_baseline` leg of bench.py.  Nothing in the product path (control-pcgrl_amd/) may call it.
+ * `cpu_baseline` leg of bench.py.  Nothing in the product path (control_pcgrl_amd/) may call it.
  * It is pinned against golden vectors captured from the reference itself (tests/golden/, produced by
  * oracle/gen_golden.py importing /root/reference) -- see tests/test_oracle_golden.py.
  *

@@ -1,10 +1,10 @@
 """ctypes binding + problem tables for the CPU oracle (oracle/pcgrl_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-The product package (control-pcgrl_amd/) never imports this module.
+The product package (control_pcgrl_amd/) never imports this module.
 
 The tables below restate the reference's per-problem constants independently of the product's
-control-pcgrl_amd/problems.py (two statements of the same reference lines, both pinned by golden rewards).
+control_pcgrl_amd/problems.py (two statements of the same reference lines, both pinned by golden rewards).
 Reference paths are relative to /root/reference/control_pcgrl/.
 """
 import ctypes as C
