@@ -113,8 +113,9 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's)")
     ap.add_argument("--workload", default="binary-narrow", choices=sorted(ALGO_BYTES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph-steps", type=int, default=0,
-                    help="launch the step kernel through a captured HIP graph of this many steps (0 = eager launches)")
+    ap.add_argument("--graph-steps", type=int, default=-1,
+                    help="launch the step kernel through a captured HIP graph of this many steps (0 = eager launches; default: "
+                         "125 when --steps >= 250, else eager -- the eager Python loop is host-bound below ~6.3 us per launch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--rollout-steps", type=int, default=64,
                     help="also time the open-loop rollout kernel (pcgrl_rollout) with this many steps per launch and "
@@ -220,7 +221,7 @@ def main():
     # The launch-bound inner loop is captured once in a HIP graph of G consecutive steps (each node = one pcgrl_step
     # launch with its own action row) and replayed; K steps = K // G replays + K % G eager launches.  G = 125 is
     # coprime with the narrow scan period (256 cells), so every cell keeps receiving fresh random actions.
-    G = max(0, args.graph_steps)
+    G = args.graph_steps if args.graph_steps >= 0 else (125 if (K >= 250 and inject is None) else 0)
     graph = None
     if G > 0:
         graph = torch.cuda.CUDAGraph()

@@ -32,6 +32,10 @@ def short(name):
     return name.split("(")[0].replace("void ", "")[:72]
 
 
+def is_m3_step(name):
+    return "m3_kernel<0>" in name or "m3_kernel<(pcgrl::M3Mode)0>" in name
+
+
 def summarize(w, stats_rows):
     import bench
     out = {}
@@ -47,8 +51,8 @@ def summarize(w, stats_rows):
                                 "pct": float(r["Percentage"])} for r in keep]
     kt = first(f"prof_{w}_kt/**/*kernel_trace.csv")
     if kt:
-        rows = [r for r in csv.DictReader(open(kt)) if dom in r["Kernel_Name"] and "M3_ROLLOUT" not in r["Kernel_Name"]
-                and ("m3_kernel<(pcgrl::M3Mode)0>" in r["Kernel_Name"] or dom == "step_kernel")]
+        rows = [r for r in csv.DictReader(open(kt)) if dom in r["Kernel_Name"]
+                and (is_m3_step(r["Kernel_Name"]) or dom == "step_kernel")]
         if len(rows) > 2:
             gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
             r0 = rows[0]
@@ -75,7 +79,7 @@ def summarize(w, stats_rows):
         for (k, c), v in agg.items():
             counters[k][c] = {"mean_per_launch": statistics.mean(v), "launches": len(v)}
     out["pmc"] = counters
-    step = next((k for k in counters if dom in k and "M3Mode)5" not in k and ("M3Mode)0" in k or dom == "step_kernel")), None)
+    step = next((k for k in counters if dom in k and (is_m3_step(k) or dom == "step_kernel")), None)
     n = ENVS.get(w, 0)
     if step:
         c = counters[step]
