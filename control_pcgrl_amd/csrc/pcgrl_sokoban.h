@@ -88,63 +88,81 @@ __device__ inline uint32_t sk_wave_xor(uint32_t v) {
          (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-// The crate list of one node, spread over the wave: lane k holds crate k in c0 and crate k + 64 in c1.
+// The crate list of one node, spread over the wave: lane k holds crate k in c0 and (BIG: levels with more than 64
+// crates) crate k + 64 in c1.
+template <bool BIG>
 struct SkCrates {
   uint32_t c0, c1;  // x | y << 8, SK_NOCRATE beyond the list
   __device__ inline void load(const SokoCtx &c, int n) {
     const uint16_t *src = c.crates + (size_t)n * SK_MAXC;
     c0 = c.lane < c.ncr ? src[c.lane] : SK_NOCRATE;
-    c1 = c.lane + 64 < c.ncr ? src[c.lane + 64] : SK_NOCRATE;
+    c1 = (BIG && c.lane + 64 < c.ncr) ? src[c.lane + 64] : SK_NOCRATE;
   }
   __device__ inline void store(const SokoCtx &c, int n) const {
     uint16_t *dst = c.crates + (size_t)n * SK_MAXC;
     if (c.lane < c.ncr) dst[c.lane] = (uint16_t)c0;
-    if (c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
+    if (BIG && c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
   }
   // index of the crate standing at (x, y), -1 if none (engine.py:263-267)
   __device__ inline int at(int x, int y) const {
     const uint32_t key = (uint32_t)x | ((uint32_t)y << 8);
-    const uint64_t b0 = __ballot(c0 == key), b1 = __ballot(c1 == key);
+    const uint64_t b0 = __ballot(c0 == key);
+    if (!BIG) return b0 ? __builtin_ctzll(b0) : -1;
+    const uint64_t b1 = __ballot(c1 == key);
     return b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : -1);
   }
   // number of crates whose cell has its bit set in `rows`
   __device__ inline int count_on(const uint64_t *rows) const {
-    const bool h0 = c0 != SK_NOCRATE && sk_bit(rows, c0 & 255, c0 >> 8), h1 = c1 != SK_NOCRATE && sk_bit(rows, c1 & 255, c1 >> 8);
-    return __popcll(__ballot(h0)) + __popcll(__ballot(h1));
+    const bool h0 = c0 != SK_NOCRATE && sk_bit(rows, c0 & 255, c0 >> 8);
+    int n = __popcll(__ballot(h0));
+    if (BIG) {
+      const bool h1 = c1 != SK_NOCRATE && sk_bit(rows, c1 & 255, c1 >> 8);
+      n += __popcll(__ballot(h1));
+    }
+    return n;
   }
   __device__ inline uint32_t hash(int lane, int px, int py) const {
     // position-dependent mix per crate, xor-combined over the wave (any function of the key will do: internal table)
     uint32_t a = (c0 + 0x9E3779B9u * (uint32_t)(lane + 1)) * 0x85EBCA6Bu;
     a ^= a >> 15;
-    uint32_t b = (c1 + 0x9E3779B9u * (uint32_t)(lane + 65)) * 0xC2B2AE35u;
-    b ^= b >> 13;
-    uint32_t h = sk_wave_xor(a ^ b);
+    if (BIG) {
+      uint32_t b = (c1 + 0x9E3779B9u * (uint32_t)(lane + 65)) * 0xC2B2AE35u;
+      a ^= b ^ (b >> 13);
+    }
+    uint32_t h = sk_wave_xor(a);
     h = (h ^ (uint32_t)px) * 16777619u;
     h = (h ^ (uint32_t)py) * 16777619u;
     return h ^ (h >> 16);
   }
-  __device__ inline bool same(const SkCrates &o) const { return __ballot(c0 != o.c0 || c1 != o.c1) == 0; }
+  __device__ inline bool same(const SkCrates &o) const { return __ballot(c0 != o.c0 || (BIG && c1 != o.c1)) == 0; }
 };
 
-__device__ inline bool sk_free_cell(const SokoCtx &c, const SkCrates &cr, int x, int y) {  // checkMovableLocation :269-270
+template <bool BIG>
+__device__ inline bool sk_free_cell(const SokoCtx &c, const SkCrates<BIG> &cr, int x, int y) {  // checkMovableLocation :269-270
   if (x < 0 || y < 0 || x > c.lv->w - 1 || y > c.lv->h - 1) return false;
   return !sk_bit(c.lv->solid, x, y) && cr.at(x, y) < 0;
 }
 
 // engine.py:282-296 getHeuristic: crates in list order greedily take the nearest remaining target (first minimum in
 // list order).  Lane t holds targets t and t + 64; per crate: broadcast its cell, one distance per lane, wave arg-min.
-__device__ inline int sk_heuristic(const SokoCtx &c, const SkCrates &cr) {
+template <bool BIG>
+__device__ inline int sk_heuristic(const SokoCtx &c, const SkCrates<BIG> &cr) {
   const int nt = c.lv->ntg;
-  const uint32_t t0 = c.lane < nt ? c.lv->target[c.lane] : SK_NOCRATE, t1 = c.lane + 64 < nt ? c.lv->target[c.lane + 64] : SK_NOCRATE;
+  const uint32_t t0 = c.lane < nt ? c.lv->target[c.lane] : SK_NOCRATE;
+  const uint32_t t1 = (BIG && c.lane + 64 < nt) ? c.lv->target[c.lane + 64] : SK_NOCRATE;
   bool u0 = t0 == SK_NOCRATE, u1 = t1 == SK_NOCRATE;  // "used" (absent targets never match)
   int distance = 0;
   for (int k = 0; k < c.ncr; k++) {
-    const uint32_t ck = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, k) : (uint32_t)__builtin_amdgcn_readlane((int)cr.c1, k - 64);
+    const uint32_t ck = (!BIG || k < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, k & 63)
+                                         : (uint32_t)__builtin_amdgcn_readlane((int)cr.c1, k - 64);
     const int cx = ck & 255, cy = ck >> 8;
     const uint32_t d0 = u0 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t0 & 255)) + abs(cy - (int)(t0 >> 8)));
-    const uint32_t d1 = u1 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t1 & 255)) + abs(cy - (int)(t1 >> 8)));
-    const uint32_t k0 = (d0 << 8) | (uint32_t)c.lane, k1 = (d1 << 8) | (uint32_t)(c.lane + 64);
-    const uint32_t best = sk_wave_min(min(k0, k1));  // smallest distance, then smallest index: the first minimum
+    uint32_t key = (d0 << 8) | (uint32_t)c.lane;
+    if (BIG) {
+      const uint32_t d1 = u1 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t1 & 255)) + abs(cy - (int)(t1 >> 8)));
+      key = min(key, (d1 << 8) | (uint32_t)(c.lane + 64));
+    }
+    const uint32_t best = sk_wave_min(key);  // smallest distance, then smallest index: the first minimum
     distance += (int)(best >> 8);  // (ncr == ntg: an unused target always exists; the distance is < w + h)
     const int t = best & 255;
     u0 = u0 || t == c.lane;
@@ -215,7 +233,8 @@ __device__ inline void sk_init_deadlocks(SokoCtx &c) {
 }
 
 // returns true if the state (px, py, cr) was already in the visited set; inserts node n otherwise
-__device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py, const SkCrates &cr) {
+template <bool BIG>
+__device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py, const SkCrates<BIG> &cr) {
   uint32_t i = cr.hash(c.lane, px, py) & (SK_VCAP - 1);
   while (true) {
     const uint32_t e = c.vis[i];
@@ -225,7 +244,7 @@ __device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py
     }
     const int m = (int)(e & 0x1FFFFu) - 1;
     if (c.nodes[m].px == px && c.nodes[m].py == py) {  // State.getKey engine.py:330-336
-      SkCrates o;
+      SkCrates<BIG> o;
       o.load(c, m);
       if (cr.same(o)) return true;
     }
@@ -235,6 +254,7 @@ __device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py
 
 // stage: b2 < 0 -> BFSAgent (engine.py:56-74); else AStarAgent with balance b2 / 2 (engine.py:96-119).  Uniform over
 // the wave.  Node 0 = root, already filled by the caller.
+template <bool BIG>
 __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
                                 bool *exhausted = nullptr) {
   uint32_t ep = 0;
@@ -267,11 +287,20 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
   const int h_root = c.nodes[0].h;
   if (c.lane == 0) c.q[0] = b2 < 0 ? 0u : ((uint32_t)(2 * h_root) << 16);
   tail = 1;
+  // BFS: the node after the current one is already in the queue, so its record is requested one iteration ahead
+  bool pre_valid = false;
+  int pre_cur = 0;
+  SokoNode pre_nd;
+  SkCrates<BIG> pre_cr;
+  pre_cr.c0 = pre_cr.c1 = SK_NOCRATE;
+  pre_nd = SokoNode();
   while (iters < max_iter && head < tail) {
     iters++;
     int cur;
+    const bool had_pre = pre_valid;
     if (b2 < 0) {
-      cur = (int)c.q[head++];  // queue.pop(0)
+      cur = had_pre ? pre_cur : (int)c.q[head];  // queue.pop(0)
+      head++;
     } else {                   // heapq.heappop
       const uint32_t last = c.q[--tail];
       if (tail > 0) {
@@ -297,10 +326,22 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
         cur = (int)(last & 0xFFFFu);
       }
     }
-    const SokoNode nd = c.nodes[cur];
+    SokoNode nd;
+    SkCrates<BIG> cr;
+    if (had_pre) {
+      nd = pre_nd;
+      cr = pre_cr;
+    } else {
+      nd = c.nodes[cur];
+      cr.load(c, cur);
+    }
+    pre_valid = b2 < 0 && head < tail;
+    if (pre_valid) {
+      pre_cur = (int)c.q[head];
+      pre_nd = c.nodes[pre_cur];
+      pre_cr.load(c, pre_cur);
+    }
     const int px = nd.px, py = nd.py;
-    SkCrates cr;
-    cr.load(c, cur);
     if (c.lv->ntg == c.ncr && c.ncr > 0 && cr.count_on(c.lv->tgt) == c.ncr) {  // checkWin engine.py:272-280
       res_h = nd.h;
       res_depth = nd.depth;
@@ -318,7 +359,7 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
         const int nx = px + DX[d], ny = py + DY[d];
         if (nx < 0 || ny < 0 || nx > c.lv->w - 1 || ny > c.lv->h - 1 || sk_bit(c.lv->solid, nx, ny)) continue;
         const int moved = cr.at(nx, ny);
-        SkCrates ch = cr;
+        SkCrates<BIG> ch = cr;
         int h = nd.h;  // the heuristic depends on the crates only
         if (moved >= 0) {
           const int bx = nx + DX[d], by = ny + DY[d];
@@ -327,7 +368,7 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
           const int ndead = n_dead - (sk_bit(c.lv->dead, nx, ny) ? 1 : 0) + (sk_bit(c.lv->dead, bx, by) ? 1 : 0);
           if (ndead > 0) continue;
           const uint32_t np = (uint32_t)bx | ((uint32_t)by << 8);
-          if (moved < 64) ch.c0 = c.lane == moved ? np : ch.c0;
+          if (!BIG || moved < 64) ch.c0 = c.lane == moved ? np : ch.c0;
           else ch.c1 = c.lane == moved - 64 ? np : ch.c1;
           h = sk_heuristic(c, ch);
         }
@@ -363,11 +404,40 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
   return false;
 }
 
+// The reference's cascade (sokoban_prob.py:99-148) from the level's root state (crates in c.lv->root).
+template <bool BIG>
+__device__ inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
+  SkCrates<BIG> root;
+  root.c0 = c.lane < c.ncr ? c.lv->root[c.lane] : SK_NOCRATE;
+  root.c1 = (BIG && c.lane + 64 < c.ncr) ? c.lv->root[c.lane + 64] : SK_NOCRATE;
+  root.store(c, 0);
+  const int h0 = sk_heuristic(c, root);
+  if (c.lane == 0) {
+    SokoNode n0;
+    n0.parent = -1;
+    n0.depth = 0;
+    n0.h = (int16_t)h0;
+    n0.px = (uint8_t)px;
+    n0.py = (uint8_t)py;
+    c.nodes[0] = n0;
+  }
+  // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
+  // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
+  // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
+  // three A* stages is therefore exact (pinned by tests/golden/stats_sokoban_solver.npz against the reference).
+  bool exhausted = false;
+  bool won = sk_stage<BIG>(c, pool, slot, -1, power, h, depth, &exhausted);
+  if (!won && !exhausted)
+    won = sk_stage<BIG>(c, pool, slot, 2, power, h, depth) || sk_stage<BIG>(c, pool, slot, 1, power, h, depth) ||
+          sk_stage<BIG>(c, pool, slot, 0, power, h, depth);
+  return won;
+}
+
 // Called by every lane of the wave in uniform control flow; `need` is uniform per group.  Groups that need the
 // solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
 // and never waits for a slot while holding one.
 template <int LPE>
-__device__ __attribute__((noinline)) void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid,
+__device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid,
                                                         uint32_t player, uint32_t crate, uint32_t target, int &dist_win, int &sol_len) {
   (void)env;
   const SokoPool &pool = *(const SokoPool *)p.soko;
@@ -453,31 +523,10 @@ __device__ __attribute__((noinline)) void sokoban_solve(const Grp<LPE> &g, const
         s_level.ntg = ntg;
       }
       sk_init_deadlocks(c);
-      SkCrates root;
-      root.c0 = g.lane < ncr ? s_level.root[g.lane] : SK_NOCRATE;
-      root.c1 = g.lane + 64 < ncr ? s_level.root[g.lane + 64] : SK_NOCRATE;
-      root.store(c, 0);
-      const int h0 = sk_heuristic(c, root);
-      if (g.lane == 0) {
-        SokoNode n0;
-        n0.parent = -1;
-        n0.depth = 0;
-        n0.h = (int16_t)h0;
-        n0.px = (uint8_t)px;
-        n0.py = (uint8_t)py;
-        c.nodes[0] = n0;
-      }
+      bool won;
       int h = 0, depth = 0;
-      const int power = p.cfg.solver_power;
-      // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
-      // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
-      // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
-      // three A* stages is therefore exact (pinned by tests/golden/stats_sokoban_solver.npz against the reference).
-      bool exhausted = false;
-      bool won = sk_stage(c, pool, slot, -1, power, h, depth, &exhausted);
-      if (!won && !exhausted)
-        won = sk_stage(c, pool, slot, 2, power, h, depth) || sk_stage(c, pool, slot, 1, power, h, depth) ||
-              sk_stage(c, pool, slot, 0, power, h, depth);
+      if (ncr > 64) won = sk_cascade<true>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+      else won = sk_cascade<false>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
       if (won) {
         dw = 0;
         sl = depth;
