@@ -262,40 +262,44 @@ def main():
     # below): the open-loop rollout kernel (pcgrl_rollout, GR steps per launch, every observation written), the engine's
     # counterpart of the reference's random-action profiling loop (profile_env.py:124-142).  Its size does not depend
     # on --steps.  Never `value`.
-    rollout = None
     GR = args.rollout_steps
-    if GR > 0 and not wkw and not bfs_active and POOL >= GR:  # (bfs-active needs the periodic map injection)
-        R = max(args.rollout_launches, 1)
-        obs_r = torch.empty((GR, N) + env.obs_shape, dtype=torch.uint8, device=dev)
-        rew_r = torch.empty((GR, N), dtype=torch.float32, device=dev)
-        done_r = torch.empty((GR, N), dtype=torch.uint8, device=dev)
-        stats_r = torch.empty((GR, N, env.n_stats), dtype=torch.int32, device=dev)
 
-        def run_rollouts(n):
-            for i in range(n):
-                rc = env._L.pcgrl_rollout(env._h, base + ((i * GR) % (POOL - GR + 1)) * stride, GR, 1, obs_r.data_ptr(), 0,
-                                          rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
-                if rc:
-                    raise RuntimeError(f"pcgrl_rollout rc={rc}")
+    def measure_rollout():
+      rollout = None
+      if GR > 0 and not wkw and not bfs_active and POOL >= GR:  # (bfs-active needs the periodic map injection)
+          R = max(args.rollout_launches, 1)
+          obs_r = torch.empty((GR, N) + env.obs_shape, dtype=torch.uint8, device=dev)
+          rew_r = torch.empty((GR, N), dtype=torch.float32, device=dev)
+          done_r = torch.empty((GR, N), dtype=torch.uint8, device=dev)
+          stats_r = torch.empty((GR, N, env.n_stats), dtype=torch.int32, device=dev)
 
-        run_rollouts(max(1, R // 10))
-        barrier()
-        t1 = time.perf_counter()
-        run_rollouts(R)
-        barrier()
-        el_r, _ = max_over_ranks(time.perf_counter() - t1)
-        env.check_errors()
-        us = el_r / (R * GR) * 1e6
-        rollout = {"value": total_envs * R * GR / el_r, "unit": "env-steps/s", "steps_per_launch": GR, "launches": R,
-                   "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                   "note": "open-loop action sequences only (actions known in advance); all per-step outputs written; "
-                           "measured before the timed region"}
-        del obs_r
+          def run_rollouts(n):
+              for i in range(n):
+                  rc = env._L.pcgrl_rollout(env._h, base + ((i * GR) % (POOL - GR + 1)) * stride, GR, 1, obs_r.data_ptr(), 0,
+                                            rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
+                  if rc:
+                      raise RuntimeError(f"pcgrl_rollout rc={rc}")
 
-    run(W)
-    # warm the reporting path too (pinned buffer, first all-reduce), then start from clean accumulators
+          run_rollouts(max(1, R // 10))
+          barrier()
+          t1 = time.perf_counter()
+          run_rollouts(R)
+          barrier()
+          el_r, _ = max_over_ranks(time.perf_counter() - t1)
+          env.check_errors()
+          us = el_r / (R * GR) * 1e6
+          rollout = {"value": total_envs * R * GR / el_r, "unit": "env-steps/s", "steps_per_launch": GR, "launches": R,
+                     "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "note": "open-loop action sequences only (actions known in advance); all per-step outputs written; "
+                             "measured before the timed region"}
+          del obs_r
+      return rollout
+
+    # the reporting path's buffers (pinned host memory takes milliseconds to allocate: nothing slow may sit between the
+    # warm-up steps and the timed region)
     ep_dev = torch.zeros(3 + env.n_stats, dtype=torch.float64, device=dev)
     ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
+    done_ev = torch.cuda.Event()
 
     def reduce_episodes():
         """the path's only exchange: one pcgrl_reduce_episodes launch; world == 1: the kernel writes its 3 + n_stats
@@ -305,6 +309,9 @@ def main():
             rc = env._L.pcgrl_reduce_episodes(env._h, ep_host.data_ptr(), 1, sptr)
             if rc:
                 raise RuntimeError(f"pcgrl_reduce_episodes rc={rc}")
+            # (waiting on an event returns ~15 us sooner than the device-wide wait; the synchronise then finds an idle device)
+            done_ev.record(stream)
+            done_ev.synchronize()
             torch.cuda.synchronize(dev)
             return
         env.reduce_episodes(clear=True, out=ep_dev)
@@ -317,8 +324,11 @@ def main():
         ep_host.copy_(ep_dev, non_blocking=True)
         torch.cuda.synchronize(dev)
 
-    reduce_episodes()
+    reduce_episodes()  # warm the reporting path (first all-reduce), clean accumulators
     local_eps = torch.zeros(1, dtype=torch.float64, device=dev)
+    rollout = measure_rollout()
+    run(W)
+    reduce_episodes()  # episodes that ended during the warm-up do not count
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()

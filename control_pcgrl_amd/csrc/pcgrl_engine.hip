@@ -331,6 +331,42 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_episodes_kernel(Params p, 
   if (threadIdx.x == 0) scr->ticket = 0;  // ready for the next call on the same stream
 }
 
+// small batches: one block, no cross-block hand-off (same fixed summation order: thread t owns envs t, t + 1024, ...;
+// lanes -> wave by an xor butterfly, waves in wave order)
+__global__ __launch_bounds__(1024) void reduce_episodes_small_kernel(Params p, double *out, int clear) {
+  __shared__ double sh[16][RED_W];
+  double ret = 0.0;
+  int64_t v[RED_W - 1];
+  for (int k = 0; k < RED_W - 1; k++) v[k] = 0;
+  for (int e = (int)threadIdx.x; e < p.n_envs; e += 1024) {
+    EpAcc *A = &p.st[e].acc;
+    if (A->n == 0) continue;  // nothing finished in this env since the last clearing call
+    ret += A->sum_return;
+    v[0] += A->sum_len;
+    v[1] += A->n;
+    for (int k = 0; k < PCGRL_MAX_STATS; k++) v[2 + k] += A->sum_stats[k];
+    if (clear) {
+      A->sum_return = 0.0;
+      A->sum_len = 0;
+      A->n = 0;
+      for (int k = 0; k < PCGRL_MAX_STATS; k++) A->sum_stats[k] = 0;
+    }
+  }
+  double w[RED_W];
+  w[0] = ret;
+  for (int k = 1; k < RED_W; k++) w[k] = (double)v[k - 1];
+  for (int k = 0; k < RED_W; k++)
+    for (int o = 32; o >= 1; o >>= 1) w[k] += __shfl_xor(w[k], o, 64);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < RED_W; k++) sh[threadIdx.x >> 6][k] = w[k];
+  __syncthreads();
+  if (threadIdx.x < 3 + (unsigned)p.cfg.n_stats) {
+    double s = 0.0;
+    for (int i = 0; i < 16; i++) s += sh[i][threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
 // pcgrl_get_rng_state / pcgrl_set_rng_state: [N][10] = rep state hi, lo, inc hi, lo; prob state hi, lo, inc hi, lo;
 // representation-wrapper flags | has32 << 32, val32
 __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, const uint64_t *in) {
@@ -773,6 +809,11 @@ void pcgrl_stats_cache_clear(void) {
 int pcgrl_reduce_episodes(pcgrl_handle h, double *d_out, int32_t clear, void *stream) {
   if (!h || !d_out) return fail(PCGRL_EINVAL, "pcgrl_reduce_episodes: bad arguments");
   ON_DEVICE(h->device);
+  if (h->p.n_envs <= 16384) {
+    hipLaunchKernelGGL(reduce_episodes_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, h->p, d_out, clear ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+  }
   const int n_blocks = std::min(RED_BLOCKS, (h->p.n_envs + RED_THREADS - 1) / RED_THREADS);
   hipLaunchKernelGGL(reduce_episodes_kernel, dim3(n_blocks), dim3(RED_THREADS), 0, (hipStream_t)stream, h->p, h->red, d_out, n_blocks,
                      clear ? 1 : 0);
