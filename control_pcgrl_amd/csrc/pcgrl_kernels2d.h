@@ -1463,7 +1463,10 @@ __device__ inline void accumulate_episode(EnvState *S) {
 // workgroups to dispatch at 4096 envs: 6.65 -> 6.57 us per launch; 4 pairs are slower, 7.7 us; zelda, whose launch is
 // bound by its observation stores, is faster with 1).
 template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
-__global__ __launch_bounds__(128 * PAIRS) void step_kernel(Params p) {
+#ifndef PCGRL_STEP_WAVES
+#define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
+#endif
+__global__ __launch_bounds__(128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : 1) void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];

@@ -197,6 +197,19 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
 #ifdef PCGRL_PHASE_TIMING
     dbg_trips++;
 #endif
+#ifdef PCGRL_PHASE_TIMING
+    uint64_t tt0_ = __builtin_readcyclecounter();
+#define M3_TT(i)                                                    \
+  do {                                                              \
+    uint64_t tt1_ = __builtin_readcyclecounter();                   \
+    if (c.lane == 0) L.dbg[i] += (uint32_t)(tt1_ - tt0_);           \
+    tt0_ = tt1_;                                                    \
+  } while (0)
+#else
+#define M3_TT(i) \
+  do {           \
+  } while (0)
+#endif
     const int nb = min(16, tail - head);
     const bool live = slot_i < nb;
     const int id = head + (live ? slot_i : 0);
@@ -214,6 +227,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const uint32_t first_slot = L.claim[ci];
     const uint32_t cc = L.col[qc], cn = L.col[qn], cj = L.col[qj];
     const bool seen = (b >> 24) == epoch;
+    M3_TT(3);  // entry read + second round of reads issued (wait happens at first use)
     // :437-440 (an entry that is not shorter is dropped) and :443-445 (no head-room); cells >= Z read as not-AIR
     const bool accept = live && !(seen && (int)((b >> 12) & 0xFFFu) <= len) && ((cc >> (z + 1)) & 1u);
     // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
@@ -228,6 +242,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const bool acc0 = doit && d == 0;
     if (acc0) L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
     mkl |= acc0 ? ((x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z)) : 0u;
+    M3_TT(4);  // accept / claim / order / best
     // Successor in direction d (helper_3D._passable :214-319), branch-free on 6-bit windows of the columns: bit i of
     // a window = AIR at height z-2+i (below the floor and above the ceiling read as not-AIR, which is what every rule's
     // explicit bounds check amounts to).  The six rules are mutually exclusive.
@@ -250,6 +265,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     rs |= doit ? ((1ull << qc) | (n_in ? 1ull << qn : 0ull) | (j_in ? 1ull << qj : 0ull)) : 0ull;
     zlo = doit ? min(zlo, z) : zlo;
     zhi = doit ? max(zhi, z) : zhi;
+    M3_TT(5);  // move rules + read set
     // never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it)
     const uint32_t bt = L.best[ok ? tcell : 0];
     if ((bt >> 24) == epoch && (int)((bt >> 12) & 0xFFFu) <= len + add) ok = false;
@@ -265,7 +281,9 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
                      (uint32_t)(len + add) | ((uint32_t)tx << 12) | ((uint32_t)ty << 18) | ((uint32_t)tz << 24) | ((uint32_t)d << 28));
     tail += npush;
     head += nproc;
+    M3_TT(6);  // prune read + push
   }
+#undef M3_TT
   mk = wave_or8(mkl);
 #ifdef PCGRL_PHASE_TIMING
   if (c.lane == 0) {
@@ -314,14 +332,11 @@ __device__ inline void m3_fill_slot(M3Lds &L, const M3Ctx &c, int s, int sx, int
   } while (0)
 #endif
   m3_search(L, c, sx, sy, sz, n_order, mk, rs, zlo, zhi, overflow);
-  M3_T(3);
   if (overflow) return;
   const int YX = c.Y * c.X;
   (void)m3_farthest(L, c, n_order, e1);
   const uint32_t f1 = L.ent[e1].y;
-  M3_T(4);
   m3_search(L, c, (int)((f1 >> 12) & 63u), (int)((f1 >> 18) & 63u), (int)((f1 >> 24) & 15u), n_order, mk2, rs, zlo, zhi, overflow);
-  M3_T(5);
   if (overflow) return;
   (void)m3_farthest(L, c, n_order, e2);
   // OR of the lanes' read sets (DPP inside the 16-lane rows, then across); min / max of the heights ride along as a
@@ -378,7 +393,6 @@ __device__ inline void m3_fill_slot(M3Lds &L, const M3Ctx &c, int s, int sx, int
     S.rs[0] = lo;
     S.rs[1] = hi;
   }
-  M3_T(6);
 #undef M3_T
 }
 

@@ -14,7 +14,7 @@ g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
 out = np.zeros(8 * n, np.uint64)
-names = ["trips", "cyc_far2+chain", "n_searches", "cyc_search1", "searches", "cyc_far1", "cyc_search2", "wall"]
+names = ["trips", "trip:push", "n_searches", "trip:reads", "searches", "trip:accept", "trip:rules", "wall"]
 rows = []
 for k in range(700):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
