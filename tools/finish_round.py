@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Collect a round's measurements into the tracked files:
+  gpurun_out/bench_<tag>_*.log         -> profiles/<tag>_bench_lines.json
+  gpurun_out/summary/<tag>_*           -> profiles/
+and regenerate the measurement tables of DESIGN.md / README.md between their <!-- NAME --> ... <!-- /NAME --> markers.
+  python tools/finish_round.py r02"""
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+short = tag.replace("r0", "r")  # bench logs are named bench_r2_*.log
+G = os.path.join(ROOT, "gpurun_out")
+
+lines = {}
+for f in sorted(glob.glob(os.path.join(G, f"bench_{short}_*.log"))):
+    name = os.path.basename(f)[len(f"bench_{short}_"):-4]
+    txt = [l for l in open(f).read().splitlines() if l.startswith("{")]
+    if txt:
+        lines[name] = json.loads(txt[-1])
+with open(os.path.join(ROOT, "profiles", f"{tag}_bench_lines.json"), "w") as fh:
+    json.dump(lines, fh, indent=1)
+for f in glob.glob(os.path.join(G, "summary", f"{tag}_*")):
+    shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
+summ = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_summary.json")))
+
+
+def fmt(x, d=2):
+    return f"{x:.{d}f}"
+
+
+def sci(x):
+    e = int(f"{x:e}".split("e")[1])
+    return f"{x / 10 ** e:.2f} × 10{str(e).translate(str.maketrans('0123456789-', '⁰¹²³⁴⁵⁶⁷⁸⁹⁻'))}"
+
+
+def kernel_us(w):
+    d = summ["workloads"].get(w, {}).get("dominant_kernel_launch")
+    return d["duration_ns"] if d else None
+
+
+b = lines["binary-narrow"]
+ws = summ["workloads"]["binary-narrow"]
+dk = ws["dominant_kernel_launch"]["duration_ns"]
+tr = ws["hbm_traffic_per_launch"]
+sq = next(v for k, v in ws["pmc"].items() if "step_kernel" in k)
+eager = lines.get("binary-narrow-eager")
+big = lines.get("binary-narrow-65536")
+headline = f"""| quantity | value | source |
+|---|---|---|
+| env-steps/s | **{sci(b['value'])}** (north-star target 1 × 10⁷) | `bench.py`, wall clock |
+| per step | {fmt(b['ms_per_step'] * 1e3)} µs wall = {fmt(b['roofline']['avg_launch_us'])} µs by HIP events on the launch stream""" + (f"; eager launches from the Python loop: {fmt(eager['ms_per_step'] * 1e3)} µs (host-bound)" if eager else "") + f""" | `bench.py` |
+| step kernel, begin–end under `rocprofv3 --kernel-trace` | mean {fmt(dk['mean'] / 1e3)} µs, median {fmt(dk['median'] / 1e3)}, p10 {fmt(dk['p10'] / 1e3)}, p99 {fmt(dk['p99'] / 1e3)} ({ws['dominant_kernel_launch']['launches']} launches; start-to-start {fmt(ws['dominant_kernel_launch']['median_start_to_start_ns'] / 1e3)} µs) | `profiles/{tag}_kernel_stats.csv`, `profiles/{tag}_summary.json` |
+| roofline | {b['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic / {fmt(b['ms_per_step'] * 1e3)} µs = {b['roofline']['achieved'] / 1e3:.2f} TB/s = **{fmt(b['roofline']['frac'], 3)} of 8 TB/s** (from the profiled kernel mean: {fmt(b['roofline']['algorithmic_bytes_per_launch'] / (dk['mean'] * 1e-9) / 8e12, 3)}) | `bench.py` |
+| HBM traffic | WRITE_SIZE {tr['write_bytes'] / 1e6:.1f} MB + 2×FETCH_SIZE {tr['fetch_bytes_x2_correction'] / 1e6:.1f} MB = {tr['traffic_bytes'] / 1e6:.1f} MB / launch = {fmt(tr['traffic_over_algorithmic'])} × algorithmic | `profiles/{tag}_summary.json` |
+| waves / LDS | {ws['occupancy']['waves_per_launch']:.0f} waves per launch ({ws['occupancy']['waves_per_cu']:.0f} per CU); {sq['SQ_INSTS_VALU']['mean_per_launch'] / 1e6:.2f} M VALU, {sq['SQ_INSTS_SALU']['mean_per_launch'] / 1e6:.2f} M SALU, {sq['SQ_INSTS_LDS']['mean_per_launch'] / 1e3:.0f} k LDS instructions; LDS bank-conflict cycles / LDS active cycles = {fmt(ws['lds']['bank_conflict_rate'])} (the byte-granular one-hot scatter into the observation rows) | `profiles/{tag}_summary.json` |
+""" + (f"| same kernel, 65 536 envs | {fmt(big['ms_per_step'] * 1e3, 1)} µs ⇒ **{sci(big['value'])} steps/s, {fmt(big['roofline']['frac'], 2)} of 8 TB/s** | `bench.py --envs 65536` |\n" if big else "") + f"""| open-loop rollout (64 steps per launch, every observation written) | {fmt(b['open_loop_rollout']['us_per_step'])} µs per step, {sci(b['open_loop_rollout']['value'])} steps/s, {fmt(b['open_loop_rollout']['roofline_frac'], 2)} of the roofline | `bench.py` `open_loop_rollout` |
+| CPU oracle (C port, OpenMP, {b['cpu_baseline']['cores']} threads of {b['cpu_baseline']['usable_cores']} usable cores, {b['cpu_baseline']['cpu_model']}) | {sci(b['cpu_baseline']['value'])} steps/s ({sci(b['cpu_baseline']['one_core'])} on one core) | `bench.py` `cpu_baseline` |
+| reference Python env (survey probe, 1 core) | ≈ 750 steps/s | BASELINE.md |"""
+
+d20 = lines.get("driver_20_5")
+driver20 = (f"{fmt(d20['ms_per_step'] * 1e3)} µs per step, {sci(d20['value'])} env-steps/s, {fmt(d20['ms_per_step'] / b['ms_per_step'])} × the long run"
+            if d20 else "n/a")
+
+NOTES = {
+    "binary-narrow": "headline",
+    "zelda-turtle": "store-bound: 37.7 MB of observations per launch",
+    "zelda-turtle-bfs": "SURVEY §8 d \"BFS-active\": maps with exactly one player / key / door re-injected every 128 steps, actions = moves and empty / solid / enemy placements (both single-source searches run); incl. the injection launches",
+    "sokoban-wide": "compile-time 16×16 wide kernel; rare solver calls after resets (dense random levels) are in the mean",
+    "minecraft_3D_maze-narrow": "the launch waits for the env with the most open map (§4.2)",
+    "binary-narrow-static": "static tiles (p ≤ 0.3, 3 walls), general kernel",
+    "binary-narrow-patch3x3": "3×3 action patch, general kernel",
+    "sokoban-wide-solver": "solver-active, see below",
+}
+rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|"]
+for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
+    if w not in lines:
+        continue
+    l = lines[w]
+    k = kernel_us(w)
+    ks = f"{k['mean'] / 1e3:.2f} / {k['median'] / 1e3:.2f}" if k else "–"
+    ro = l.get("open_loop_rollout")
+    cb = l.get("cpu_baseline")
+    rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {ks} | {l['roofline']['frac']:.3f} | "
+                + (f"{ro['us_per_step']:.2f}" if ro else "–") + " | " + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + f" | {NOTES.get(w, '')} |")
+extra = []
+for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow"):
+    s_ = summ["workloads"].get(w, {})
+    if "hbm_traffic_per_launch" in s_ and "lds" in s_:
+        extra.append(f"{w}: traffic {s_['hbm_traffic_per_launch']['traffic_bytes'] / 1e6:.1f} MB / launch = {s_['hbm_traffic_per_launch']['traffic_over_algorithmic']:.2f} × algorithmic, "
+                     f"{s_['occupancy']['waves_per_cu']:.0f} waves per CU, LDS bank-conflict rate {s_['lds']['bank_conflict_rate']:.2f}")
+workload_table = "\n".join(rows) + "\n\nCounters (`profiles/" + tag + "_summary.json`): " + "; ".join(extra) + "."
+
+sa = lines.get("sokoban-wide-solver")
+solver_active = ""
+if sa:
+    cb = sa.get("cpu_baseline") or {}
+    solver_active = (f"Engine: {sci(sa['value'])} env-steps/s ({sa['ms_per_step']:.0f} ms per step launch at 2048 envs, "
+                     f"{100 * sa['solver_active']['envs_with_solver_result_at_end']:.0f} % of the envs with a solver result at the end, "
+                     f"{100 * sa['solver_active']['envs_solved_at_end']:.0f} % solved); CPU oracle: {sci(cb.get('value', 0))} on {cb.get('cores', '?')} threads.")
+
+blocks = {"HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active}
+p = os.path.join(ROOT, "DESIGN.md")
+s = open(p).read()
+for name, text in blocks.items():
+    inline = name in ("DRIVER20", "SOLVER_ACTIVE")
+    new = f"<!-- {name} -->{'' if inline else chr(10)}{text}{'' if inline else chr(10)}<!-- /{name} -->"
+    if f"@@{name}@@" in s:
+        s = s.replace(f"@@{name}@@", new)
+    else:
+        s = re.sub(rf"<!-- {name} -->.*?<!-- /{name} -->", lambda m: new, s, flags=re.S)
+open(p, "w").write(s)
+print(headline)
+print(workload_table)
+print(driver20)
+print(solver_active)
