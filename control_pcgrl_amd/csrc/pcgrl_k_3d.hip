@@ -5,6 +5,16 @@
 
 hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
+  const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7 && p.cfg.obs_window[0] == 14 &&
+                  p.cfg.obs_window[1] == 14 && p.cfg.obs_window[2] == 14;
+  if (d7 && id == K_STEP) {
+    hipLaunchKernelGGL((m3_kernel<M3_STEP, true>), grid, dim3(128), 0, s, p, cpl);
+    return hipGetLastError();
+  }
+  if (d7 && id == K_ROLLOUT) {
+    hipLaunchKernelGGL((m3_kernel<M3_ROLLOUT, true>), grid, block, 0, s, p, cpl);
+    return hipGetLastError();
+  }
   switch (id) {
     case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP>), grid, dim3(128), 0, s, p, cpl); break;  // simulate + observe wave
     case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET>), grid, block, 0, s, p, cpl); break;

@@ -104,24 +104,25 @@ __device__ inline uint64_t dpp64_down(uint64_t v) {  // from lane+1
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// maximum over the 64 lanes, result in every lane: DPP butterfly inside the 16-lane rows, then across rows
+// maximum over the 64 lanes (result uniform): DPP butterfly inside the 16-lane rows, the four rows through SGPRs
 __device__ inline uint32_t wave_max(uint32_t v) {
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
-  v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
-  v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
-  return v;
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
 }
-// OR over the 64 lanes of a value with at most 8 significant bits
-__device__ inline uint32_t wave_or8(uint32_t v) {
-  uint32_t r = 0;
-#pragma unroll
-  for (int b = 0; b < 8; b++) r |= (__ballot((v >> b) & 1u) != 0 ? 1u : 0u) << b;
-  return r;
+// OR over the 64 lanes (result uniform), same shape
+__device__ inline uint32_t wave_or(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
-
 // helper_3D.py:396-406 calc_num_regions (6-neighbour components of AIR)
 __device__ inline int m3_regions(const M3Ctx &c, uint64_t air) {
   uint64_t notx0 = 0, notxl = 0;  // plane bits whose x is not 0 / not X-1
@@ -284,7 +285,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     M3_TT(6);  // prune read + push
   }
 #undef M3_TT
-  mk = wave_or8(mkl);
+  mk = wave_or(mkl);
 #ifdef PCGRL_PHASE_TIMING
   if (c.lane == 0) {
     L.dbg[0] += (uint32_t)dbg_trips;
@@ -341,22 +342,9 @@ __device__ inline void m3_fill_slot(M3Lds &L, const M3Ctx &c, int s, int sx, int
   (void)m3_farthest(L, c, n_order, e2);
   // OR of the lanes' read sets (DPP inside the 16-lane rows, then across); min / max of the heights ride along as a
   // unary mask of the planes seen
-  uint32_t lo = (uint32_t)rs, hi = (uint32_t)(rs >> 32), zm = zlo <= zhi ? ((2u << zhi) - (1u << zlo)) : 0u;
-#define M3_DPP_OR(ctl)                                                                 \
-  lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, ctl, 0xF, 0xF, true);         \
-  hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, ctl, 0xF, 0xF, true);         \
-  zm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)zm, ctl, 0xF, 0xF, true)
-  M3_DPP_OR(0xB1);
-  M3_DPP_OR(0x4E);
-  M3_DPP_OR(0x141);
-  M3_DPP_OR(0x140);
-#undef M3_DPP_OR
-  lo |= (uint32_t)__shfl_xor((int)lo, 16, 64);
-  hi |= (uint32_t)__shfl_xor((int)hi, 16, 64);
-  zm |= (uint32_t)__shfl_xor((int)zm, 16, 64);
-  lo |= (uint32_t)__shfl_xor((int)lo, 32, 64);
-  hi |= (uint32_t)__shfl_xor((int)hi, 32, 64);
-  zm |= (uint32_t)__shfl_xor((int)zm, 32, 64);
+  // OR of the lanes' read sets; min / max of the heights ride along as a unary mask of the planes seen
+  const uint32_t lo = wave_or((uint32_t)rs), hi = wave_or((uint32_t)(rs >> 32));
+  uint32_t zm = wave_or(zlo <= zhi ? ((2u << zhi) - (1u << zlo)) : 0u);
   // The tiles of paths[(mx,my,mz)] as a bit mask: every lane walks the parent chain (uniform reads), lane w keeps word
   // w of the mask.  An entry knows its move kind and direction, so the parent's cell and the intermediate tiles of the
   // move (helper_3D.py:214-319) follow without reading the parent: +-YX = one plane up / down.
@@ -555,15 +543,18 @@ __device__ inline void m3_advance_pos(const M3Ctx &c, int *pos, int &n_step) {
   n_step++;
 }
 
-template <int MODE>
+// D7: the BASELINE map shape 7 x 7 x 7 with compile-time dimensions (the search trip is instruction-bound: constant
+// strides and bounds take a fifth of its instructions away)
+template <int MODE, bool D7 = false>
 __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p, int cpl) {
   __shared__ M3Lds L;
   __shared__ M3ObsLds O;
   M3Ctx c;
   c.lane = (int)__lane_id();
-  c.Z = p.cfg.dims[0];
-  c.Y = p.cfg.dims[1];
-  c.X = p.cfg.dims[2];
+  c.Z = D7 ? 7 : p.cfg.dims[0];
+  c.Y = D7 ? 7 : p.cfg.dims[1];
+  c.X = D7 ? 7 : p.cfg.dims[2];
+  if (D7) cpl = 6;  // ceil(343 / 64)
   c.n_cells = c.Z * c.Y * c.X;
   c.nw = (c.n_cells + 31) >> 5;
   const int env = blockIdx.x;
