@@ -120,6 +120,7 @@ class VecPcgrlEnv:
         _lib.check(L.pcgrl_create(C.byref(self.cfg), self.num_envs, dev_index, C.byref(h)), "pcgrl_create")
         self._h = h
         self._L = L
+        self._dev_index = dev_index
         shape = (C.c_int32 * 4)()
         nd = C.c_int32()
         _lib.check(L.pcgrl_obs_shape(h, C.byref(shape), C.byref(nd)), "pcgrl_obs_shape")
@@ -139,6 +140,12 @@ class VecPcgrlEnv:
         self._reward64 = torch.empty(N, dtype=torch.float64, device=dev) if reward_dtype == torch.float64 else None
         self._ctrl_obs = torch.zeros((N, 2 * len(self.controls)), dtype=torch.float32, device=dev) if self.controls else None
         self._ex = self._reward64 is not None or self._ctrl_obs is not None
+        # step() hands out the same tensors every call (they are overwritten in place): the tuple is built once
+        done = self._done.view(torch.bool)
+        info = {"stats": self._stats}
+        if self._ctrl_obs is not None:
+            info["ctrl_obs"] = self._ctrl_obs
+        self._step_out = (self._obs, self._reward64 if self._reward64 is not None else self._reward, done, done, info)
         if seeds is not None:
             self.seed(seeds)
 
@@ -155,7 +162,11 @@ class VecPcgrlEnv:
             pass
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """raw hipStream_t of torch's current stream on the env's device (the fast accessor when this torch has it)"""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self._dev_index)
+        except AttributeError:  # pragma: no cover
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     def seed(self, seeds):
         """Env i gets numpy PCG64(SeedSequence(seeds[i])) for both RNG streams (envs/pcgrl_env.py:142-146)."""
@@ -205,11 +216,7 @@ class VecPcgrlEnv:
                                     self._ptrs[1], self._ptrs[2], self._ptrs[3], self._stream())
         if rc:
             _lib.check(rc, "pcgrl_step")
-        done = self._done.view(torch.bool)
-        info = {"stats": self._stats}
-        if self._ctrl_obs is not None:
-            info["ctrl_obs"] = self._ctrl_obs
-        return self._obs, (self._reward64 if self._reward64 is not None else self._reward), done, done, info
+        return self._step_out
 
     # -- controllable generation (control_wrappers.py:27-121) -----------------------------------------------------
     def queue_targets(self, trgs, mask=None):

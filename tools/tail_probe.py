@@ -43,3 +43,12 @@ print("20 steps + event sync %.1f us" % t(twenty_e, 50))
 def launch_only():
     for k in range(20): env.step_raw(acts[k].data_ptr(), sptr)
 print("20 launches (host)   %.1f us" % t(launch_only, 50)); torch.cuda.synchronize()
+# the Python wrapper a policy-in-the-loop user calls (tensor checks + ctypes + launch), host side only
+a32 = acts[0].contiguous()
+def wrapped():
+    for k in range(20): env.step(a32)
+print("20 x VecPcgrlEnv.step (host) %.1f us" % t(wrapped, 50)); torch.cuda.synchronize()
+def wrapped_sync():
+    for k in range(20): env.step(a32)
+    torch.cuda.synchronize(dev)
+print("20 x VecPcgrlEnv.step + sync %.1f us" % t(wrapped_sync, 50))
