@@ -194,6 +194,11 @@ def test_zelda_turtle_4096_envs_vs_oracle():
     assert n_done == 4096
 
 
+def test_sokoban_wide_2048_envs_vs_oracle():
+    """BASELINE configs[3] at its batch size (2048 envs per GPU): random wide actions, auto-reset."""
+    _rollout_vs_oracle("sokoban", "wide", (16, 16), 2048, 400, seed0=77, full_every=131, threads=16, change_percentage=0.2)
+
+
 @pytest.mark.parametrize("problem,rep", [("binary", "turtle"), ("binary", "wide"), ("zelda", "narrow"),
                                          ("zelda", "wide"), ("sokoban", "narrow"), ("sokoban", "turtle"),
                                          ("sokoban", "wide")])
