@@ -265,35 +265,35 @@ def main():
     GR = args.rollout_steps
 
     def measure_rollout():
-      rollout = None
-      if GR > 0 and not wkw and not bfs_active and POOL >= GR:  # (bfs-active needs the periodic map injection)
-          R = max(args.rollout_launches, 1)
-          obs_r = torch.empty((GR, N) + env.obs_shape, dtype=torch.uint8, device=dev)
-          rew_r = torch.empty((GR, N), dtype=torch.float32, device=dev)
-          done_r = torch.empty((GR, N), dtype=torch.uint8, device=dev)
-          stats_r = torch.empty((GR, N, env.n_stats), dtype=torch.int32, device=dev)
+        rollout = None
+        if GR > 0 and not wkw and not bfs_active and POOL >= GR:  # (bfs-active needs the periodic map injection)
+            R = max(args.rollout_launches, 1)
+            obs_r = torch.empty((GR, N) + env.obs_shape, dtype=torch.uint8, device=dev)
+            rew_r = torch.empty((GR, N), dtype=torch.float32, device=dev)
+            done_r = torch.empty((GR, N), dtype=torch.uint8, device=dev)
+            stats_r = torch.empty((GR, N, env.n_stats), dtype=torch.int32, device=dev)
 
-          def run_rollouts(n):
-              for i in range(n):
-                  rc = env._L.pcgrl_rollout(env._h, base + ((i * GR) % (POOL - GR + 1)) * stride, GR, 1, obs_r.data_ptr(), 0,
-                                            rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
-                  if rc:
-                      raise RuntimeError(f"pcgrl_rollout rc={rc}")
+            def run_rollouts(n):
+                for i in range(n):
+                    rc = env._L.pcgrl_rollout(env._h, base + ((i * GR) % (POOL - GR + 1)) * stride, GR, 1, obs_r.data_ptr(), 0,
+                                              rew_r.data_ptr(), done_r.data_ptr(), stats_r.data_ptr(), sptr)
+                    if rc:
+                        raise RuntimeError(f"pcgrl_rollout rc={rc}")
 
-          run_rollouts(max(1, R // 10))
-          barrier()
-          t1 = time.perf_counter()
-          run_rollouts(R)
-          barrier()
-          el_r, _ = max_over_ranks(time.perf_counter() - t1)
-          env.check_errors()
-          us = el_r / (R * GR) * 1e6
-          rollout = {"value": total_envs * R * GR / el_r, "unit": "env-steps/s", "steps_per_launch": GR, "launches": R,
-                     "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "note": "open-loop action sequences only (actions known in advance); all per-step outputs written; "
-                             "measured before the timed region"}
-          del obs_r
-      return rollout
+            run_rollouts(max(1, R // 10))
+            barrier()
+            t1 = time.perf_counter()
+            run_rollouts(R)
+            barrier()
+            el_r, _ = max_over_ranks(time.perf_counter() - t1)
+            env.check_errors()
+            us = el_r / (R * GR) * 1e6
+            rollout = {"value": total_envs * R * GR / el_r, "unit": "env-steps/s", "steps_per_launch": GR, "launches": R,
+                       "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                       "note": "open-loop action sequences only (actions known in advance); all per-step outputs written; "
+                               "measured before the timed region"}
+            del obs_r
+        return rollout
 
     # the reporting path's buffers (pinned host memory takes milliseconds to allocate: nothing slow may sit between the
     # warm-up steps and the timed region)

@@ -1,5 +1,7 @@
-import sys, time, ctypes
-sys.path.insert(0, "/root/repo")
+"""Host-side latencies around the step launch (one MI355X): synchronisation flavours, eager launch rate, the Python
+wrapper's per-call cost.  Run on the GPU box: python tools/tail_probe.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from control_pcgrl_amd import VecPcgrlEnv
 dev = torch.device("cuda:0")
