@@ -33,7 +33,7 @@ def short(name):
 
 
 def is_m3_step(name):
-    return "m3_kernel<0>" in name or "m3_kernel<(pcgrl::M3Mode)0>" in name
+    return "m3_kernel<0" in name or "m3_kernel<(pcgrl::M3Mode)0" in name  # (<0>, <0, true>: the 7x7x7 variant)
 
 
 def summarize(w, stats_rows):
