@@ -80,6 +80,7 @@ struct Params {
   void *soko;             // SokoPool* (sokoban solver workspace), else null
   int32_t *solver_seen;   // host-mapped counter of device solver runs (sokoban), else null
   int32_t spread;         // sokoban step: one env per wave pair (see step_kernel)
+  int32_t sk_helpers;     // sokoban: helper wavefronts per workgroup for the solver's A* stages (0 or 3, see pcgrl_sokoban.h)
   void *m3cache;          // M3Slot[N][M3_SLOTS]: cached path-search results per start plane (3-D maze), else null
   // per-call I/O
   const int32_t *actions;

@@ -58,6 +58,8 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
                                     : (p.cfg.obs_window[0] == 32 && p.cfg.obs_window[1] == 32));
   // stale statistics (after pcgrl_update) are only handled by the general step / rollout kernels
   const bool fast = fast_cfg && !(p.no_fast && (id == K_STEP || id == K_ROLLOUT) && !p.update_only);
+  // sokoban with p.sk_helpers: the solver's helper wavefronts ride behind the simulate / observe waves
+  const unsigned helper_threads = PROB == PCGRL_PROB_SOKOBAN ? 64u * (unsigned)p.sk_helpers : 0u;
   hipError_t e = hipSuccess;
   switch (id) {
     case K_STEP:
@@ -75,18 +77,18 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
           }
 #endif
           if (ctrl)
-            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128), lds, s, p);
+            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128 + helper_threads), lds, s, p);
           else
-            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128), lds, s, p);
+            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128 + helper_threads), lds, s, p);
           break;
         }
       }
       if (p.trg || p.reward64) {
         if ((e = allow_lds(step_kernel<PROB, LPE, M, false, true>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, true>), grid, dim3(128), lds, s, p);
+        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, true>), grid, dim3(128 + helper_threads), lds, s, p);
       } else {
         if ((e = allow_lds(step_kernel<PROB, LPE, M, false, false>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128), lds, s, p);
+        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128 + helper_threads), lds, s, p);
       }
       break;
     case K_ROLLOUT: {
@@ -125,7 +127,8 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
       hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
       break;
     case K_STATS_FOR_GRIDS:  // (sokoban: one map per wavefront, see the kernel)
-      hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), PROB == PCGRL_PROB_SOKOBAN ? dim3(p.n_envs) : grid, block, 0, s, p);
+      hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), PROB == PCGRL_PROB_SOKOBAN ? dim3(p.n_envs) : grid,
+                         dim3(64 + helper_threads), 0, s, p);
       break;
   }
   return hipGetLastError();

@@ -412,6 +412,7 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
   if (h->spread_left > 0) {
     h->spread_left--;
     p.spread = 1;
+    p.sk_helpers = 3;  // ... and three more wavefronts per env run the A* stages next to the BFS stage
   }
 }
 
@@ -780,6 +781,7 @@ int pcgrl_stats_for_grids_h(pcgrl_handle h, int32_t n, const uint8_t *d_grids, i
   p.n_envs = n;  // the kernel touches no per-env engine state
   p.init_grids = d_grids;
   p.stats_out = d_stats;
+  p.sk_helpers = h->p.soko ? 3 : 0;  // sokoban: one map per workgroup, the solver's stages side by side
   HIPCHK(launch(K_STATS_FOR_GRIDS, h->lpe, p, 0, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }

@@ -549,6 +549,17 @@ struct ProbTraits<PCGRL_PROB_MC3DMAZE> {
 template <int LPE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
+// helper wavefronts of the solver (pcgrl_sokoban.h): kernels launched with Params::sk_helpers carry three of them per
+// workgroup, behind the simulate / observe waves
+__device__ inline void sokoban_helper(const Params &p, int k);
+__device__ inline void sokoban_helpers_init();
+__device__ inline void sokoban_helpers_release();
+struct SokoHelpersGuard {  // the simulate wave lets its helpers go when it leaves the kernel, whichever way
+  bool on;
+  __device__ ~SokoHelpersGuard() {
+    if (on) sokoban_helpers_release();
+  }
+};
 
 // cells that count for calc_num_regions: zelda everything but solid and door (zelda_ctrl_prob.py:104), sokoban
 // everything but solid (sokoban_prob.py:166)
@@ -1466,7 +1477,8 @@ template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
 #ifndef PCGRL_STEP_WAVES
 #define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
 #endif
-__global__ __launch_bounds__(128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : 1) void step_kernel(Params p) {
+__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 320 : 128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : 1)
+void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
@@ -1475,7 +1487,21 @@ __global__ __launch_bounds__(128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? 
   const int wave = (int)(threadIdx.x >> 6), pair = wave >> 1;
   const bool observer = (wave & 1) != 0;  // wave-uniform
   uint8_t *lds = lds_all + (size_t)pair * p.lds_pair_bytes;
-  if (observer && p.obs == nullptr) return;  // (no barrier below is reached by wave 0 in that case either)
+  // sokoban, launched with p.sk_helpers (while its solver is busy): waves 2.. are the solver's helpers
+  const bool helped = PROB == PCGRL_PROB_SOKOBAN && p.sk_helpers != 0;
+  if constexpr (PROB == PCGRL_PROB_SOKOBAN) {
+    if (wave >= 2 * PAIRS) {
+      if (wave == 2 * PAIRS) sokoban_helpers_init();
+      __syncthreads();
+      sokoban_helper(p, wave - 2 * PAIRS + 1);
+      return;
+    }
+  }
+  if (observer && p.obs == nullptr) {  // (no barrier below is reached by wave 0 in that case either)
+    if (helped) __syncthreads();
+    return;
+  }
+  SokoHelpersGuard helpers_guard{helped && !observer};
   PHASE_DECL();
   TRACE_DECL();
   const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
@@ -1517,7 +1543,7 @@ __global__ __launch_bounds__(128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? 
   if (observer && p.auto_reset != 0 && (iteration + 1 > p.cfg.max_iterations || p.cfg.max_changes >= 0) && g.row < 8)
     rng_stash[g.row] = ((const uint64_t *)&p.rng[e])[g.row];  // rep[4], prob[4]
   // both waves have read the old state before wave 0 may overwrite it
-  if (p.obs != nullptr) __syncthreads();
+  if (p.obs != nullptr || helped) __syncthreads();
   PHASE_MARK(0);  // loads + barrier
   const M tile0_old = b[0];
   M pre[NB];  // pre-update tile planes (zelda / sokoban: incremental region count)
@@ -2053,10 +2079,22 @@ __global__ __launch_bounds__(64) void last_episode_kernel(Params p) {
 
 // Problem.get_stats on caller-provided byte grids (no engine state)
 template <int PROB, int LPE, typename M>
-__global__ __launch_bounds__(64) void stats_for_grids_kernel(Params p) {
+__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 256 : 64) void stats_for_grids_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   Grp<LPE> g;
   g.init();
+  const bool helped = PROB == PCGRL_PROB_SOKOBAN && p.sk_helpers != 0;  // waves 1..3: the solver's helpers
+  if constexpr (PROB == PCGRL_PROB_SOKOBAN) {
+    const int wave = (int)(threadIdx.x >> 6);
+    if (wave >= 1) {
+      if (wave == 1) sokoban_helpers_init();
+      __syncthreads();
+      sokoban_helper(p, wave);
+      return;
+    }
+    if (helped) __syncthreads();
+  }
+  SokoHelpersGuard helpers_guard{helped};
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   // sokoban: one map per wavefront (its first lane group) -- a wave runs the solver for one of its maps at a time, so
   // spreading the maps over waves lets all of them search concurrently

@@ -17,6 +17,12 @@
 // The open list stores (2h + 2*balance*depth) << 16 | node, so CPython's sift comparisons read no node records.
 // Node pool / visited table / open list live in an HBM workspace slot taken from a lock-protected pool sized to the
 // batch; a wavefront holds at most one slot at a time (no lock cycles however many envs need solving at once).
+//
+// The four stages of the cascade are independent searches from the same root: only which results are USED depends on
+// the order.  Kernels launched with Params::sk_helpers = 3 carry three helper wavefronts per workgroup that run the A*
+// stages speculatively (each in its own quarter of the slot) while the simulate wave runs the BFS stage; a stage is
+// cancelled as soon as an earlier one has won (or the BFS stage has expanded the whole state space), so the launch
+// waits for the longest single stage instead of the sum of four.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,6 +32,36 @@
 #include "pcgrl_kernels2d.h"
 
 namespace pcgrl {
+
+// Development aid: -DPCGRL_SK_TIMING adds up the shader-clock cycles of the phases of a search iteration (pop, record
+// loads + win test, visited set, children) per stage kind into p.err[64..] (tools/solver_phase.py).  Not shipped.
+#ifdef PCGRL_SK_TIMING
+#define SK_T_DECL() uint64_t _skt[5] = {0, 0, 0, 0, 0}; uint64_t _sk_prev = __builtin_readcyclecounter()
+#define SK_T_MARK(i)                                 \
+  do {                                               \
+    const uint64_t _t = __builtin_readcyclecounter(); \
+    _skt[i] += _t - _sk_prev;                        \
+    _sk_prev = _t;                                   \
+  } while (0)
+#define SK_T_FLUSH(kind, iters)                                                                         \
+  do {                                                                                                  \
+    if (c.lane == 0 && c.dbg != nullptr) {                                                              \
+      for (int _i = 0; _i < 5; _i++) atomicAdd(c.dbg + (kind) * 8 + _i, (unsigned long long)_skt[_i]);   \
+      atomicAdd(c.dbg + (kind) * 8 + 5, (unsigned long long)(iters));                                   \
+      atomicAdd(c.dbg + (kind) * 8 + 6, 1ull);                                                          \
+    }                                                                                                   \
+  } while (0)
+#else
+#define SK_T_DECL() \
+  do {              \
+  } while (0)
+#define SK_T_MARK(i) \
+  do {               \
+  } while (0)
+#define SK_T_FLUSH(kind, iters) \
+  do {                          \
+  } while (0)
+#endif
 
 constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
 constexpr int SK_MAXDIM = 34;    // bordered level side (W+2, H+2 <= 34)
@@ -46,13 +82,32 @@ struct alignas(16) SokoNode {
 };
 static_assert(sizeof(SokoNode) == 16, "node header");
 
+constexpr int SK_STAGES = 4;  // BFS, A* balance 1, 0.5, 0 (sokoban_prob.py:131-145)
 struct SokoPool {  // lives in Params-reachable global memory
   int32_t n_slots, max_nodes;
-  size_t slot_bytes;
+  size_t stage_bytes;  // one stage's workspace; a slot holds SK_STAGES of them
   uint8_t *base;
   int32_t *locks;   // [n_slots] 0 = free
-  uint32_t *epochs; // [n_slots]
+  uint32_t *epochs; // [n_slots][SK_STAGES]
 };
+// hand-over between the simulate wave and the helper waves of its workgroup (LDS)
+struct SokoMail {
+  int32_t seq;           // job number, bumped by the simulate wave once the level and the fields below are in place
+  int32_t exit;          // the simulate wave is done with the launch
+  int32_t slot, px, py, power;
+  int32_t cancel_after;  // stages with a larger index stop
+  int32_t done[SK_STAGES], won[SK_STAGES], h[SK_STAGES], depth[SK_STAGES];
+};
+struct SokoShared {
+  SokoLevel level;
+  SokoMail mail;
+};
+__device__ inline SokoShared &sk_shared() {
+  __shared__ SokoShared s;
+  return s;
+}
+__device__ inline int sk_ld(const int32_t *x) { return __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void sk_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 struct SokoCtx {
   SokoLevel *lv;
@@ -63,7 +118,9 @@ struct SokoCtx {
   int32_t n_nodes, max_nodes, ncr;
   uint32_t epoch;
   int lane;
+  int stage;  // which quarter of the slot this context is bound to
   bool pool_full;
+  unsigned long long *dbg;  // PCGRL_SK_TIMING builds
 };
 
 __device__ inline bool sk_bit(const uint64_t *rows, int x, int y) { return (rows[y] >> x) & 1ull; }
@@ -254,78 +311,138 @@ __device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py
 
 // stage: b2 < 0 -> BFSAgent (engine.py:56-74); else AStarAgent with balance b2 / 2 (engine.py:96-119).  Uniform over
 // the wave.  Node 0 = root, already filled by the caller.
+// ---- the A* open list: CPython's heapq on c.q[0 .. tail), entries (2h + b2*depth) << 16 | node, compared by the key only
+// (Node.__lt__ engine.py:49-50).  heapq's sift loops are chains of dependent reads; here a wavefront reads five levels of
+// the tree per memory round trip (lane j holds the j-th descendant of the current position in level order) and walks them
+// with scalar lane reads, remembers the path in its lanes and writes the whole path back with one store.
+__device__ inline bool sk_key_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
+
+// heapq.heappop (heapq.py:129-141 + _siftup :258-277 + _siftdown :205-218); tail > 0 on entry
+__device__ inline uint32_t sk_heappop(SokoCtx &c, int &tail) {
+  const int lane = c.lane;
+  tail--;
+  int pos = 0, depth = 0;
+  uint32_t myval = 0, myprev = 0, last = 0, top = 0;
+  int mypos = 0;
+  bool leaf = false;
+  // local index t = lane + 1 of the subtree rooted at `pos` (t = 0): level l = floor(log2(t + 1)), offset t + 1 - 2^l
+  const int t1 = lane + 2, lvl = 31 - __builtin_clz((unsigned)t1), off = t1 - (1 << lvl);
+  for (int round = 0; !leaf; round++) {
+    int idx = ((pos + 1) << lvl) - 1 + off;
+    if (round == 0 && lane == 62) idx = 0;     // the item to return
+    if (round == 0 && lane == 63) idx = tail;  // heap.pop(): the last element, re-inserted from the root
+    const bool in = (lane < 62 ? idx < tail : round == 0);
+    const uint32_t v = in ? c.q[idx] : 0u;
+    if (round == 0) {
+      top = (uint32_t)__builtin_amdgcn_readlane((int)v, 62);
+      last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+      if (tail == 0) return last;  // it was the only element
+    }
+    int loc = 0;  // local index of `pos`
+    for (int step = 0; step < 5; step++) {
+      int child = 2 * pos + 1, cloc = 2 * loc + 1;
+      if (child >= tail) {
+        leaf = true;
+        break;
+      }
+      uint32_t pick = (uint32_t)__builtin_amdgcn_readlane((int)v, cloc - 1);
+      if (child + 1 < tail) {
+        const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)v, cloc);
+        if (!sk_key_lt(pick, rc)) {
+          child++;
+          cloc++;
+          pick = rc;
+        }
+      }
+      // heap[pos] = heap[childpos]
+      if (lane == depth) {
+        myval = pick;
+        mypos = pos;
+      }
+      if (lane == depth + 1) myprev = pick;
+      pos = child;
+      loc = cloc;
+      depth++;
+    }
+  }
+  // heap[pos] = newitem; _siftdown(heap, 0, pos): `last` climbs while it is smaller than the parent (= the picks above it)
+  if (lane == depth) mypos = pos;
+  const uint64_t smaller = __ballot(lane < depth && sk_key_lt(last, myval));
+  const uint64_t stops = ~smaller & ((1ull << depth) - 1ull);
+  const int m = stops ? depth - 1 - (63 - __builtin_clzll(stops)) : depth;  // levels `last` climbs
+  if (lane <= depth) c.q[mypos] = lane < depth - m ? myval : (lane == depth - m ? last : myprev);
+  return top;
+}
+
+// heapq.heappush (heapq.py:129-132 + _siftdown): the ancestors of the new leaf are read together (their positions follow
+// from the leaf's alone); those larger than the item move down one level each.
+__device__ inline void sk_heappush(SokoCtx &c, int &tail, uint32_t item) {
+  const int lane = c.lane, pos = tail++;
+  const int levels = 31 - __builtin_clz((unsigned)(pos + 1));  // ancestors of pos
+  const int sh = lane < 30 ? lane : 30;
+  const int anc = ((pos + 1) >> (sh + 1)) - 1;                 // lane j: ancestor j + 1 (ancestor 0 = pos itself)
+  const bool has = lane < levels;
+  const uint32_t v = has ? c.q[anc] : 0u;
+  const uint64_t up = __ballot(has && sk_key_lt(item, v));
+  const uint64_t stop = ~up;
+  const int m = __builtin_ctzll(stop);  // (bit `levels` is always clear in `up`)
+  const int mine = ((pos + 1) >> sh) - 1;  // ancestor `lane`
+  if (lane < m) c.q[mine] = v;
+  if (lane == m) c.q[mine] = item;
+}
+
+// `cancel` (helper-wave mode): the stage gives up as soon as *cancel < my_stage (its result is not needed).
 template <bool BIG>
 __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
-                                bool *exhausted = nullptr) {
+                                bool *exhausted = nullptr, const int32_t *cancel = nullptr, int my_stage = 0) {
+  uint32_t *epoch_word = &pool.epochs[slot * SK_STAGES + c.stage];
   uint32_t ep = 0;
-  if (c.lane == 0) ep = (atomicAdd(&pool.epochs[slot], 1u) + 1u) & 0x7FFFu;
+  if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
   ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
   if (ep == 0) {  // wrapped: start over with a clean table
     for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = 0;
-    if (c.lane == 0) ep = (atomicAdd(&pool.epochs[slot], 1u) + 1u) & 0x7FFFu;
+    if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
     ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
   }
   c.epoch = ep;
   c.n_nodes = 1;
   const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
   int head = 0, tail = 0, best = -1, best_h = 0, best_depth = 0, iters = 0;
-  // Node.__lt__ engine.py:49-50 on the keys kept in the heap entries: h + balance*depth <=> 2h + b2*depth
-  auto lt = [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); };
-  auto siftdown = [&](int startpos, int pos, uint32_t item) {  // heapq._siftdown of `item` placed at `pos`
-    while (pos > startpos) {
-      const int pp = (pos - 1) >> 1;
-      const uint32_t parent = c.q[pp];
-      if (lt(item, parent)) {
-        if (c.lane == 0) c.q[pos] = parent;
-        pos = pp;
-        continue;
-      }
-      break;
-    }
-    if (c.lane == 0) c.q[pos] = item;
-  };
   const int h_root = c.nodes[0].h;
   if (c.lane == 0) c.q[0] = b2 < 0 ? 0u : ((uint32_t)(2 * h_root) << 16);
   tail = 1;
-  // BFS: the node after the current one is already in the queue, so its record is requested one iteration ahead
+  // BFS: the queue is read 64 entries at a time (lane l holds q[qbase + l]) and the node after the current one is
+  // already in it, so its record is requested one iteration ahead
+  int qbase = 0, qvalid = 0;
+  uint32_t qv = 0;
+  auto bfs_entry = [&](int i) -> int {  // q[i], head <= i < tail
+    if (i - qbase >= qvalid) {
+      qbase = i;
+      qvalid = tail - i < 64 ? tail - i : 64;
+      qv = c.lane < qvalid ? c.q[i + c.lane] : 0u;
+    }
+    return __builtin_amdgcn_readlane((int)qv, i - qbase);
+  };
   bool pre_valid = false;
   int pre_cur = 0;
   SokoNode pre_nd;
   SkCrates<BIG> pre_cr;
   pre_cr.c0 = pre_cr.c1 = SK_NOCRATE;
   pre_nd = SokoNode();
+  SK_T_DECL();
   while (iters < max_iter && head < tail) {
+    if (cancel != nullptr && __builtin_amdgcn_readfirstlane(sk_ld(cancel)) < my_stage) break;
     iters++;
+    SK_T_MARK(4);
     int cur;
     const bool had_pre = pre_valid;
     if (b2 < 0) {
-      cur = had_pre ? pre_cur : (int)c.q[head];  // queue.pop(0)
+      cur = had_pre ? pre_cur : bfs_entry(head);  // queue.pop(0)
       head++;
-    } else {                   // heapq.heappop
-      const uint32_t last = c.q[--tail];
-      if (tail > 0) {
-        cur = (int)(c.q[0] & 0xFFFFu);
-        int pos = 0, child = 1;
-        while (child < tail) {
-          const int right = child + 1;
-          const uint32_t lc = c.q[child];
-          uint32_t pick = lc;
-          if (right < tail) {
-            const uint32_t rc = c.q[right];
-            if (!lt(lc, rc)) {
-              child = right;
-              pick = rc;
-            }
-          }
-          if (c.lane == 0) c.q[pos] = pick;
-          pos = child;
-          child = 2 * pos + 1;
-        }
-        siftdown(0, pos, last);
-      } else {
-        cur = (int)(last & 0xFFFFu);
-      }
+    } else {  // heapq.heappop
+      cur = (int)(sk_heappop(c, tail) & 0xFFFFu);
     }
+    SK_T_MARK(0);  // pop
     SokoNode nd;
     SkCrates<BIG> cr;
     if (had_pre) {
@@ -337,7 +454,7 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
     }
     pre_valid = b2 < 0 && head < tail;
     if (pre_valid) {
-      pre_cur = (int)c.q[head];
+      pre_cur = bfs_entry(head);
       pre_nd = c.nodes[pre_cur];
       pre_cr.load(c, pre_cur);
     }
@@ -345,9 +462,13 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
     if (c.lv->ntg == c.ncr && c.ncr > 0 && cr.count_on(c.lv->tgt) == c.ncr) {  // checkWin engine.py:272-280
       res_h = nd.h;
       res_depth = nd.depth;
+      SK_T_FLUSH(b2 < 0 ? 0 : 1, iters);
       return true;
     }
-    if (!sk_visited_test_and_set(c, cur, px, py, cr)) {
+    SK_T_MARK(1);  // record loads + win test
+    const bool seen = sk_visited_test_and_set(c, cur, px, py, cr);
+    SK_T_MARK(2);  // visited set
+    if (!seen) {
       if (best < 0 || nd.h < best_h || (nd.h == best_h && nd.depth < best_depth)) {  // engine.py:66-69
         best = cur;
         best_h = nd.h;
@@ -392,21 +513,36 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
           if (c.lane == 0) c.q[tail] = item;
           tail++;
         } else {
-          tail++;
-          siftdown(0, tail - 1, item);  // heapq.heappush
+          sk_heappush(c, tail, item);
         }
       }
+      SK_T_MARK(3);  // children
     }
   }
+  SK_T_FLUSH(b2 < 0 ? 0 : 1, iters);
   res_h = best_h;
   res_depth = best_depth;
   if (exhausted) *exhausted = head >= tail;  // the open list ran dry: every reachable state was expanded
   return false;
 }
 
-// The reference's cascade (sokoban_prob.py:99-148) from the level's root state (crates in c.lv->root).
+// bind the context to stage workspace `stage` of `slot`
+__device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int stage) {
+  uint8_t *b = pool.base + ((size_t)slot * SK_STAGES + stage) * pool.stage_bytes;
+  c.stage = stage;
+  c.max_nodes = pool.max_nodes;
+  c.nodes = (SokoNode *)b;
+  b += sizeof(SokoNode) * (size_t)c.max_nodes;
+  c.crates = (uint16_t *)b;
+  b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
+  c.vis = (uint32_t *)b;
+  b += sizeof(uint32_t) * SK_VCAP;
+  c.q = (uint32_t *)b;
+}
+
+// node 0 of the bound workspace = the level's root state (crates in c.lv->root)
 template <bool BIG>
-__device__ inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
+__device__ inline void sk_root(SokoCtx &c, int px, int py) {
   SkCrates<BIG> root;
   root.c0 = c.lane < c.ncr ? c.lv->root[c.lane] : SK_NOCRATE;
   root.c1 = (BIG && c.lane + 64 < c.ncr) ? c.lv->root[c.lane + 64] : SK_NOCRATE;
@@ -421,6 +557,13 @@ __device__ inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, in
     n0.py = (uint8_t)py;
     c.nodes[0] = n0;
   }
+}
+
+// The reference's cascade (sokoban_prob.py:99-148), all four stages on the calling wave (stage workspace 0).
+template <bool BIG>
+__device__ inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
+  sk_bind(c, pool, slot, 0);
+  sk_root<BIG>(c, px, py);
   // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
   // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
   // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
@@ -433,6 +576,110 @@ __device__ inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, in
   return won;
 }
 
+// The same with helper waves: this wave runs the BFS stage, helper k (1..3) the A* stage with balance (3 - k) / 2.
+template <bool BIG>
+__device__ inline bool sk_cascade_helped(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
+  SokoMail &m = sk_shared().mail;
+  int seq = 0;
+  if (c.lane == 0) {
+    seq = sk_ld(&m.seq) + 1;
+    m.slot = slot;
+    m.px = px;
+    m.py = py;
+    m.power = power;
+    sk_st(&m.cancel_after, SK_STAGES);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the level in LDS, the dead-cell table, the fields above)
+    sk_st(&m.seq, seq);
+  }
+  seq = __builtin_amdgcn_readfirstlane(seq);
+  sk_bind(c, pool, slot, 0);
+  sk_root<BIG>(c, px, py);
+  bool exhausted = false;
+  bool won = sk_stage<BIG>(c, pool, slot, -1, power, h, depth, &exhausted);
+  if (won || exhausted) {
+    if (c.lane == 0) sk_st(&m.cancel_after, 0);
+  } else {
+    for (int k = 1; k < SK_STAGES && !won; k++) {
+      while (__builtin_amdgcn_readfirstlane(sk_ld(&m.done[k])) != seq) __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      won = __builtin_amdgcn_readfirstlane(sk_ld(&m.won[k])) != 0;
+      h = __builtin_amdgcn_readfirstlane(sk_ld(&m.h[k]));
+      depth = __builtin_amdgcn_readfirstlane(sk_ld(&m.depth[k]));
+      if (won && c.lane == 0) atomicMin(&m.cancel_after, k);
+    }
+  }
+  // the helpers are done with the slot (cancelled stages stop within one iteration)
+  for (int k = 1; k < SK_STAGES; k++)
+    while (__builtin_amdgcn_readfirstlane(sk_ld(&m.done[k])) != seq) __builtin_amdgcn_s_sleep(2);
+  return won;
+}
+
+// Body of helper wave k (1..3) of a workgroup launched with Params::sk_helpers: serve the simulate wave's jobs until it
+// leaves.  The caller has passed the workgroup barrier that follows sokoban_helpers_init.
+__device__ inline void sokoban_helper(const Params &p, int k) {
+  const SokoPool &pool = *(const SokoPool *)p.soko;
+  SokoShared &sh = sk_shared();
+  SokoMail &m = sh.mail;
+  SokoCtx c;
+  c.lv = &sh.level;
+  c.lane = (int)(threadIdx.x & 63);
+  c.pool_full = false;
+#ifdef PCGRL_SK_TIMING
+  c.dbg = (unsigned long long *)(p.err + 64);
+#else
+  c.dbg = nullptr;
+#endif
+  int seen = 0;
+  while (true) {
+    int s;
+    while ((s = __builtin_amdgcn_readfirstlane(sk_ld(&m.seq))) == seen) {
+      if (__builtin_amdgcn_readfirstlane(sk_ld(&m.exit)) != 0) return;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    seen = s;
+    const int slot = m.slot, px = m.px, py = m.py, power = m.power;
+    c.ncr = sh.level.ncr;
+    sk_bind(c, pool, slot, k);
+    int h = 0, depth = 0;
+    bool won = false;
+    if (__builtin_amdgcn_readfirstlane(sk_ld(&m.cancel_after)) >= k) {
+      const int b2 = 3 - k;  // balance 1, 0.5, 0
+      if (c.ncr > 64) {
+        sk_root<true>(c, px, py);
+        won = sk_stage<true>(c, pool, slot, b2, power, h, depth, nullptr, &m.cancel_after, k);
+      } else {
+        sk_root<false>(c, px, py);
+        won = sk_stage<false>(c, pool, slot, b2, power, h, depth, nullptr, &m.cancel_after, k);
+      }
+    }
+    if (c.lane == 0) {
+      if (won) atomicMin(&m.cancel_after, k);
+      m.won[k] = won ? 1 : 0;
+      m.h[k] = h;
+      m.depth[k] = depth;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      sk_st(&m.done[k], s);
+    }
+    if (c.pool_full && c.lane == 0) atomicOr(p.err, 2);
+    c.pool_full = false;
+  }
+}
+// first helper wave, before the workgroup barrier: an empty mailbox
+__device__ inline void sokoban_helpers_init() {
+  SokoMail &m = sk_shared().mail;
+  if ((threadIdx.x & 63) == 0) {
+    m.seq = 0;
+    m.exit = 0;
+    m.cancel_after = SK_STAGES;
+    for (int k = 0; k < SK_STAGES; k++) m.done[k] = 0;
+  }
+}
+// simulate wave, when it leaves the kernel
+__device__ inline void sokoban_helpers_release() {
+  if ((threadIdx.x & 63) == 0) sk_st(&sk_shared().mail.exit, 1);
+}
+
 // Called by every lane of the wave in uniform control flow; `need` is uniform per group.  Groups that need the
 // solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
 // and never waits for a slot while holding one.
@@ -443,7 +690,7 @@ __device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env
   const SokoPool &pool = *(const SokoPool *)p.soko;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
   constexpr int EPW = 64 / LPE;
-  __shared__ SokoLevel s_level;
+  SokoLevel &s_level = sk_shared().level;
   for (int gi = 0; gi < EPW; gi++) {
     const bool mine = need && (g.lane / LPE) == gi;
     if (__ballot(mine) == 0) continue;
@@ -451,6 +698,11 @@ __device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env
     c.lv = &s_level;
     c.lane = g.lane;
     c.pool_full = false;
+#ifdef PCGRL_SK_TIMING
+    c.dbg = (unsigned long long *)(p.err + 64);
+#else
+    c.dbg = nullptr;
+#endif
     // take a workspace slot (lane 0; the slot index is broadcast)
     int slot = 0;
     if (g.lane == 0) {
@@ -465,17 +717,6 @@ __device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // tell the host that searches are running: it then launches the step kernel with one env per wavefront
     if (g.lane == 0 && p.solver_seen != nullptr) __hip_atomic_fetch_add(p.solver_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    {
-      uint8_t *b = pool.base + (size_t)slot * pool.slot_bytes;
-      c.max_nodes = pool.max_nodes;
-      c.nodes = (SokoNode *)b;
-      b += sizeof(SokoNode) * (size_t)c.max_nodes;
-      c.crates = (uint16_t *)b;
-      b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
-      c.vis = (uint32_t *)b;
-      b += sizeof(uint32_t) * SK_VCAP;
-      c.q = (uint32_t *)b;
-    }
     // the level: the group's rows are broadcast to the wave; level coords = map coords + 1 (sokoban_prob.py:107-124:
     // one-tile solid border around the map); crates / targets are listed in row-major order (engine.py:170-188)
     const uint64_t full = (1ull << (W + 2)) - 1ull;
@@ -525,8 +766,13 @@ __device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env
       sk_init_deadlocks(c);
       bool won;
       int h = 0, depth = 0;
-      if (ncr > 64) won = sk_cascade<true>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
-      else won = sk_cascade<false>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+      if (p.sk_helpers != 0) {
+        if (ncr > 64) won = sk_cascade_helped<true>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+        else won = sk_cascade_helped<false>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+      } else {
+        if (ncr > 64) won = sk_cascade<true>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+        else won = sk_cascade<false>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+      }
       if (won) {
         dw = 0;
         sl = depth;
@@ -548,28 +794,30 @@ __device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env
 // ---------------------------------------------------------------------------------------------- host side
 static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int envs_per_wave) {
   SokoPool pool;
-  // one workspace slot per env of the batch (in spread mode every env's search runs on its own wavefront), between 64 (so
-  // that pcgrl_stats_for_grids_h can serve many maps from a small engine) and 2048 (~11 MB each at the default
-  // solver_power, 23 GB in all: the 288 GB of HBM are there to be used)
+  // A slot = SK_STAGES stage workspaces (~11 MB each at the default solver_power).  One slot per four envs of the batch,
+  // between 64 (so that pcgrl_stats_for_grids_h can serve many maps from a small engine) and 512 (23 GB in all: the
+  // 288 GB of HBM are there to be used); searches beyond that wait for a slot.
   (void)envs_per_wave;
-  pool.n_slots = p.n_envs < 64 ? 64 : (p.n_envs > 2048 ? 2048 : p.n_envs);
+  const int want = (p.n_envs + 3) / 4;
+  pool.n_slots = want < 64 ? 64 : (want > 512 ? 512 : want);
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
   const size_t vis_off = sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
   size_t sz = vis_off + sizeof(uint32_t) * SK_VCAP + sizeof(uint32_t) * (size_t)pool.max_nodes;
-  pool.slot_bytes = (sz + 255) & ~(size_t)255;
+  pool.stage_bytes = (sz + 255) & ~(size_t)255;
+  const size_t n_ws = (size_t)pool.n_slots * SK_STAGES;
   hipError_t e;
   void *base = nullptr, *locks = nullptr, *epochs = nullptr, *dpool = nullptr;
-  if ((e = hipMalloc(&base, pool.slot_bytes * pool.n_slots)) != hipSuccess) return e;
+  if ((e = hipMalloc(&base, pool.stage_bytes * n_ws)) != hipSuccess) return e;
   allocs.push_back(base);
   // only the visited tables need a defined start (entries carry the epoch of the stage that wrote them; 0 = empty)
-  for (int s = 0; s < pool.n_slots; s++)
-    if ((e = hipMemsetAsync((uint8_t *)base + (size_t)s * pool.slot_bytes + vis_off, 0, sizeof(uint32_t) * SK_VCAP, 0)) != hipSuccess) return e;
+  for (size_t s = 0; s < n_ws; s++)
+    if ((e = hipMemsetAsync((uint8_t *)base + s * pool.stage_bytes + vis_off, 0, sizeof(uint32_t) * SK_VCAP, 0)) != hipSuccess) return e;
   if ((e = hipMalloc(&locks, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
   allocs.push_back(locks);
   if ((e = hipMemset(locks, 0, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
-  if ((e = hipMalloc(&epochs, sizeof(uint32_t) * pool.n_slots)) != hipSuccess) return e;
+  if ((e = hipMalloc(&epochs, sizeof(uint32_t) * n_ws)) != hipSuccess) return e;
   allocs.push_back(epochs);
-  if ((e = hipMemset(epochs, 0, sizeof(uint32_t) * pool.n_slots)) != hipSuccess) return e;
+  if ((e = hipMemset(epochs, 0, sizeof(uint32_t) * n_ws)) != hipSuccess) return e;
   pool.base = (uint8_t *)base;
   pool.locks = (int32_t *)locks;
   pool.epochs = (uint32_t *)epochs;
