@@ -60,6 +60,7 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
   const bool fast = fast_cfg && !(p.no_fast && (id == K_STEP || id == K_ROLLOUT) && !p.update_only);
   // sokoban with p.sk_helpers: the solver's helper wavefronts ride behind the simulate / observe waves
   const unsigned helper_threads = PROB == PCGRL_PROB_SOKOBAN ? 64u * (unsigned)p.sk_helpers : 0u;
+  const size_t helper_lds = PROB == PCGRL_PROB_SOKOBAN ? (size_t)p.sk_helpers * SK_HELPER_LDS : 0;  // (their A* heaps)
   hipError_t e = hipSuccess;
   switch (id) {
     case K_STEP:
@@ -76,19 +77,22 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
             break;
           }
 #endif
-          if (ctrl)
-            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128 + helper_threads), lds, s, p);
-          else
-            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128 + helper_threads), lds, s, p);
+          if (ctrl) {
+            if ((e = allow_lds(step_kernel<PROB, LPE, M, true, true>, lds + helper_lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, true>), grid, dim3(128 + helper_threads), lds + helper_lds, s, p);
+          } else {
+            if ((e = allow_lds(step_kernel<PROB, LPE, M, true, false>, lds + helper_lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false>), grid, dim3(128 + helper_threads), lds + helper_lds, s, p);
+          }
           break;
         }
       }
       if (p.trg || p.reward64) {
-        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, true>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, true>), grid, dim3(128 + helper_threads), lds, s, p);
+        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, true>, lds + helper_lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, true>), grid, dim3(128 + helper_threads), lds + helper_lds, s, p);
       } else {
-        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, false>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128 + helper_threads), lds, s, p);
+        if ((e = allow_lds(step_kernel<PROB, LPE, M, false, false>, lds + helper_lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false>), grid, dim3(128 + helper_threads), lds + helper_lds, s, p);
       }
       break;
     case K_ROLLOUT: {
@@ -127,8 +131,9 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
       hipLaunchKernelGGL((last_episode_kernel<PROB, LPE>), dim3((p.n_envs + 63) / 64), block, 0, s, p);
       break;
     case K_STATS_FOR_GRIDS:  // (sokoban: one map per wavefront, see the kernel)
+      if ((e = allow_lds(stats_for_grids_kernel<PROB, LPE, M>, helper_lds)) != hipSuccess) return e;
       hipLaunchKernelGGL((stats_for_grids_kernel<PROB, LPE, M>), PROB == PCGRL_PROB_SOKOBAN ? dim3(p.n_envs) : grid,
-                         dim3(64 + helper_threads), 0, s, p);
+                         dim3(64 + helper_threads), helper_lds, s, p);
       break;
   }
   return hipGetLastError();

@@ -407,7 +407,7 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
   const int32_t seen = *(volatile int32_t *)h->seen_host;
   if (seen != h->seen_last) {
     h->seen_last = seen;
-    h->spread_left = 64;
+    h->spread_left = 16;
   }
   if (h->spread_left > 0) {
     h->spread_left--;

@@ -551,7 +551,8 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
 // helper wavefronts of the solver (pcgrl_sokoban.h): kernels launched with Params::sk_helpers carry three of them per
 // workgroup, behind the simulate / observe waves
-__device__ inline void sokoban_helper(const Params &p, int k);
+__device__ inline void sokoban_helper(const Params &p, int k, uint32_t *lds_heap);
+constexpr int SK_HELPER_LDS = 32 * 1024;  // dynamic LDS per helper wave (the top of its A* heap), behind the kernel's own
 __device__ inline void sokoban_helpers_init();
 __device__ inline void sokoban_helpers_release();
 struct SokoHelpersGuard {  // the simulate wave lets its helpers go when it leaves the kernel, whichever way
@@ -1484,7 +1485,8 @@ void step_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
   Grp<LPE> g;
   g.init();
-  const int wave = (int)(threadIdx.x >> 6), pair = wave >> 1;
+  // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; with it the role branches are scalar)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wave >> 1;
   const bool observer = (wave & 1) != 0;  // wave-uniform
   uint8_t *lds = lds_all + (size_t)pair * p.lds_pair_bytes;
   // sokoban, launched with p.sk_helpers (while its solver is busy): waves 2.. are the solver's helpers
@@ -1493,7 +1495,8 @@ void step_kernel(Params p) {
     if (wave >= 2 * PAIRS) {
       if (wave == 2 * PAIRS) sokoban_helpers_init();
       __syncthreads();
-      sokoban_helper(p, wave - 2 * PAIRS + 1);
+      sokoban_helper(p, wave - 2 * PAIRS + 1,
+                     (uint32_t *)(lds_all + (size_t)PAIRS * p.lds_pair_bytes + (size_t)(wave - 2 * PAIRS) * SK_HELPER_LDS));
       return;
     }
   }
@@ -1720,7 +1723,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   Grp<LPE> g;
   g.init();
-  const bool observer = threadIdx.x >= 64;  // wave-uniform
+  const bool observer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;  // wave-uniform
   if (observer && p.obs == nullptr) return;
   PHASE_DECL();  // (development builds: the shared helpers take the phase counters; nothing is flushed here)
   const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
@@ -2085,11 +2088,12 @@ __global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 256 : 64) void stats_f
   g.init();
   const bool helped = PROB == PCGRL_PROB_SOKOBAN && p.sk_helpers != 0;  // waves 1..3: the solver's helpers
   if constexpr (PROB == PCGRL_PROB_SOKOBAN) {
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave >= 1) {
       if (wave == 1) sokoban_helpers_init();
       __syncthreads();
-      sokoban_helper(p, wave);
+      extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+      sokoban_helper(p, wave, (uint32_t *)(lds_all + (size_t)(wave - 1) * SK_HELPER_LDS));
       return;
     }
     if (helped) __syncthreads();

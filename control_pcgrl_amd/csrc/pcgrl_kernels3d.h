@@ -567,7 +567,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
 
   if constexpr (MODE == M3_STEP) {
     // ------------------------------------------------------------------------------------------ observe wave
-    if (threadIdx.x >= 64) {
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {  // (readfirstlane: a scalar branch)
       if (p.obs == nullptr) return;  // (the simulate wave skips the barrier in that case, too)
       for (int i = c.lane; i < c.nw + 2; i += 64) {
         O.dirt[i] = i < c.nw ? gd[i] : 0u;

@@ -75,12 +75,36 @@ struct SokoLevel {  // LDS, one per workgroup (one solve at a time per simulate 
   uint16_t root[SK_MAXC];     // crates of the level in row-major order: x | y << 8 (engine.py:170-188)
   uint16_t target[SK_MAXC];   // targets, same encoding
 };
-struct alignas(16) SokoNode {
-  int32_t parent;
-  int16_t depth, h;
-  uint8_t px, py, pad[6];
+// The workspace pointers carry their address space (global / LDS): pointers read from memory are generic otherwise and
+// every access becomes a flat_load that counts on both the vector-memory and the LDS counter.
+#define SK_GLOBAL __attribute__((address_space(1)))
+#define SK_LDS __attribute__((address_space(3)))
+typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
+// node record in memory, 16 bytes: parent | depth (low 16) h (high 16) | px (bits 0-7) py (bits 8-15) | unused
+struct SokoNode {
+  int32_t parent, depth, h, px, py;
+  __device__ inline sk_u32x4 pack() const {
+    sk_u32x4 r;
+    r.x = (uint32_t)parent;
+    r.y = ((uint32_t)depth & 0xFFFFu) | ((uint32_t)h << 16);
+    r.z = (uint32_t)px | ((uint32_t)py << 8);
+    r.w = 0;
+    return r;
+  }
+  __device__ static inline SokoNode unpack(sk_u32x4 r) {
+    SokoNode n;
+    n.parent = (int32_t)r.x;
+    n.depth = (int32_t)(r.y & 0xFFFFu);
+    n.h = (int32_t)(r.y >> 16);
+    n.px = (int32_t)(r.z & 255u);
+    n.py = (int32_t)((r.z >> 8) & 255u);
+    return n;
+  }
 };
-static_assert(sizeof(SokoNode) == 16, "node header");
+constexpr size_t SK_NODE_BYTES = 16;
+// wave-uniform values the compiler cannot prove uniform (loop-carried counters, words read back from memory): one
+// v_readfirstlane keeps the search's control flow on the scalar unit instead of exec-masked branches
+__device__ inline int sk_u(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 constexpr int SK_STAGES = 4;  // BFS, A* balance 1, 0.5, 0 (sokoban_prob.py:131-145)
 struct SokoPool {  // lives in Params-reachable global memory
@@ -111,14 +135,16 @@ __device__ inline void sk_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATO
 
 struct SokoCtx {
   SokoLevel *lv;
-  SokoNode *nodes;
-  uint16_t *crates;  // [max_nodes][SK_MAXC]  x | y << 8 per crate
-  uint32_t *vis;     // [SK_VCAP]  (epoch << 17) | (node + 1)
-  uint32_t *q;       // [max_nodes] BFS queue (node) / A* heap (key << 16 | node)
+  sk_u32x4 SK_GLOBAL *nodes;  // [max_nodes] SokoNode::pack()
+  uint16_t SK_GLOBAL *crates;  // [max_nodes][SK_MAXC]  x | y << 8 per crate
+  uint32_t SK_GLOBAL *vis;     // [SK_VCAP]  (epoch << 17) | (node + 1)
+  uint32_t SK_GLOBAL *q;       // [max_nodes] BFS queue (node) / A* heap (key << 16 | node)
   int32_t n_nodes, max_nodes, ncr;
   uint32_t epoch;
   int lane;
   int stage;  // which quarter of the slot this context is bound to
+  uint32_t SK_LDS *hl;  // helper waves: the first `hcap` entries of the A* heap live in LDS instead of c.q (else hcap = 0)
+  int hcap;
   bool pool_full;
   unsigned long long *dbg;  // PCGRL_SK_TIMING builds
 };
@@ -151,12 +177,12 @@ template <bool BIG>
 struct SkCrates {
   uint32_t c0, c1;  // x | y << 8, SK_NOCRATE beyond the list
   __device__ inline void load(const SokoCtx &c, int n) {
-    const uint16_t *src = c.crates + (size_t)n * SK_MAXC;
+    const uint16_t SK_GLOBAL *src = c.crates + (size_t)n * SK_MAXC;
     c0 = c.lane < c.ncr ? src[c.lane] : SK_NOCRATE;
     c1 = (BIG && c.lane + 64 < c.ncr) ? src[c.lane + 64] : SK_NOCRATE;
   }
   __device__ inline void store(const SokoCtx &c, int n) const {
-    uint16_t *dst = c.crates + (size_t)n * SK_MAXC;
+    uint16_t SK_GLOBAL *dst = c.crates + (size_t)n * SK_MAXC;
     if (c.lane < c.ncr) dst[c.lane] = (uint16_t)c0;
     if (BIG && c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
   }
@@ -203,7 +229,7 @@ __device__ inline bool sk_free_cell(const SokoCtx &c, const SkCrates<BIG> &cr, i
 // engine.py:282-296 getHeuristic: crates in list order greedily take the nearest remaining target (first minimum in
 // list order).  Lane t holds targets t and t + 64; per crate: broadcast its cell, one distance per lane, wave arg-min.
 template <bool BIG>
-__device__ inline int sk_heuristic(const SokoCtx &c, const SkCrates<BIG> &cr) {
+__device__ __attribute__((always_inline)) inline int sk_heuristic(const SokoCtx &c, const SkCrates<BIG> &cr) {
   const int nt = c.lv->ntg;
   const uint32_t t0 = c.lane < nt ? c.lv->target[c.lane] : SK_NOCRATE;
   const uint32_t t1 = (BIG && c.lane + 64 < nt) ? c.lv->target[c.lane + 64] : SK_NOCRATE;
@@ -232,7 +258,7 @@ __device__ inline int sk_heuristic(const SokoCtx &c, const SkCrates<BIG> &cr) {
 // between two such corners of one row (column) when all cells between them are free, non-target and walled on at
 // least one side -- i.e. inside a maximal run of such cells (corners are such cells themselves) everything between the
 // first and the last corner is dead.  Lane r owns row r, then column r: shifts and scans in registers.
-__device__ inline void sk_init_deadlocks(SokoCtx &c) {
+__device__ __attribute__((always_inline)) inline void sk_init_deadlocks(SokoCtx &c) {
   SokoLevel *lv = c.lv;
   const int w = lv->w, h = lv->h, r = c.lane;
   const bool inner = r >= 1 && r < h - 1;
@@ -291,16 +317,17 @@ __device__ inline void sk_init_deadlocks(SokoCtx &c) {
 
 // returns true if the state (px, py, cr) was already in the visited set; inserts node n otherwise
 template <bool BIG>
-__device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py, const SkCrates<BIG> &cr) {
+__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py, const SkCrates<BIG> &cr) {
   uint32_t i = cr.hash(c.lane, px, py) & (SK_VCAP - 1);
   while (true) {
-    const uint32_t e = c.vis[i];
+    const uint32_t e = (uint32_t)sk_u((int)c.vis[i]);
     if ((e >> 17) != c.epoch || (e & 0x1FFFFu) == 0) {
       if (c.lane == 0) c.vis[i] = (c.epoch << 17) | (uint32_t)(n + 1);
       return false;
     }
     const int m = (int)(e & 0x1FFFFu) - 1;
-    if (c.nodes[m].px == px && c.nodes[m].py == py) {  // State.getKey engine.py:330-336
+    const uint32_t mxy = (uint32_t)sk_u((int)((const uint32_t SK_GLOBAL *)c.nodes)[(size_t)m * 4 + 2]);
+    if (mxy == ((uint32_t)px | ((uint32_t)py << 8))) {  // State.getKey engine.py:330-336
       SkCrates<BIG> o;
       o.load(c, m);
       if (cr.same(o)) return true;
@@ -316,11 +343,28 @@ __device__ inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py
 // the tree per memory round trip (lane j holds the j-th descendant of the current position in level order) and walks them
 // with scalar lane reads, remembers the path in its lanes and writes the whole path back with one store.
 __device__ inline bool sk_key_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
+// heap entry i: the top of the tree sits in LDS when the wave has some (no memory round trips there)
+constexpr int SK_LDS_HEAP = 8192;  // entries per helper wave (32 KiB): a 10 000-iteration stage rarely grows beyond
+__device__ inline uint32_t sk_hq_load(const SokoCtx &c, int i, bool pred) {
+  uint32_t v = 0;
+  if (pred) {
+    if (i < c.hcap) v = c.hl[i];
+    else v = c.q[i];
+  }
+  return v;
+}
+__device__ inline void sk_hq_store(const SokoCtx &c, int i, uint32_t v, bool pred) {
+  if (pred) {
+    if (i < c.hcap) c.hl[i] = v;
+    else c.q[i] = v;
+  }
+}
 
 // heapq.heappop (heapq.py:129-141 + _siftup :258-277 + _siftdown :205-218); tail > 0 on entry
-__device__ inline uint32_t sk_heappop(SokoCtx &c, int &tail) {
+// *new_top: the entry at the root afterwards (the next pop unless a smaller key is pushed first)
+__device__ __attribute__((always_inline)) inline uint32_t sk_heappop(SokoCtx &c, int &tail, uint32_t *new_top) {
   const int lane = c.lane;
-  tail--;
+  tail = sk_u(tail) - 1;
   int pos = 0, depth = 0;
   uint32_t myval = 0, myprev = 0, last = 0, top = 0;
   int mypos = 0;
@@ -332,7 +376,7 @@ __device__ inline uint32_t sk_heappop(SokoCtx &c, int &tail) {
     if (round == 0 && lane == 62) idx = 0;     // the item to return
     if (round == 0 && lane == 63) idx = tail;  // heap.pop(): the last element, re-inserted from the root
     const bool in = (lane < 62 ? idx < tail : round == 0);
-    const uint32_t v = in ? c.q[idx] : 0u;
+    const uint32_t v = sk_hq_load(c, idx, in);
     if (round == 0) {
       top = (uint32_t)__builtin_amdgcn_readlane((int)v, 62);
       last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
@@ -370,30 +414,32 @@ __device__ inline uint32_t sk_heappop(SokoCtx &c, int &tail) {
   const uint64_t smaller = __ballot(lane < depth && sk_key_lt(last, myval));
   const uint64_t stops = ~smaller & ((1ull << depth) - 1ull);
   const int m = stops ? depth - 1 - (63 - __builtin_clzll(stops)) : depth;  // levels `last` climbs
-  if (lane <= depth) c.q[mypos] = lane < depth - m ? myval : (lane == depth - m ? last : myprev);
+  const uint32_t fin = lane < depth - m ? myval : (lane == depth - m ? last : myprev);
+  sk_hq_store(c, mypos, fin, lane <= depth);
+  *new_top = (uint32_t)__builtin_amdgcn_readlane((int)fin, 0);
   return top;
 }
 
 // heapq.heappush (heapq.py:129-132 + _siftdown): the ancestors of the new leaf are read together (their positions follow
 // from the leaf's alone); those larger than the item move down one level each.
-__device__ inline void sk_heappush(SokoCtx &c, int &tail, uint32_t item) {
-  const int lane = c.lane, pos = tail++;
+__device__ __attribute__((always_inline)) inline void sk_heappush(SokoCtx &c, int &tail, uint32_t item) {
+  const int lane = c.lane, pos = sk_u(tail);
+  tail = pos + 1;
   const int levels = 31 - __builtin_clz((unsigned)(pos + 1));  // ancestors of pos
   const int sh = lane < 30 ? lane : 30;
   const int anc = ((pos + 1) >> (sh + 1)) - 1;                 // lane j: ancestor j + 1 (ancestor 0 = pos itself)
   const bool has = lane < levels;
-  const uint32_t v = has ? c.q[anc] : 0u;
+  const uint32_t v = sk_hq_load(c, anc, has);
   const uint64_t up = __ballot(has && sk_key_lt(item, v));
   const uint64_t stop = ~up;
   const int m = __builtin_ctzll(stop);  // (bit `levels` is always clear in `up`)
   const int mine = ((pos + 1) >> sh) - 1;  // ancestor `lane`
-  if (lane < m) c.q[mine] = v;
-  if (lane == m) c.q[mine] = item;
+  sk_hq_store(c, mine, lane < m ? v : item, lane <= m);
 }
 
 // `cancel` (helper-wave mode): the stage gives up as soon as *cancel < my_stage (its result is not needed).
 template <bool BIG>
-__device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
+__device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
                                 bool *exhausted = nullptr, const int32_t *cancel = nullptr, int my_stage = 0) {
   uint32_t *epoch_word = &pool.epochs[slot * SK_STAGES + c.stage];
   uint32_t ep = 0;
@@ -408,8 +454,12 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
   c.n_nodes = 1;
   const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
   int head = 0, tail = 0, best = -1, best_h = 0, best_depth = 0, iters = 0;
-  const int h_root = c.nodes[0].h;
-  if (c.lane == 0) c.q[0] = b2 < 0 ? 0u : ((uint32_t)(2 * h_root) << 16);
+  const int h_root = sk_u(SokoNode::unpack(c.nodes[0]).h);
+  if (b2 < 0) {
+    if (c.lane == 0) c.q[0] = 0u;
+  } else {
+    sk_hq_store(c, 0, (uint32_t)(2 * h_root) << 16, c.lane == 0);
+  }
   tail = 1;
   // BFS: the queue is read 64 entries at a time (lane l holds q[qbase + l]) and the node after the current one is
   // already in it, so its record is requested one iteration ahead
@@ -428,19 +478,24 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
   SokoNode pre_nd;
   SkCrates<BIG> pre_cr;
   pre_cr.c0 = pre_cr.c1 = SK_NOCRATE;
-  pre_nd = SokoNode();
+  pre_nd.parent = pre_nd.depth = pre_nd.h = pre_nd.px = pre_nd.py = 0;
   SK_T_DECL();
   while (iters < max_iter && head < tail) {
-    if (cancel != nullptr && __builtin_amdgcn_readfirstlane(sk_ld(cancel)) < my_stage) break;
+    if (cancel != nullptr && sk_u(sk_ld(cancel)) < my_stage) break;
     iters++;
+    head = sk_u(head);
+    tail = sk_u(tail);
+    c.n_nodes = sk_u(c.n_nodes);
     SK_T_MARK(4);
     int cur;
-    const bool had_pre = pre_valid;
+    bool had_pre = pre_valid;
+    uint32_t new_top = 0;
     if (b2 < 0) {
       cur = had_pre ? pre_cur : bfs_entry(head);  // queue.pop(0)
       head++;
     } else {  // heapq.heappop
-      cur = (int)(sk_heappop(c, tail) & 0xFFFFu);
+      cur = (int)(sk_heappop(c, tail, &new_top) & 0xFFFFu);
+      had_pre = had_pre && cur == pre_cur;  // (the record requested ahead of time: the root the previous pop left behind)
     }
     SK_T_MARK(0);  // pop
     SokoNode nd;
@@ -449,13 +504,17 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
       nd = pre_nd;
       cr = pre_cr;
     } else {
-      nd = c.nodes[cur];
+      nd = SokoNode::unpack(c.nodes[cur]);
       cr.load(c, cur);
     }
-    pre_valid = b2 < 0 && head < tail;
+    nd.depth = sk_u(nd.depth);
+    nd.h = sk_u(nd.h);
+    nd.px = sk_u(nd.px);
+    nd.py = sk_u(nd.py);
+    pre_valid = head < tail;  // BFS: the next queue entry; A*: the heap's new root
     if (pre_valid) {
-      pre_cur = bfs_entry(head);
-      pre_nd = c.nodes[pre_cur];
+      pre_cur = b2 < 0 ? bfs_entry(head) : (int)(new_top & 0xFFFFu);
+      pre_nd = SokoNode::unpack(c.nodes[pre_cur]);
       pre_cr.load(c, pre_cur);
     }
     const int px = nd.px, py = nd.py;
@@ -502,11 +561,11 @@ __device__ inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int 
         if (c.lane == 0) {
           SokoNode nn;
           nn.parent = cur;
-          nn.depth = (int16_t)(nd.depth + 1);
-          nn.h = (int16_t)h;
-          nn.px = (uint8_t)nx;
-          nn.py = (uint8_t)ny;
-          c.nodes[k] = nn;
+          nn.depth = nd.depth + 1;
+          nn.h = h;
+          nn.px = nx;
+          nn.py = ny;
+          c.nodes[k] = nn.pack();
         }
         const uint32_t item = b2 < 0 ? (uint32_t)k : (((uint32_t)(2 * h + b2 * (nd.depth + 1)) << 16) | (uint32_t)k);
         if (b2 < 0) {
@@ -531,13 +590,13 @@ __device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int s
   uint8_t *b = pool.base + ((size_t)slot * SK_STAGES + stage) * pool.stage_bytes;
   c.stage = stage;
   c.max_nodes = pool.max_nodes;
-  c.nodes = (SokoNode *)b;
-  b += sizeof(SokoNode) * (size_t)c.max_nodes;
-  c.crates = (uint16_t *)b;
+  c.nodes = (sk_u32x4 SK_GLOBAL *)b;
+  b += SK_NODE_BYTES * (size_t)c.max_nodes;
+  c.crates = (uint16_t SK_GLOBAL *)b;
   b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
-  c.vis = (uint32_t *)b;
+  c.vis = (uint32_t SK_GLOBAL *)b;
   b += sizeof(uint32_t) * SK_VCAP;
-  c.q = (uint32_t *)b;
+  c.q = (uint32_t SK_GLOBAL *)b;
 }
 
 // node 0 of the bound workspace = the level's root state (crates in c.lv->root)
@@ -552,33 +611,35 @@ __device__ inline void sk_root(SokoCtx &c, int px, int py) {
     SokoNode n0;
     n0.parent = -1;
     n0.depth = 0;
-    n0.h = (int16_t)h0;
-    n0.px = (uint8_t)px;
-    n0.py = (uint8_t)py;
-    c.nodes[0] = n0;
+    n0.h = h0;
+    n0.px = px;
+    n0.py = py;
+    c.nodes[0] = n0.pack();
   }
 }
 
 // The reference's cascade (sokoban_prob.py:99-148), all four stages on the calling wave (stage workspace 0).
 template <bool BIG>
-__device__ inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
+__device__ __attribute__((always_inline)) inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
   sk_bind(c, pool, slot, 0);
   sk_root<BIG>(c, px, py);
   // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
   // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
   // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
   // three A* stages is therefore exact (pinned by tests/golden/stats_sokoban_solver.npz against the reference).
-  bool exhausted = false;
-  bool won = sk_stage<BIG>(c, pool, slot, -1, power, h, depth, &exhausted);
-  if (!won && !exhausted)
-    won = sk_stage<BIG>(c, pool, slot, 2, power, h, depth) || sk_stage<BIG>(c, pool, slot, 1, power, h, depth) ||
-          sk_stage<BIG>(c, pool, slot, 0, power, h, depth);
+  bool exhausted = false, won = false;
+  for (int st = 0; st < SK_STAGES && !won && !exhausted; st++)  // (one call site: the stage is inlined once)
+  {
+    bool ex = false;
+    won = sk_stage<BIG>(c, pool, slot, st == 0 ? -1 : 3 - st, power, h, depth, &ex);
+    exhausted = st == 0 && ex;  // (only the BFS stage's flag ends the cascade, see above)
+  }
   return won;
 }
 
 // The same with helper waves: this wave runs the BFS stage, helper k (1..3) the A* stage with balance (3 - k) / 2.
 template <bool BIG>
-__device__ inline bool sk_cascade_helped(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
+__device__ __attribute__((always_inline)) inline bool sk_cascade_helped(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
   SokoMail &m = sk_shared().mail;
   int seq = 0;
   if (c.lane == 0) {
@@ -616,7 +677,7 @@ __device__ inline bool sk_cascade_helped(SokoCtx &c, const SokoPool &pool, int s
 
 // Body of helper wave k (1..3) of a workgroup launched with Params::sk_helpers: serve the simulate wave's jobs until it
 // leaves.  The caller has passed the workgroup barrier that follows sokoban_helpers_init.
-__device__ inline void sokoban_helper(const Params &p, int k) {
+__device__ __attribute__((always_inline)) inline void sokoban_helper(const Params &p, int k, uint32_t *lds_heap) {
   const SokoPool &pool = *(const SokoPool *)p.soko;
   SokoShared &sh = sk_shared();
   SokoMail &m = sh.mail;
@@ -624,6 +685,8 @@ __device__ inline void sokoban_helper(const Params &p, int k) {
   c.lv = &sh.level;
   c.lane = (int)(threadIdx.x & 63);
   c.pool_full = false;
+  c.hl = (uint32_t SK_LDS *)lds_heap;  // [SK_LDS_HEAP], or null
+  c.hcap = lds_heap ? SK_LDS_HEAP : 0;
 #ifdef PCGRL_SK_TIMING
   c.dbg = (unsigned long long *)(p.err + 64);
 #else
@@ -684,7 +747,7 @@ __device__ inline void sokoban_helpers_release() {
 // solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
 // and never waits for a slot while holding one.
 template <int LPE>
-__device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid,
+__device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid,
                                                         uint32_t player, uint32_t crate, uint32_t target, int &dist_win, int &sol_len) {
   (void)env;
   const SokoPool &pool = *(const SokoPool *)p.soko;
@@ -698,6 +761,8 @@ __device__ inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env
     c.lv = &s_level;
     c.lane = g.lane;
     c.pool_full = false;
+    c.hl = (uint32_t SK_LDS *)nullptr;
+    c.hcap = 0;
 #ifdef PCGRL_SK_TIMING
     c.dbg = (unsigned long long *)(p.err + 64);
 #else
@@ -801,7 +866,7 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, i
   const int want = (p.n_envs + 3) / 4;
   pool.n_slots = want < 64 ? 64 : (want > 512 ? 512 : want);
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
-  const size_t vis_off = sizeof(SokoNode) * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
+  const size_t vis_off = SK_NODE_BYTES * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
   size_t sz = vis_off + sizeof(uint32_t) * SK_VCAP + sizeof(uint32_t) * (size_t)pool.max_nodes;
   pool.stage_bytes = (sz + 255) & ~(size_t)255;
   const size_t n_ws = (size_t)pool.n_slots * SK_STAGES;

@@ -1,0 +1,6 @@
+for w in binary-narrow zelda-turtle sokoban-wide minecraft_3D_maze-narrow; do
+  timeout 200 python bench.py --workload $w --no-cpu-baseline --rollout-steps 0 2>&1 | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('$w', round(l['ms_per_step']*1e3,2),'us', round(l['roofline']['frac'],3))"
+done
+timeout 200 python bench.py --envs 65536 --no-cpu-baseline --rollout-steps 0 2>&1 | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('65536', round(l['ms_per_step']*1e3,2),'us', round(l['roofline']['frac'],3))"
+timeout 120 python tools/solver_bench.py 2>&1 | tail -2
+timeout 200 python bench.py --workload sokoban-wide-solver --steps 40 --warmup 8 --no-cpu-baseline --rollout-steps 0 2>&1 | tail -1 | cut -c1-250
