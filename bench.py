@@ -324,8 +324,40 @@ def main():
         ep_host.copy_(ep_dev, non_blocking=True)
         torch.cuda.synchronize(dev)
 
+    def measure_fill():
+        """What a write-only kernel reaches at this launch size: a device fill of exactly the launch's algorithmic byte
+        count (graph of 20 fills, HIP events).  At 13.7 MB (4096 binary envs) a fill ends after ~4.2 us = 0.40 of the
+        8 TB/s spec peak -- launch ramp and drain of one short kernel -- and ~0.86 of it from 200 MB up.  Reported next to
+        the roofline as context for `frac`; measured before the timed region; never `value`."""
+        nbytes = ALGO_BYTES[args.workload] * N
+        if rank != 0 or nbytes > (8 << 30):
+            return None
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(stream)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(20):
+                    buf.fill_(1)
+        stream.wait_stream(side)
+        reps = max(3, min(50, int(2e-3 / (20 * max(nbytes / 6.5e12, 4e-6)))))
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                g.replay()
+            e1.record(stream)
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) / (reps * 20) * 1e3
+        del g, buf
+        return {"bytes": nbytes, "us": us, "GBps": nbytes / us / 1e3, "frac_of_peak": nbytes / us / 1e3 / HBM_PEAK_GBS}
+
     reduce_episodes()  # warm the reporting path (first all-reduce), clean accumulators
     local_eps = torch.zeros(1, dtype=torch.float64, device=dev)
+    fill = measure_fill() if not args.dry_run else None
     rollout = measure_rollout()
     run(W)
     reduce_episodes()  # episodes that ended during the warm-up do not count
@@ -378,7 +410,9 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "clock": "wall clock of the timed region / steps (the clock of `value`)",
                          "achieved_hip_events": achieved_ev, "frac_hip_events": achieved_ev / HBM_PEAK_GBS,
-                         "avg_launch_us": kernel_ms * 1e3},
+                         "avg_launch_us": kernel_ms * 1e3,
+                         # context, not a peak: a device fill of the same byte count on the same GPU in the same run
+                         "fill_same_bytes": (dict(fill, step_over_fill=(elapsed / K * 1e6) / fill["us"]) if fill else None)},
             "episodes": ep,
         }
         if world > 1:

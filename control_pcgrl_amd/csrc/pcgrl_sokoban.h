@@ -65,7 +65,9 @@ namespace pcgrl {
 
 constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
 constexpr int SK_MAXDIM = 34;    // bordered level side (W+2, H+2 <= 34)
-constexpr int SK_VCAP = 1 << 15; // visited table slots (>= 2 x iterations per stage)
+constexpr int SK_VCAP = 1 << 15; // visited table entries (>= 2 x iterations per stage), 16 bytes each, in groups of 8
+constexpr int SK_VGROUPS = SK_VCAP / 8;  // a group = one 128-byte line: a probe reads it with one load (lane l < 8: entry l)
+constexpr size_t SK_VIS_BYTES = 16 * (size_t)SK_VCAP;
 constexpr int SK_MAX_POWER = 16000;  // cfg.solver_power accepted by pcgrl_create: node ids (<= 4 * power + 8) fit 16 bits
 constexpr uint32_t SK_NOCRATE = 0xFFFFu;
 
@@ -136,10 +138,11 @@ __device__ inline void sk_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATO
 struct SokoCtx {
   SokoLevel *lv;
   sk_u32x4 SK_GLOBAL *nodes;  // [max_nodes] SokoNode::pack()
-  uint16_t SK_GLOBAL *crates;  // [max_nodes][SK_MAXC]  x | y << 8 per crate
-  uint32_t SK_GLOBAL *vis;     // [SK_VCAP]  (epoch << 17) | (node + 1)
+  uint16_t SK_GLOBAL *crates;  // [max_nodes][cstride]  x | y << 8 per crate (the area is sized for SK_MAXC per node)
+  sk_u32x4 SK_GLOBAL *vis;     // [SK_VCAP]  x = (epoch << 17) | (node + 1), yzw = the state's key (SkKey)
   uint32_t SK_GLOBAL *q;       // [max_nodes] BFS queue (node) / A* heap (key << 16 | node)
   int32_t n_nodes, max_nodes, ncr;
+  int32_t cstride;  // crate-list stride of this level in uint16: ncr rounded up to 4 (compact records stay in the L2)
   uint32_t epoch;
   int lane;
   int stage;  // which quarter of the slot this context is bound to
@@ -177,12 +180,12 @@ template <bool BIG>
 struct SkCrates {
   uint32_t c0, c1;  // x | y << 8, SK_NOCRATE beyond the list
   __device__ inline void load(const SokoCtx &c, int n) {
-    const uint16_t SK_GLOBAL *src = c.crates + (size_t)n * SK_MAXC;
+    const uint16_t SK_GLOBAL *src = c.crates + (size_t)n * c.cstride;
     c0 = c.lane < c.ncr ? src[c.lane] : SK_NOCRATE;
     c1 = (BIG && c.lane + 64 < c.ncr) ? src[c.lane + 64] : SK_NOCRATE;
   }
   __device__ inline void store(const SokoCtx &c, int n) const {
-    uint16_t SK_GLOBAL *dst = c.crates + (size_t)n * SK_MAXC;
+    uint16_t SK_GLOBAL *dst = c.crates + (size_t)n * c.cstride;
     if (c.lane < c.ncr) dst[c.lane] = (uint16_t)c0;
     if (BIG && c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
   }
@@ -315,24 +318,86 @@ __device__ __attribute__((always_inline)) inline void sk_init_deadlocks(SokoCtx 
   if (r < h) lv->dead[r] = dead;
 }
 
-// returns true if the state (px, py, cr) was already in the visited set; inserts node n otherwise
+// State.getKey (engine.py:330-336: player position + the ORDERED crate list; targets never change) as 96 bits: exact for
+// levels with up to five crates (every designed level), a 80-bit hash plus the position beyond (then a matching table
+// entry is confirmed against the node's stored crate list).
+struct SkKey {
+  uint32_t k0, k1, k2;
+  bool exact;
+  __device__ inline int group() const {  // which line of the visited table
+    uint32_t h = k0 * 0x9E3779B1u ^ k1 * 0x85EBCA77u ^ k2 * 0xC2B2AE3Du;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    return (int)((h ^ (h >> 13)) & (uint32_t)(SK_VGROUPS - 1));
+  }
+};
 template <bool BIG>
-__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, int px, int py, const SkCrates<BIG> &cr) {
-  uint32_t i = cr.hash(c.lane, px, py) & (SK_VCAP - 1);
+__device__ __attribute__((always_inline)) inline SkKey sk_key(const SokoCtx &c, int px, int py, const SkCrates<BIG> &cr) {
+  SkKey k;
+  const uint32_t xy = (uint32_t)px | ((uint32_t)py << 8);
+  k.exact = c.ncr <= 5;
+  if (k.exact) {  // (lanes beyond the list hold SK_NOCRATE)
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, 0), a1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, 1);
+    const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, 3);
+    const uint32_t a4 = (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, 4);
+    k.k0 = xy | (a0 << 16);
+    k.k1 = (a1 & 0xFFFFu) | (a2 << 16);
+    k.k2 = (a3 & 0xFFFFu) | (a4 << 16);
+  } else {  // two independent position-dependent mixes per crate, xor-combined over the wave
+    uint32_t a = (cr.c0 + 0x9E3779B9u * (uint32_t)(c.lane + 1)) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    uint32_t b = (cr.c0 ^ (0x7F4A7C15u + 0x632BE5ABu * (uint32_t)c.lane)) * 0xC2B2AE35u;
+    b ^= b >> 13;
+    if (BIG) {
+      uint32_t a1 = (cr.c1 + 0x9E3779B9u * (uint32_t)(c.lane + 65)) * 0xC2B2AE35u;
+      a ^= a1 ^ (a1 >> 13);
+      uint32_t b1 = (cr.c1 ^ (0x1B873593u + 0x632BE5ABu * (uint32_t)(c.lane + 64))) * 0x85EBCA6Bu;
+      b ^= b1 ^ (b1 >> 15);
+    }
+    k.k1 = sk_wave_xor(a);
+    k.k2 = sk_wave_xor(b);
+    k.k0 = xy | ((k.k1 * 0x9E3779B1u ^ k.k2) & 0xFFFF0000u);
+  }
+  return k;
+}
+
+// returns true if the state (key; crates cr) was already in the visited set; inserts node n otherwise.  A probe reads one
+// group of 8 entries with one load; a full group overflows into the next.
+template <bool BIG>
+__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, const SkKey &key, const SkCrates<BIG> &cr) {
+  int grp = key.group();
   while (true) {
-    const uint32_t e = (uint32_t)sk_u((int)c.vis[i]);
-    if ((e >> 17) != c.epoch || (e & 0x1FFFFu) == 0) {
-      if (c.lane == 0) c.vis[i] = (c.epoch << 17) | (uint32_t)(n + 1);
+    sk_u32x4 e = {0u, 0u, 0u, 0u};
+    if (c.lane < 8) e = c.vis[grp * 8 + c.lane];
+    const bool valid = c.lane < 8 && (e.x >> 17) == c.epoch && (e.x & 0x1FFFFu) != 0;
+    const uint32_t empties = (uint32_t)__ballot(c.lane < 8 && !valid);
+    const uint32_t matches = (uint32_t)__ballot(valid && e.y == key.k0 && e.z == key.k1 && e.w == key.k2);
+    const int lim = empties ? __builtin_ctz(empties) : 8;  // entries are filled in order: nothing valid lies beyond
+    uint32_t cand = matches & ((1u << lim) - 1u);
+    if (key.exact) {
+      if (cand) return true;
+    } else {
+      while (cand) {
+        const int j = __builtin_ctz(cand);
+        cand &= cand - 1u;
+        const int m = (int)((uint32_t)__builtin_amdgcn_readlane((int)e.x, j) & 0x1FFFFu) - 1;
+        SkCrates<BIG> o;
+        o.load(c, m);
+        if (cr.same(o)) return true;
+      }
+    }
+    if (empties) {
+      if (c.lane == 0) {
+        sk_u32x4 w;
+        w.x = (c.epoch << 17) | (uint32_t)(n + 1);
+        w.y = key.k0;
+        w.z = key.k1;
+        w.w = key.k2;
+        c.vis[grp * 8 + lim] = w;
+      }
       return false;
     }
-    const int m = (int)(e & 0x1FFFFu) - 1;
-    const uint32_t mxy = (uint32_t)sk_u((int)((const uint32_t SK_GLOBAL *)c.nodes)[(size_t)m * 4 + 2]);
-    if (mxy == ((uint32_t)px | ((uint32_t)py << 8))) {  // State.getKey engine.py:330-336
-      SkCrates<BIG> o;
-      o.load(c, m);
-      if (cr.same(o)) return true;
-    }
-    i = (i + 1) & (SK_VCAP - 1);
+    grp = (grp + 1) & (SK_VGROUPS - 1);
   }
 }
 
@@ -345,96 +410,119 @@ __device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(So
 __device__ inline bool sk_key_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
 // heap entry i: the top of the tree sits in LDS when the wave has some (no memory round trips there)
 constexpr int SK_LDS_HEAP = 8192;  // entries per helper wave (32 KiB): a 10 000-iteration stage rarely grows beyond
-__device__ inline uint32_t sk_hq_load(const SokoCtx &c, int i, bool pred) {
+// LDSONLY (the whole heap is in LDS, the common case): no global access is compiled in, so the sift never waits for the
+// vector-memory counter -- i.e. for the previous iteration's record stores and the record requested ahead of time.
+template <bool LDSONLY>
+__device__ __attribute__((always_inline)) inline uint32_t sk_hq_load(const SokoCtx &c, int i, bool pred) {
   uint32_t v = 0;
-  if (pred) {
+  if (LDSONLY) {
+    if (pred) v = c.hl[i];
+  } else if (pred) {
     if (i < c.hcap) v = c.hl[i];
     else v = c.q[i];
   }
   return v;
 }
-__device__ inline void sk_hq_store(const SokoCtx &c, int i, uint32_t v, bool pred) {
-  if (pred) {
+template <bool LDSONLY>
+__device__ __attribute__((always_inline)) inline void sk_hq_store(const SokoCtx &c, int i, uint32_t v, bool pred) {
+  if (LDSONLY) {
+    if (pred) c.hl[i] = v;
+  } else if (pred) {
     if (i < c.hcap) c.hl[i] = v;
     else c.q[i] = v;
   }
 }
-
 // heapq.heappop (heapq.py:129-141 + _siftup :258-277 + _siftdown :205-218); tail > 0 on entry
 // *new_top: the entry at the root afterwards (the next pop unless a smaller key is pushed first)
-__device__ __attribute__((always_inline)) inline uint32_t sk_heappop(SokoCtx &c, int &tail, uint32_t *new_top) {
+template <bool LDSONLY>
+__device__ __attribute__((always_inline)) inline uint32_t sk_heappop_impl(SokoCtx &c, int &tail, uint32_t *new_top) {
   const int lane = c.lane;
   tail = sk_u(tail) - 1;
   int pos = 0, depth = 0;
-  uint32_t myval = 0, myprev = 0, last = 0, top = 0;
-  int mypos = 0;
+  int myval = 0, mypos = 0;  // lane d: the value that moves into path position d, and that position
+  uint32_t last = 0, top = 0;
   bool leaf = false;
-  // local index t = lane + 1 of the subtree rooted at `pos` (t = 0): level l = floor(log2(t + 1)), offset t + 1 - 2^l
-  const int t1 = lane + 2, lvl = 31 - __builtin_clz((unsigned)t1), off = t1 - (1 << lvl);
+  // lane j holds node j (level order, j = 0: `pos` itself) of the 6-level subtree below `pos`; lane 63 is spare
+  const int j1 = lane + 1, lvl = 31 - __builtin_clz((unsigned)j1), off = j1 - (1 << lvl);
+  const int kids = lane < 31 ? 2 * lane + 1 : 0;  // lanes of my children
   for (int round = 0; !leaf; round++) {
     int idx = ((pos + 1) << lvl) - 1 + off;
-    if (round == 0 && lane == 62) idx = 0;     // the item to return
-    if (round == 0 && lane == 63) idx = tail;  // heap.pop(): the last element, re-inserted from the root
-    const bool in = (lane < 62 ? idx < tail : round == 0);
-    const uint32_t v = sk_hq_load(c, idx, in);
+    if (lane == 63) idx = tail;  // round 0: heap.pop(), the last element, re-inserted from the root
+    const bool in = lane < 63 ? idx < tail : round == 0;
+    const uint32_t v = sk_hq_load<LDSONLY>(c, idx, in);
     if (round == 0) {
-      top = (uint32_t)__builtin_amdgcn_readlane((int)v, 62);
+      top = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);  // the item to return
       last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
       if (tail == 0) return last;  // it was the only element
     }
-    int loc = 0;  // local index of `pos`
-    for (int step = 0; step < 5; step++) {
-      int child = 2 * pos + 1, cloc = 2 * loc + 1;
-      if (child >= tail) {
+    // every inner node picks the child _siftup would move up: the right one unless left < right
+    const uint32_t vl = (uint32_t)__builtin_amdgcn_ds_bpermute(kids << 2, (int)v);
+    const uint32_t vr = (uint32_t)__builtin_amdgcn_ds_bpermute((kids + 1) << 2, (int)v);
+    const int il = 2 * idx + 1;
+    const bool hasl = lane < 31 && il < tail, right = lane < 31 && il + 1 < tail && !sk_key_lt(vl, vr);
+    const int sel = hasl ? kids + (right ? 1 : 0) : -1;  // lane of that child, -1: no children
+    const int pickv = (int)(right ? vr : vl);
+    // the walk itself only follows `sel` (one scalar lane read per level); the lanes of the nodes it passed are packed
+    // into a scalar, 6 bits per level, and every lane of the path fetches its own value / position afterwards
+    int loc = 0, steps = 0;
+    uint32_t locs = 0;
+    for (int step = 0; step < 5; step++) {  // (the children of level 5 are not in this fetch)
+      const int sl = __builtin_amdgcn_readlane(sel, loc);
+      if (sl < 0) {
         leaf = true;
         break;
       }
-      uint32_t pick = (uint32_t)__builtin_amdgcn_readlane((int)v, cloc - 1);
-      if (child + 1 < tail) {
-        const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)v, cloc);
-        if (!sk_key_lt(pick, rc)) {
-          child++;
-          cloc++;
-          pick = rc;
-        }
-      }
-      // heap[pos] = heap[childpos]
-      if (lane == depth) {
-        myval = pick;
-        mypos = pos;
-      }
-      if (lane == depth + 1) myprev = pick;
-      pos = child;
-      loc = cloc;
-      depth++;
+      loc = sl;
+      steps++;
+      locs |= (uint32_t)sl << (6 * steps);
     }
+    // heap[pos] = heap[childpos] for the `steps` levels walked: path position depth + t is node ((locs >> 6t) & 63)
+    const int t = lane - depth;
+    const bool on = t >= 0 && t < steps;
+    const int ml = on ? (int)((locs >> (6 * (t < 0 ? 0 : (t > 4 ? 4 : t)))) & 63u) : 0;
+    const int pv = __builtin_amdgcn_ds_bpermute(ml << 2, pickv), pi = __builtin_amdgcn_ds_bpermute(ml << 2, idx);
+    myval = on ? pv : myval;
+    mypos = on ? pi : mypos;
+    pos = __builtin_amdgcn_readlane(idx, loc);
+    depth += steps;
   }
   // heap[pos] = newitem; _siftdown(heap, 0, pos): `last` climbs while it is smaller than the parent (= the picks above it)
-  if (lane == depth) mypos = pos;
-  const uint64_t smaller = __ballot(lane < depth && sk_key_lt(last, myval));
+  mypos = lane == depth ? pos : mypos;
+  const int myprev = __builtin_amdgcn_ds_bpermute((lane > 0 ? lane - 1 : 0) << 2, myval);  // the pick one level up
+  const uint64_t smaller = __ballot(lane < depth && sk_key_lt(last, (uint32_t)myval));
   const uint64_t stops = ~smaller & ((1ull << depth) - 1ull);
   const int m = stops ? depth - 1 - (63 - __builtin_clzll(stops)) : depth;  // levels `last` climbs
-  const uint32_t fin = lane < depth - m ? myval : (lane == depth - m ? last : myprev);
-  sk_hq_store(c, mypos, fin, lane <= depth);
+  const uint32_t fin = lane < depth - m ? (uint32_t)myval : (lane == depth - m ? last : (uint32_t)myprev);
+  sk_hq_store<LDSONLY>(c, mypos, fin, lane <= depth);
   *new_top = (uint32_t)__builtin_amdgcn_readlane((int)fin, 0);
   return top;
 }
 
 // heapq.heappush (heapq.py:129-132 + _siftdown): the ancestors of the new leaf are read together (their positions follow
 // from the leaf's alone); those larger than the item move down one level each.
-__device__ __attribute__((always_inline)) inline void sk_heappush(SokoCtx &c, int &tail, uint32_t item) {
+template <bool LDSONLY>
+__device__ __attribute__((always_inline)) inline void sk_heappush_impl(SokoCtx &c, int &tail, uint32_t item) {
   const int lane = c.lane, pos = sk_u(tail);
   tail = pos + 1;
   const int levels = 31 - __builtin_clz((unsigned)(pos + 1));  // ancestors of pos
   const int sh = lane < 30 ? lane : 30;
   const int anc = ((pos + 1) >> (sh + 1)) - 1;                 // lane j: ancestor j + 1 (ancestor 0 = pos itself)
   const bool has = lane < levels;
-  const uint32_t v = sk_hq_load(c, anc, has);
+  const uint32_t v = sk_hq_load<LDSONLY>(c, anc, has);
   const uint64_t up = __ballot(has && sk_key_lt(item, v));
   const uint64_t stop = ~up;
   const int m = __builtin_ctzll(stop);  // (bit `levels` is always clear in `up`)
   const int mine = ((pos + 1) >> sh) - 1;  // ancestor `lane`
-  sk_hq_store(c, mine, lane < m ? v : item, lane <= m);
+  sk_hq_store<LDSONLY>(c, mine, lane < m ? v : item, lane <= m);
+}
+
+__device__ __attribute__((always_inline)) inline uint32_t sk_heappop(SokoCtx &c, int &tail, uint32_t *new_top) {
+  if (sk_u(tail) <= c.hcap) return sk_heappop_impl<true>(c, tail, new_top);
+  return sk_heappop_impl<false>(c, tail, new_top);
+}
+__device__ __attribute__((always_inline)) inline void sk_heappush(SokoCtx &c, int &tail, uint32_t item) {
+  if (sk_u(tail) < c.hcap) sk_heappush_impl<true>(c, tail, item);
+  else sk_heappush_impl<false>(c, tail, item);
 }
 
 // `cancel` (helper-wave mode): the stage gives up as soon as *cancel < my_stage (its result is not needed).
@@ -446,7 +534,7 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
   if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
   ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
   if (ep == 0) {  // wrapped: start over with a clean table
-    for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = 0;
+    for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = sk_u32x4{0u, 0u, 0u, 0u};
     if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
     ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
   }
@@ -458,7 +546,7 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
   if (b2 < 0) {
     if (c.lane == 0) c.q[0] = 0u;
   } else {
-    sk_hq_store(c, 0, (uint32_t)(2 * h_root) << 16, c.lane == 0);
+    sk_hq_store<false>(c, 0, (uint32_t)(2 * h_root) << 16, c.lane == 0);
   }
   tail = 1;
   // BFS: the queue is read 64 entries at a time (lane l holds q[qbase + l]) and the node after the current one is
@@ -525,7 +613,8 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
       return true;
     }
     SK_T_MARK(1);  // record loads + win test
-    const bool seen = sk_visited_test_and_set(c, cur, px, py, cr);
+    const SkKey key = sk_key(c, px, py, cr);
+    const bool seen = sk_visited_test_and_set(c, cur, key, cr);
     SK_T_MARK(2);  // visited set
     if (!seen) {
       if (best < 0 || nd.h < best_h || (nd.h == best_h && nd.depth < best_depth)) {  // engine.py:66-69
@@ -594,8 +683,8 @@ __device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int s
   b += SK_NODE_BYTES * (size_t)c.max_nodes;
   c.crates = (uint16_t SK_GLOBAL *)b;
   b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
-  c.vis = (uint32_t SK_GLOBAL *)b;
-  b += sizeof(uint32_t) * SK_VCAP;
+  c.vis = (sk_u32x4 SK_GLOBAL *)b;
+  b += SK_VIS_BYTES;
   c.q = (uint32_t SK_GLOBAL *)b;
 }
 
@@ -702,7 +791,8 @@ __device__ __attribute__((always_inline)) inline void sokoban_helper(const Param
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     seen = s;
     const int slot = m.slot, px = m.px, py = m.py, power = m.power;
-    c.ncr = sh.level.ncr;
+    c.ncr = sk_u(sh.level.ncr);
+    c.cstride = (c.ncr + 3) & ~3;
     sk_bind(c, pool, slot, k);
     int h = 0, depth = 0;
     bool won = false;
@@ -824,6 +914,7 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
       if (g.lane == 0) atomicOr(p.err, 2);  // beyond the device solver's limits: reported by pcgrl_poll_error
     } else {
       c.ncr = ncr;
+      c.cstride = (ncr + 3) & ~3;
       if (g.lane == 0) {
         s_level.ncr = ncr;
         s_level.ntg = ntg;
@@ -867,7 +958,7 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, i
   pool.n_slots = want < 64 ? 64 : (want > 512 ? 512 : want);
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
   const size_t vis_off = SK_NODE_BYTES * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
-  size_t sz = vis_off + sizeof(uint32_t) * SK_VCAP + sizeof(uint32_t) * (size_t)pool.max_nodes;
+  size_t sz = vis_off + SK_VIS_BYTES + sizeof(uint32_t) * (size_t)pool.max_nodes;
   pool.stage_bytes = (sz + 255) & ~(size_t)255;
   const size_t n_ws = (size_t)pool.n_slots * SK_STAGES;
   hipError_t e;
@@ -876,7 +967,7 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, i
   allocs.push_back(base);
   // only the visited tables need a defined start (entries carry the epoch of the stage that wrote them; 0 = empty)
   for (size_t s = 0; s < n_ws; s++)
-    if ((e = hipMemsetAsync((uint8_t *)base + s * pool.stage_bytes + vis_off, 0, sizeof(uint32_t) * SK_VCAP, 0)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync((uint8_t *)base + s * pool.stage_bytes + vis_off, 0, SK_VIS_BYTES, 0)) != hipSuccess) return e;
   if ((e = hipMalloc(&locks, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
   allocs.push_back(locks);
   if ((e = hipMemset(locks, 0, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;

@@ -20,7 +20,11 @@ if "--build" in sys.argv:
 import numpy as np
 import torch
 
-_lib.LIB_PATH = TIMING_LIB
+PLAIN = "--plain" in sys.argv  # the shipped library (no counters): for rocprofv3 --pmc runs of the same launch
+if PLAIN:
+    sys.argv.remove("--plain")
+else:
+    _lib.LIB_PATH = TIMING_LIB
 from control_pcgrl_amd import VecPcgrlEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -44,6 +48,9 @@ t0 = time.perf_counter()
 st = env.stats_for_grids(gd)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if PLAIN:
+    print(f"{n} levels in one launch: {dt * 1e3:.1f} ms")
+    sys.exit(0)
 env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 16)
 print(f"{n} levels in one launch: {dt * 1e3:.1f} ms; solved: {(st[:, -1] > 0).sum().item() if st.shape[1] else '?'}")
 names = ["pop", "record loads + win test", "visited set", "children", "loop overhead"]
