@@ -58,7 +58,7 @@ headline = f"""| quantity | value | source |
 | roofline | {b['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic / {fmt(b['ms_per_step'] * 1e3)} µs = {b['roofline']['achieved'] / 1e3:.2f} TB/s = **{fmt(b['roofline']['frac'], 3)} of 8 TB/s** (from the profiled kernel mean: {fmt(b['roofline']['algorithmic_bytes_per_launch'] / (dk['mean'] * 1e-9) / 8e12, 3)}) | `bench.py` |
 | HBM traffic | WRITE_SIZE {tr['write_bytes'] / 1e6:.1f} MB + 2×FETCH_SIZE {tr['fetch_bytes_x2_correction'] / 1e6:.1f} MB = {tr['traffic_bytes'] / 1e6:.1f} MB / launch = {fmt(tr['traffic_over_algorithmic'])} × algorithmic | `profiles/{tag}_summary.json` |
 | waves / LDS | {ws['occupancy']['waves_per_launch']:.0f} waves per launch ({ws['occupancy']['waves_per_cu']:.0f} per CU); {sq['SQ_INSTS_VALU']['mean_per_launch'] / 1e6:.2f} M VALU, {sq['SQ_INSTS_SALU']['mean_per_launch'] / 1e6:.2f} M SALU, {sq['SQ_INSTS_LDS']['mean_per_launch'] / 1e3:.0f} k LDS instructions; LDS bank-conflict cycles / LDS active cycles = {fmt(ws['lds']['bank_conflict_rate'])} (the byte-granular one-hot scatter into the observation rows) | `profiles/{tag}_summary.json` |
-""" + (f"| same kernel, 65 536 envs | {fmt(big['ms_per_step'] * 1e3, 1)} µs ⇒ **{sci(big['value'])} steps/s, {fmt(big['roofline']['frac'], 2)} of 8 TB/s** | `bench.py --envs 65536` |\n" if big else "") + f"""| open-loop rollout (64 steps per launch, every observation written) | {fmt(b['open_loop_rollout']['us_per_step'])} µs per step, {sci(b['open_loop_rollout']['value'])} steps/s, {fmt(b['open_loop_rollout']['roofline_frac'], 2)} of the roofline | `bench.py` `open_loop_rollout` |
+""" + (f"| device fill of the same {b['roofline']['fill_same_bytes']['bytes'] / 1e6:.1f} MB, same run (context: what a write-only kernel of this size reaches) | {fmt(b['roofline']['fill_same_bytes']['us'])} µs = {fmt(b['roofline']['fill_same_bytes']['frac_of_peak'], 2)} of 8 TB/s; the step launch takes {fmt(b['roofline']['fill_same_bytes']['step_over_fill'])} × that | `bench.py` `roofline.fill_same_bytes` |\n" if b['roofline'].get('fill_same_bytes') else "") + (f"| same kernel, 65 536 envs | {fmt(big['ms_per_step'] * 1e3, 1)} µs ⇒ **{sci(big['value'])} steps/s, {fmt(big['roofline']['frac'], 2)} of 8 TB/s**" + (f" (a fill of the same {big['roofline']['fill_same_bytes']['bytes'] / 1e6:.0f} MB: {fmt(big['roofline']['fill_same_bytes']['us'], 1)} µs = {fmt(big['roofline']['fill_same_bytes']['frac_of_peak'], 2)})" if big['roofline'].get('fill_same_bytes') else "") + f" | `bench.py --envs 65536` |\n" if big else "") + f"""| open-loop rollout (64 steps per launch, every observation written) | {fmt(b['open_loop_rollout']['us_per_step'])} µs per step, {sci(b['open_loop_rollout']['value'])} steps/s, {fmt(b['open_loop_rollout']['roofline_frac'], 2)} of the roofline | `bench.py` `open_loop_rollout` |
 | CPU oracle (C port, OpenMP, {b['cpu_baseline']['cores']} threads of {b['cpu_baseline']['usable_cores']} usable cores, {b['cpu_baseline']['cpu_model']}) | {sci(b['cpu_baseline']['value'])} steps/s ({sci(b['cpu_baseline']['one_core'])} on one core) | `bench.py` `cpu_baseline` |
 | reference Python env (survey probe, 1 core) | ≈ 750 steps/s | BASELINE.md |"""
 
@@ -76,7 +76,7 @@ NOTES = {
     "binary-narrow-patch3x3": "3×3 action patch, general kernel",
     "sokoban-wide-solver": "solver-active, see below",
 }
-rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|"]
+rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac | same-size fill µs | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|---|"]
 for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
     if w not in lines:
         continue
@@ -86,6 +86,7 @@ for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-na
     ro = l.get("open_loop_rollout")
     cb = l.get("cpu_baseline")
     rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {ks} | {l['roofline']['frac']:.3f} | "
+                + (f"{l['roofline']['fill_same_bytes']['us']:.2f}" if l['roofline'].get('fill_same_bytes') else "–") + " | "
                 + (f"{ro['us_per_step']:.2f}" if ro else "–") + " | " + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + f" | {NOTES.get(w, '')} |")
 extra = []
 for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow"):
