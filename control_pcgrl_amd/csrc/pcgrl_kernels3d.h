@@ -221,8 +221,8 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     // everything that depends only on the entry comes back in one LDS round trip: `best` and first slot of its cell, its
     // column and the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map)
     const int nx = x + dxl, ny = y + dyl, jx = nx + dxl, jy = ny + dyl;
-    const bool n_in = (unsigned)nx < (unsigned)c.X && (unsigned)ny < (unsigned)c.Y;
-    const bool j_in = (unsigned)jx < (unsigned)c.X && (unsigned)jy < (unsigned)c.Y;
+    const bool n_in = ((unsigned)nx < (unsigned)c.X) & ((unsigned)ny < (unsigned)c.Y);
+    const bool j_in = ((unsigned)jx < (unsigned)c.X) & ((unsigned)jy < (unsigned)c.Y);
     const int qc = ci - z * YX, qn = n_in ? qc + dq : 0, qj = j_in ? qc + 2 * dq : 0;
     const uint32_t b = L.best[ci];
     const uint32_t first_slot = L.claim[ci];
@@ -230,17 +230,18 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const bool seen = (b >> 24) == epoch;
     M3_TT(3);  // entry read + second round of reads issued (wait happens at first use)
     // :437-440 (an entry that is not shorter is dropped) and :443-445 (no head-room); cells >= Z read as not-AIR
-    const bool accept = live && !(seen && (int)((b >> 12) & 0xFFFu) <= len) && ((cc >> (z + 1)) & 1u);
+    // (bitwise on purpose, here and below: `&&` / `||` compile to exec-masked branches, these to mask arithmetic)
+    const bool accept = live & !(seen & ((int)((b >> 12) & 0xFFFu) <= len)) & (((cc >> (z + 1)) & 1u) != 0u);
     // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
-    const uint64_t dupb = __ballot(accept && d == 0 && first_slot != (uint32_t)slot_i);
+    const uint64_t dupb = __ballot(accept & (d == 0) & (first_slot != (uint32_t)slot_i));
     const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
     if (live && d == 0) L.claim[ci] = NONE;
-    const bool doit = accept && slot_i < nproc;
-    const bool first = doit && d == 0 && !seen;
+    const bool doit = accept & (slot_i < nproc);
+    const bool first = doit & (d == 0) & !seen;
     const uint64_t fb = __ballot(first);
     if (first) L.order[n_order + __popcll(fb & lt)] = (uint16_t)ci;
     n_order += __popcll(fb);
-    const bool acc0 = doit && d == 0;
+    const bool acc0 = doit & (d == 0);
     if (acc0) L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
     mkl |= acc0 ? ((x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z)) : 0u;
     M3_TT(4);  // accept / claim / order / best
@@ -249,17 +250,17 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     // explicit bounds check amounts to).  The six rules are mutually exclusive.
     const uint32_t wn = ((cn << 2) >> z) & 0x3Fu, wj = ((cj << 2) >> z) & 0x3Fu, c4 = (cc >> (z + 2)) & 1u;
     const bool walk = (wn & 0x0Eu) == 0x0Cu;                      // stands at z: !n[z-1], n[z], n[z+1]
-    const bool down = z >= 1 && (wn & 0x0Fu) == 0x0Eu;            // stands at z-1: !n[z-2], n[z-1], n[z], n[z+1]
-    const bool up = (wn & 0x1Cu) == 0x18u && c4;                  // stands at z+1: !n[z], n[z+1], n[z+2], own z+2 free
-    const bool gap = z >= 2 && (wn & 0x1Fu) == 0x1Fu && c4 && j_in;  // n[z-2..z+2] all AIR: a gap to jump over
-    const bool jflat = gap && (wj & 0x1Eu) == 0x1Cu;              // !j[z-1], j[z], j[z+1], j[z+2]
-    const bool jup = gap && (wj & 0x3Cu) == 0x38u;                // !j[z], j[z+1], j[z+2], j[z+3]
-    const bool jdown = gap && (wj & 0x0Fu) == 0x0Eu;              // !j[z-2], j[z-1], j[z], j[z+1]
-    const bool jump = jflat || jup || jdown;
-    bool ok = doit && n_in && (walk || down || up || jump);
+    const bool down = (z >= 1) & ((wn & 0x0Fu) == 0x0Eu);            // stands at z-1: !n[z-2], n[z-1], n[z], n[z+1]
+    const bool up = ((wn & 0x1Cu) == 0x18u) & (c4 != 0u);                  // stands at z+1: !n[z], n[z+1], n[z+2], own z+2 free
+    const bool gap = (z >= 2) & ((wn & 0x1Fu) == 0x1Fu) & (c4 != 0u) & j_in;  // n[z-2..z+2] all AIR: a gap to jump over
+    const bool jflat = gap & ((wj & 0x1Eu) == 0x1Cu);              // !j[z-1], j[z], j[z+1], j[z+2]
+    const bool jup = gap & ((wj & 0x3Cu) == 0x38u);                // !j[z], j[z+1], j[z+2], j[z+3]
+    const bool jdown = gap & ((wj & 0x0Fu) == 0x0Eu);              // !j[z-2], j[z-1], j[z], j[z+1]
+    const bool jump = jflat | jup | jdown;
+    bool ok = doit & n_in & (walk | down | up | jump);
     const int kind = walk ? M3_WALK : (down ? M3_DOWN : (up ? M3_UP : (jflat ? M3_JFLAT : (jup ? M3_JUP : M3_JDOWN))));
-    const int add = walk ? 1 : ((jup || jdown) ? 3 : 2);
-    const int tz = z + ((up || jup) ? 1 : 0) - ((down || jdown) ? 1 : 0);
+    const int add = walk ? 1 : ((jup | jdown) ? 3 : 2);
+    const int tz = z + ((up | jup) ? 1 : 0) - ((down | jdown) ? 1 : 0);
     const int tq = jump ? qj : qn, tx = jump ? jx : nx, ty = jump ? jy : ny;
     const int tcell = tz * YX + tq;
     // read set: this entry's column, the neighbour's and the landing's
@@ -269,7 +270,7 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     M3_TT(5);  // move rules + read set
     // never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it)
     const uint32_t bt = L.best[ok ? tcell : 0];
-    if ((bt >> 24) == epoch && (int)((bt >> 12) & 0xFFFu) <= len + add) ok = false;
+    ok &= !(((bt >> 24) == epoch) & ((int)((bt >> 12) & 0xFFFu) <= len + add));
     const uint64_t okb = __ballot(ok);
     const int npush = __popcll(okb);
     if (tail + npush > M3_ENT_CAP) {
