@@ -546,6 +546,23 @@ struct ProbTraits<PCGRL_PROB_MC3DMAZE> {
   static constexpr int NAUX = 0;
 };
 
+// The kernel argument block (Params, ~750 bytes = 12 cache lines) is new for every launch, so the first read of each of its
+// lines misses the scalar cache, and the compiler reads fields where they are first used: the step kernel's prologue paid
+// five to six DEPENDENT scalar-memory round trips before its first useful instruction.  One dword of every line, all
+// requested at once at kernel entry (a single asm statement: its operands must be in registers together), turns that into
+// one round trip; the later reads hit the scalar cache.
+__device__ __attribute__((always_inline)) inline void touch_kernarg(const Params &p) {
+  const int32_t *kw = (const int32_t *)&p;
+  constexpr int L = (int)((sizeof(Params) + 63) / 64);
+  static_assert(L <= 13, "touch_kernarg: one operand per 64-byte line");
+  asm volatile("" ::"s"(kw[0]), "s"(kw[16 < sizeof(Params) / 4 ? 16 : 0]), "s"(kw[32 < sizeof(Params) / 4 ? 32 : 0]),
+               "s"(kw[48 < sizeof(Params) / 4 ? 48 : 0]), "s"(kw[64 < sizeof(Params) / 4 ? 64 : 0]),
+               "s"(kw[80 < sizeof(Params) / 4 ? 80 : 0]), "s"(kw[96 < sizeof(Params) / 4 ? 96 : 0]),
+               "s"(kw[112 < sizeof(Params) / 4 ? 112 : 0]), "s"(kw[128 < sizeof(Params) / 4 ? 128 : 0]),
+               "s"(kw[144 < sizeof(Params) / 4 ? 144 : 0]), "s"(kw[160 < sizeof(Params) / 4 ? 160 : 0]),
+               "s"(kw[176 < sizeof(Params) / 4 ? 176 : 0]), "s"(kw[192 < sizeof(Params) / 4 ? 192 : 0]));
+}
+
 template <int LPE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
                               uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
@@ -1483,6 +1500,8 @@ void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+  // (binary: no gain at 4096 envs and six more VGPRs, i.e. one wave per SIMD less at large batches; sokoban-wide -6 %)
+  if constexpr (PROB != PCGRL_PROB_BINARY) touch_kernarg(p);
   Grp<LPE> g;
   g.init();
   // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; with it the role branches are scalar)

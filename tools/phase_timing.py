@@ -26,15 +26,18 @@ _lib.LIB_PATH = TIMING_LIB
 from control_pcgrl_amd import VecPcgrlEnv
 
 three_d = "--3d" in sys.argv
-n, iters = (1024, 1000) if three_d else (4096, 2000)
+soko = "--sokoban" in sys.argv  # sokoban-wide 16x16, 2048 envs (BASELINE C4)
+n, iters = (1024, 1000) if three_d else ((2048, 2000) if soko else (4096, 2000))
 if three_d:
     NAMES = ["loads+action", "observation", "column masks", "regions", "path searches", "overlay", "loss/outputs/write-back"]
     env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
+elif soko:
+    env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 else:
     env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
-pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
+pool = torch.randint(0, 256 * 5 if soko else 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
 for k in range(300):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
