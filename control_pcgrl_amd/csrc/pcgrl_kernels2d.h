@@ -1524,6 +1524,10 @@ void step_kernel(Params p) {
     return;
   }
   SokoHelpersGuard helpers_guard{helped && !observer};
+  // Small batches are bound by the simulate wave's dependent chain: it issues ahead of the observe wave that shares its
+  // SIMD (binary 4096 envs 5.88 -> 5.73 us, sokoban-wide 6.14 -> 5.90).  From 16 384 envs on the launch is bound by
+  // the observation stores and the same priority costs 3-4 %, so it depends on the batch.
+  if (PROB != PCGRL_PROB_ZELDA && !observer && p.n_envs <= 8192) __builtin_amdgcn_s_setprio(3);  // (zelda: store-bound at any size)
   PHASE_DECL();
   TRACE_DECL();
   const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
@@ -1783,6 +1787,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   const size_t astride = N * (size_t)p.n_act;  // action entries per step
   int action = (active && p.n_act == 1) ? p.actions[e] : 0;
   if (p.obs != nullptr) __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
+  if (PROB != PCGRL_PROB_ZELDA && !observer && p.n_envs <= 8192) __builtin_amdgcn_s_setprio(3);  // (as in step_kernel)
   bool any_change = false, any_reset = false, bad_any = false;
 
   for (int k = 0; k < K; k++) {

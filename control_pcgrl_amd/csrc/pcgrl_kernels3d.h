@@ -606,6 +606,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       TRACE_PUT(3, TRACE_NOW());
       return;
     }
+    __builtin_amdgcn_s_setprio(3);  // the simulate wave's dependent chain issues ahead of the observe wave on its SIMD
   }
 
   if constexpr (MODE == M3_STATS_FOR_GRIDS) {
