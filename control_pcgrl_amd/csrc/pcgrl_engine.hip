@@ -404,6 +404,12 @@ __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, 
 // nothing and may lag a launch or two, which only delays the switch.
 static void choose_spread(pcgrl_engine *h, Params &p) {
   if (!h->seen_host || h->p.ext) return;
+  static const int force = getenv("PCGRL_FORCE_SPREAD") ? atoi(getenv("PCGRL_FORCE_SPREAD")) : 0;  // development: 1 = spread, 2 = + helpers
+  if (force) {
+    p.spread = 1;
+    p.sk_helpers = force == 2 ? 3 : 0;
+    return;
+  }
   const int32_t seen = *(volatile int32_t *)h->seen_host;
   if (seen != h->seen_last) {
     h->seen_last = seen;

@@ -1092,6 +1092,33 @@ def _solvable_rooms(n, seed, shape=(16, 16)):
     return g
 
 
+def test_sokoban_solver_long_searches_vs_oracle():
+    """Unsolvable open rooms (one target sits at the far end of an L-shaped alcove no crate can be pushed into) with 3-6
+    crates at the largest accepted solver_power (16 000): all four stages run to the cap, the A* open lists grow past the
+    part the helper waves keep in LDS (8 192 entries), so the sifts cross from LDS into the HBM part of the heap; the
+    visited table fills to half (group overflow); the levels with six crates use hashed instead of exact keys."""
+    rng = np.random.default_rng(11)
+    n = 12
+    g = np.ones((n, 16, 16), np.uint8)
+    for i in range(n):
+        h, w = int(rng.integers(8, 12)), int(rng.integers(9, 14))
+        y0, x0 = int(rng.integers(3, 16 - h)), int(rng.integers(1, 16 - w))
+        g[i, y0:y0 + h, x0:x0 + w] = 0
+        g[i, y0 - 2:y0, x0 + 2] = 0
+        g[i, y0 - 2, x0 + 3] = 4
+        k = 3 + i % 4
+        inner = [(y, x) for y in range(y0 + 1, y0 + h - 1) for x in range(x0 + 1, x0 + w - 1)]
+        pick = rng.permutation(len(inner))[:2 * k]
+        for c, t in zip(pick, [2] + [3] * k + [4] * (k - 1)):
+            g[i, inner[c][0], inner[c][1]] = t
+    want = po.stats_for_grids("sokoban", g, solver_power=16000)
+    assert (want[:, 4] != 8192).all() and (want[:, 5] == 0).all(), "the solver runs on every level and never wins"
+    env = _vec("sokoban", "narrow", (16, 16), 4, solver_power=16000)
+    got = env.stats_for_grids(torch.as_tensor(g).to(env.device)).cpu().numpy()
+    assert np.array_equal(got, want), (got, want)
+    env.check_errors()
+
+
 def test_sokoban_wide_2048_envs_solver_inside_episodes_vs_oracle():
     """BASELINE configs[3] at its batch size with the solver FIRING inside step launches: playable levels are injected,
     the agent edits floor / wall cells, and dist-win / sol-length move the reward; hundreds of waves hold workspace slots
