@@ -211,6 +211,11 @@ def main():
     step_raw = env.step_raw
 
     def run_eager(n, first=0):
+        if inject is None:  # n launches issued by one call into the library (a C host's loop: no per-launch ctypes cost)
+            rc = env.step_seq_raw(base, stride // 4, POOL, first % POOL, n, sptr) if n > 0 else 0
+            if rc:
+                raise RuntimeError(f"pcgrl_step_seq rc={rc}")
+            return
         for k in range(first, first + n):
             if inject is not None and k % REINJECT == 0:
                 env._L.pcgrl_reset(env._h, None, inject.data_ptr(), None, sptr)
@@ -315,6 +320,7 @@ def main():
             torch.cuda.synchronize(dev)
             return
         env.reduce_episodes(clear=True, out=ep_dev)
+        local_eps.copy_(ep_dev[2:3], non_blocking=True)  # (test evidence: this rank's own episode count)
         if coll_dev.type == "cpu":  # gloo test hook
             t = ep_dev.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -355,8 +361,8 @@ def main():
         del g, buf
         return {"bytes": nbytes, "us": us, "GBps": nbytes / us / 1e3, "frac_of_peak": nbytes / us / 1e3 / HBM_PEAK_GBS}
 
-    reduce_episodes()  # warm the reporting path (first all-reduce), clean accumulators
     local_eps = torch.zeros(1, dtype=torch.float64, device=dev)
+    reduce_episodes()  # warm the reporting path (first all-reduce), clean accumulators
     fill = measure_fill() if not args.dry_run else None
     rollout = measure_rollout()
     run(W)
@@ -367,11 +373,10 @@ def main():
     ev0.record(stream)
     run(K)
     ev1.record(stream)
-    if world > 1:  # (test evidence: this rank's own episode count, read after the timed region)
-        local_eps = env.reduce_episodes(clear=False)[2:3].clone()
-    reduce_episodes()  # (synchronises the device)
-    if world > 1:
-        barrier()
+    # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-reduce of the episode sums
+    # cannot complete on any rank before every rank has contributed, i.e. finished its K launches; one collective instead
+    # of an all-reduce followed by a barrier.  Ends with the device synchronised.
+    reduce_episodes()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
     env.check_errors()
@@ -401,7 +406,7 @@ def main():
                                    + "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)",
-                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step",
+                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
                        "seed_ranges": [[0x5EED + lo, 0x5EED + hi - 1] for lo, hi in
                                        (shard_env_range(total_envs, r, world) for r in range(world))]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -40,6 +40,8 @@ SYMBOLS = {
     "pcgrl_destroy": (None, [C.c_void_p]),
     "pcgrl_seed": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pcgrl_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_step_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "pcgrl_step_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

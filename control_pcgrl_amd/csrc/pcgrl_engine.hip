@@ -578,6 +578,19 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   return PCGRL_OK;
 }
 
+int pcgrl_step_seq(pcgrl_handle h, const int32_t *d_action_rows, int64_t row_stride, int32_t n_rows, int32_t first_row,
+                   int32_t n_steps, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done, int32_t *d_stats,
+                   void *stream) {
+  if (!h || !d_action_rows || n_rows < 1 || n_steps < 0 || first_row < 0 || row_stride < 0)
+    return fail(PCGRL_EINVAL, "pcgrl_step_seq: bad arguments");
+  for (int32_t k = 0; k < n_steps; k++) {
+    const int rc = pcgrl_step(h, d_action_rows + (size_t)((first_row + k) % n_rows) * (size_t)row_stride, auto_reset, d_obs, d_reward,
+                              d_done, d_stats, stream);
+    if (rc != PCGRL_OK) return rc;
+  }
+  return PCGRL_OK;
+}
+
 int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                   double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step_ex: bad arguments");

@@ -257,6 +257,12 @@ class VecPcgrlEnv:
         return self._L.pcgrl_step(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
                                   self._ptrs[2], self._ptrs[3], stream)
 
+    def step_seq_raw(self, rows_ptr, row_stride, n_rows, first_row, n_steps, stream):
+        """n_steps pcgrl_step launches from ONE foreign call (pcgrl_step_seq): step k uses action row
+        (first_row + k) % n_rows of the int32 buffer at rows_ptr (rows row_stride entries apart)."""
+        return self._L.pcgrl_step_seq(self._h, rows_ptr, row_stride, n_rows, first_row, n_steps, 1 if self.auto_reset else 0,
+                                      self._ptrs[0], self._ptrs[1], self._ptrs[2], self._ptrs[3], stream)
+
     def rollout(self, actions, want_obs="all"):
         """Open-loop rollout: `actions` int32 [K, N] (or [K, N, prod(act_window)] with an action patch); K steps in one
         launch (pcgrl_rollout / pcgrl_rollout_ex).  Returns (obs, reward [K, N], done [K, N], stats [K, N, n_stats]); obs

@@ -109,6 +109,15 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
 int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                uint8_t *d_done, int32_t *d_stats, void *stream);
 
+/* n_steps pcgrl_step launches issued by one call: step k takes the action row (first_row + k) % n_rows of
+ * d_action_rows (rows row_stride int32 apart) and writes the same output buffers.  Exactly what a C host's loop over
+ * pcgrl_step does (one launch per step, each with its own actions); it exists so that a Python host pays the
+ * foreign-call cost once per sequence instead of once per launch (the reference's random-action loop,
+ * profile_env.py:124-142, and bench.py's eager launches). */
+int pcgrl_step_seq(pcgrl_handle h, const int32_t *d_action_rows, int64_t row_stride, int32_t n_rows, int32_t first_row,
+                   int32_t n_steps, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done, int32_t *d_stats,
+                   void *stream);
+
 /* pcgrl_step with the extra outputs of the controllable mode (any pointer may be NULL):
  *   d_reward64 double [N]         the reward in float64 (float targets make the loss non-integral)
  *   d_ctrl_obs float [N][2*n_ctrl] observe_metric_trgs (control_wrappers.py:189-214): for control k, column 2k =

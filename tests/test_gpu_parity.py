@@ -1092,6 +1092,26 @@ def _solvable_rooms(n, seed, shape=(16, 16)):
     return g
 
 
+def test_step_seq_equals_single_steps():
+    """pcgrl_step_seq = the same launches as a loop over pcgrl_step (action rows taken round-robin from a pool)"""
+    n, pool, k = 300, 7, 23
+    a = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True, change_percentage=0.05)
+    b = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True, change_percentage=0.05)
+    a.reset()
+    b.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rows = torch.randint(0, 2, (pool, n), generator=g, device="cuda", dtype=torch.int32)
+    sp = torch.cuda.current_stream().cuda_stream
+    assert a.step_seq_raw(rows.data_ptr(), n, pool, 3, k, sp) == 0
+    for i in range(k):
+        out = b.step(rows[(3 + i) % pool])
+    sa, sb = a.get_state(), b.get_state()
+    for f in ("grids", "pos", "counters", "stats", "last_loss", "ep_return"):
+        assert torch.equal(getattr(sa, f), getattr(sb, f)), f
+    assert torch.equal(a._obs, b._obs) and torch.equal(a._reward, b._reward) and torch.equal(a._done, b._done)
+    a.check_errors()
+
+
 def test_sokoban_solver_long_searches_vs_oracle():
     """Unsolvable open rooms (one target sits at the far end of an L-shaped alcove no crate can be pushed into) with 3-6
     crates at the largest accepted solver_power (16 000): all four stages run to the cap, the A* open lists grow past the
