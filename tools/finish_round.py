@@ -53,7 +53,7 @@ big = lines.get("binary-narrow-65536")
 headline = f"""| quantity | value | source |
 |---|---|---|
 | env-steps/s | **{sci(b['value'])}** (north-star target 1 × 10⁷) | `bench.py`, wall clock |
-| per step | {fmt(b['ms_per_step'] * 1e3)} µs wall = {fmt(b['roofline']['avg_launch_us'])} µs by HIP events on the launch stream""" + (f"; eager launches from the Python loop: {fmt(eager['ms_per_step'] * 1e3)} µs (host-bound)" if eager else "") + f""" | `bench.py` |
+| per step | {fmt(b['ms_per_step'] * 1e3)} µs wall = {fmt(b['roofline']['avg_launch_us'])} µs by HIP events on the launch stream""" + (f"; eager launches (`pcgrl_step_seq`): {fmt(eager['ms_per_step'] * 1e3)} µs" if eager else "") + f""" | `bench.py` |
 | step kernel, begin–end under `rocprofv3 --kernel-trace` | mean {fmt(dk['mean'] / 1e3)} µs, median {fmt(dk['median'] / 1e3)}, p10 {fmt(dk['p10'] / 1e3)}, p99 {fmt(dk['p99'] / 1e3)} ({ws['dominant_kernel_launch']['launches']} launches; start-to-start {fmt(ws['dominant_kernel_launch']['median_start_to_start_ns'] / 1e3)} µs) | `profiles/{tag}_kernel_stats.csv`, `profiles/{tag}_summary.json` |
 | roofline | {b['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic / {fmt(b['ms_per_step'] * 1e3)} µs = {b['roofline']['achieved'] / 1e3:.2f} TB/s = **{fmt(b['roofline']['frac'], 3)} of 8 TB/s** (from the profiled kernel mean: {fmt(b['roofline']['algorithmic_bytes_per_launch'] / (dk['mean'] * 1e-9) / 8e12, 3)}) | `bench.py` |
 | HBM traffic | WRITE_SIZE {tr['write_bytes'] / 1e6:.1f} MB + 2×FETCH_SIZE {tr['fetch_bytes_x2_correction'] / 1e6:.1f} MB = {tr['traffic_bytes'] / 1e6:.1f} MB / launch = {fmt(tr['traffic_over_algorithmic'])} × algorithmic | `profiles/{tag}_summary.json` |
