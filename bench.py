@@ -226,7 +226,11 @@ def main():
     # The launch-bound inner loop is captured once in a HIP graph of G consecutive steps (each node = one pcgrl_step
     # launch with its own action row) and replayed; K steps = K // G replays + K % G eager launches.  G = 125 is
     # coprime with the narrow scan period (256 cells), so every cell keeps receiving fresh random actions.
-    G = args.graph_steps if args.graph_steps >= 0 else (125 if (K >= 250 and inject is None) else 0)
+    # Short runs (the driver's --steps 20 --warmup 5): a graph of gcd(W, K) steps, so that its first, cold replay falls
+    # into the warm-up and the timed region only sees warm replays.
+    import math
+    G_short = math.gcd(W, K) if (0 < W and 2 <= math.gcd(W, K) <= 125) else 0
+    G = args.graph_steps if args.graph_steps >= 0 else ((125 if K >= 250 else G_short) if inject is None else 0)
     graph = None
     if G > 0:
         graph = torch.cuda.CUDAGraph()
