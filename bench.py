@@ -233,17 +233,24 @@ def main():
     G = args.graph_steps if args.graph_steps >= 0 else ((125 if K >= 250 else G_short) if inject is None else 0)
     graph = None
     if G > 0:
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(stream)
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                cap = torch.cuda.current_stream(dev).cuda_stream
-                for k in range(G):
-                    rc = step_raw(base + (k % POOL) * stride, cap)
-                    if rc:
-                        raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
-        stream.wait_stream(side)
+        # (thread-local capture mode: with N > 1 ranks the RCCL watchdog thread queries events while this thread captures;
+        # if the capture fails all the same, the launches are issued eagerly)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    cap = torch.cuda.current_stream(dev).cuda_stream
+                    for k in range(G):
+                        rc = step_raw(base + (k % POOL) * stride, cap)
+                        if rc:
+                            raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
+            stream.wait_stream(side)
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: graph capture failed ({exc!r}); eager launches", file=sys.stderr, flush=True)
+            graph = None
+            torch.cuda.synchronize(dev)
 
     def run(n):
         if graph is None:
