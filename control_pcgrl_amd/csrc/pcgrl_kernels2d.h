@@ -221,6 +221,33 @@ __device__ inline M expand(const Grp<LPE> &g, M f) {
   return (f << 1) | (f >> 1) | g.from_above(f) | g.from_below(f);
 }
 
+// One BFS level: returns the new frontier expand(front) & free_cells and removes it from free_cells.  16-row maps with
+// 32-bit masks (the headline kernels): six instructions instead of the compiler's seven -- the row shifts ride on the ORs
+// (v_or_b32_dpp; the compiler re-associates the four-way OR into 2 x v_mov_b32_dpp + v_or3_b32) and both results come from
+// one three-input bit operation each.  The two plain shifts come first: a DPP operand written by the preceding vector
+// instruction needs two wait states.  bitop3 truth tables (index = a<<2 | b<<1 | free): 0xA8 = (a | b) & free,
+// 0x02 = free & ~(a | b).
+template <int LPE, typename M>
+__device__ __attribute__((always_inline)) inline M bfs_level(const Grp<LPE> &g, M front, M &free_cells) {
+  if constexpr (LPE == 16 && sizeof(M) == 4) {
+    uint32_t nb, a, b, fr = (uint32_t)free_cells;
+    asm("v_lshlrev_b32 %1, 1, %4\n\t"
+        "v_lshrrev_b32 %2, 1, %4\n\t"
+        "v_or_b32_dpp %1, %4, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_or_b32_dpp %2, %4, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8\n\t"
+        "v_bitop3_b32 %3, %1, %2, %3 bitop3:2"
+        : "=&v"(nb), "=&v"(a), "=&v"(b), "+v"(fr)
+        : "v"((uint32_t)front));
+    free_cells = (M)fr;
+    return (M)nb;
+  } else {
+    const M nb = expand(g, front) & free_cells;
+    free_cells ^= nb;
+    return nb;
+  }
+}
+
 // first set cell in row-major order: one bit in one lane of the group (0 everywhere if the set is empty)
 template <int LPE, typename M>
 __device__ inline M first_rowmajor(const Grp<LPE> &g, M x) {
@@ -288,11 +315,7 @@ __device__ inline M flood(const Grp<LPE> &g, M seed, M avail) {
     M front = seed & avail, free_cells = avail & ~front;
     while (true) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const M nb = expand(g, front) & free_cells;
-        free_cells ^= nb;
-        front = nb;
-      }
+      for (int u = 0; u < 8; u++) front = bfs_level(g, front, free_cells);
       if (__ballot(front != 0) == 0) break;
     }
     return avail & ~free_cells;
@@ -344,8 +367,7 @@ __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &las
   for (int trip = 0; trip < SWEEP_TRACKED_TRIPS && more; trip++) {
 #pragma unroll
     for (int u = 0; u < SWEEP_UNROLL; u++) {
-      const M nb = expand(g, front) & free_cells;
-      free_cells ^= nb;
+      const M nb = bfs_level(g, front, free_cells);
       lev++;
       mylev = nb ? lev : mylev;
       mynb = nb ? nb : mynb;
@@ -358,11 +380,7 @@ __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &las
     int s_lev = lev;
     while (true) {
 #pragma unroll
-      for (int u = 0; u < SWEEP_UNTRACKED_UNROLL; u++) {
-        const M nb = expand(g, front) & free_cells;
-        free_cells ^= nb;
-        front = nb;
-      }
+      for (int u = 0; u < SWEEP_UNTRACKED_UNROLL; u++) front = bfs_level(g, front, free_cells);
       lev += SWEEP_UNTRACKED_UNROLL;
       const uint64_t bal = __ballot(front != 0);
       const bool alive = g.gslice(bal) != 0;
@@ -378,8 +396,7 @@ __device__ inline void sweep(const Grp<LPE> &g, M src, M avail, int &len, M &las
     mynb = f ? f : mynb;
 #pragma unroll
     for (int u = 0; u < SWEEP_UNTRACKED_UNROLL; u++) {
-      const M nb = expand(g, f) & fr;
-      fr ^= nb;
+      const M nb = bfs_level(g, f, fr);
       l++;
       mylev = nb ? l : mylev;
       mynb = nb ? nb : mynb;
@@ -503,8 +520,7 @@ __device__ inline void bfs_first_hit(const Grp<LPE> &g, M src, M avail, M target
   while (true) {
 #pragma unroll
     for (int u = 0; u < SWEEP_UNROLL; u++) {
-      const M nb = expand(g, front) & free_cells;
-      free_cells ^= nb;
+      const M nb = bfs_level(g, front, free_cells);
       lev++;
       myA = ((nb & targetA) != 0 && myA == NONE) ? lev : myA;
       myB = ((nb & targetB) != 0 && myB == NONE) ? lev : myB;
@@ -1504,8 +1520,10 @@ void step_kernel(Params p) {
   if constexpr (PROB != PCGRL_PROB_BINARY) touch_kernarg(p);
   Grp<LPE> g;
   g.init();
-  // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; with it the role branches are scalar)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wave >> 1;
+  // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; with it the role branches are scalar.
+  // Not for binary: no gain there and a register allocation of 86 instead of 80 VGPRs, i.e. 5 instead of 6 waves per SIMD)
+  const int wave = PROB == PCGRL_PROB_BINARY ? (int)(threadIdx.x >> 6) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pair = wave >> 1;
   const bool observer = (wave & 1) != 0;  // wave-uniform
   uint8_t *lds = lds_all + (size_t)pair * p.lds_pair_bytes;
   // sokoban, launched with p.sk_helpers (while its solver is busy): waves 2.. are the solver's helpers
