@@ -1516,8 +1516,7 @@ void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
-  // (binary: no gain at 4096 envs and six more VGPRs, i.e. one wave per SIMD less at large batches; sokoban-wide -6 %)
-  if constexpr (PROB != PCGRL_PROB_BINARY) touch_kernarg(p);
+  touch_kernarg(p);
   Grp<LPE> g;
   g.init();
   // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; with it the role branches are scalar.
@@ -1557,11 +1556,10 @@ void step_kernel(Params p) {
   const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
   const int e = active ? env : 0;
 
+  // (both roles issue the same loads -- the observe wave just never looks at the statistics masks: with role-dependent
+  // loads the compiler waits for them at the join, before the state and action loads are even issued)
   M b[NW];
-  if (observer)
-    load_planes<NB, M, FAST>(p, e, g.row, rowok, b);
-  else
-    load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
+  load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
   // representation wrappers (static tiles / action patch): run-time option of the general kernels only
   ExtRow<NB, M> X;
   bool ext = false;
@@ -1776,11 +1774,10 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   const size_t N = (size_t)p.n_envs;
   const int K = p.n_steps;
 
+  // (both roles issue the same loads -- the observe wave just never looks at the statistics masks: with role-dependent
+  // loads the compiler waits for them at the join, before the state and action loads are even issued)
   M b[NW];
-  if (observer)
-    load_planes<NB, M, FAST>(p, e, g.row, rowok, b);
-  else
-    load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
+  load_planes<NW, M, FAST>(p, e, g.row, rowok, b);
   ExtRow<NB, M> X;
   bool ext = false;
   if constexpr (!FAST) {

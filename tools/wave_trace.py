@@ -27,7 +27,7 @@ n = 1024 if three_d else 4096
 if three_d:
     env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
 else:
-    env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+    env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset="--no-reset" not in sys.argv)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
