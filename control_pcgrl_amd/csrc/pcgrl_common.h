@@ -79,6 +79,9 @@ struct Params {
   int32_t *err;           // device error word
   void *soko;             // SokoPool* (sokoban solver workspace), else null
   int32_t *solver_seen;   // host-mapped counter of device solver runs (sokoban), else null
+  // the static targets as integers when all of them are integral or infinite (see get_loss); int_targets = 0 otherwise
+  int32_t trg_lo_i[PCGRL_MAX_STATS], trg_hi_i[PCGRL_MAX_STATS];
+  int32_t int_targets;
   int32_t spread;         // sokoban step: one env per wave pair (see step_kernel)
   int32_t sk_helpers;     // sokoban: helper wavefronts per workgroup for the solver's A* stages (0 or 3, see pcgrl_sokoban.h)
   void *m3cache;          // M3Slot[N][M3_SLOTS]: cached path-search results per start plane (3-D maze), else null

@@ -445,6 +445,30 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   Params &p = e->p;
   memset(&p, 0, sizeof(p));
   p.cfg = *cfg;
+  {  // integer form of the static targets (get_loss): statistics are far below 2^29 in magnitude, so infinite bounds clamp there
+    bool integral = true;
+    for (int k = 0; k < PCGRL_MAX_STATS; k++) {
+      const double lo = cfg->trg_lo[k], hi = cfg->trg_hi[k];
+      const int32_t big = 1 << 29;
+      int32_t lo_i = 0, hi_i = 0;
+      if (k < cfg->n_stats && cfg->has_trg[k]) {
+        if (lo != lo || hi != hi || lo > hi) integral = false;  // (NaN, or an empty interval: the float64 form decides)
+        else {
+          if (lo <= -(double)big) lo_i = -big;
+          else if (lo >= (double)big) lo_i = big;
+          else if (lo == (double)(int32_t)lo) lo_i = (int32_t)lo;
+          else integral = false;
+          if (hi >= (double)big) hi_i = big;
+          else if (hi <= -(double)big) hi_i = -big;
+          else if (hi == (double)(int32_t)hi) hi_i = (int32_t)hi;
+          else integral = false;
+        }
+      }
+      p.trg_lo_i[k] = lo_i;
+      p.trg_hi_i[k] = hi_i;
+    }
+    p.int_targets = integral ? 1 : 0;
+  }
   p.n_envs = n_envs;
   p.n_tiles = n_tiles_of(cfg->problem);
   const bool is3d = cfg->problem == PCGRL_PROB_MC3DMAZE;

@@ -35,6 +35,8 @@ elif soko:
     env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 else:
     env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+if soko:
+    NAMES = ["loads+barrier", "action+state", "stats refresh", "loss + outputs", "auto-reset block", "-", "state write-back"]
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 256 * 5 if soko else 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
