@@ -606,14 +606,40 @@ __device__ inline M region_cells(const M *b, M cm) {
 
 // Region count after editing the single cell `x` (one bit in one lane; 0 for groups that keep their count).  If the
 // cell's membership flips, let U be the component of x in the map where x counts: on the other side of the edit U - x
-// falls into `pieces` components (0..4), so the count moves by +-(pieces - 1).  One flood and at most four fills instead
-// of one fill per region of the whole map.
+// falls into `pieces` components (0..4), so the count moves by +-(pieces - 1).  Every cell of U - x is connected, not
+// through x, to one of x's (up to four) member neighbours, so `pieces` is the number of classes of those neighbours:
+//   * no member neighbour: pieces = 0;
+//   * all of them connected to each other inside the eight cells around x (a walk of at most seven steps along that
+//     ring): pieces = 1, WITHOUT looking at the rest of the map -- the common case;
+//   * otherwise one flood from the first neighbour over the members other than x; neighbours it does not reach start
+//     further floods (at most three more, rare).
+// Round 1 / first pass of round 2: one flood for U plus one fill per piece, for every flipping edit.
 template <int LPE, typename M>
 __device__ inline int regions_update(const Grp<LPE> &g, M x, M w_old, M w_new, int regions_old) {
   const bool flip = g.gany((x & (w_old ^ w_new)) != 0);
   const bool became = g.gany((x & w_new & ~w_old) != 0);
-  const M U = flood(g, flip ? x : M(0), became ? w_new : w_old);
-  const int pieces = count_regions(g, U & ~x);
+  const M xs = flip ? x : M(0);
+  const M W = (w_old | w_new) & ~xs;  // the members other than x (the two maps differ in x only)
+  const M xh = xs | (xs << 1) | (xs >> 1);
+  const M ring = (xh | g.from_above(xh) | g.from_below(xh)) & W;  // members among the eight cells around x
+  const M nbr = expand(g, xs) & W;                                // members among the four neighbours
+  // the ring class of the first neighbour (ring cells that follow each other on the ring are 4-adjacent)
+  M loc = first_rowmajor(g, nbr);
+#pragma unroll
+  for (int u = 0; u < 7; u++) loc |= expand(g, loc) & ring;
+  M rest = nbr & ~loc;
+  int pieces = g.gany(nbr != 0) ? 1 : 0;
+  if (__ballot(rest != 0) != 0) {  // (some group's neighbours are not connected around x: ask the map)
+    const bool open = g.gany(rest != 0);
+    M seen = flood(g, open ? loc : M(0), W);
+    rest &= ~seen;
+    while (__ballot(rest != 0) != 0) {
+      pieces += g.gany(rest != 0) ? 1 : 0;
+      const M f = flood(g, first_rowmajor(g, rest), W & ~seen);
+      seen |= f;
+      rest &= ~f;
+    }
+  }
   return flip ? (became ? regions_old - pieces + 1 : regions_old - 1 + pieces) : regions_old;
 }
 
