@@ -268,14 +268,27 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     zlo = doit ? min(zlo, z) : zlo;
     zhi = doit ? max(zhi, z) : zhi;
     M3_TT(5);  // move rules + read set
-    // never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it)
-    const uint32_t bt = L.best[ok ? tcell : 0];
-    ok &= !(((bt >> 24) == epoch) & ((int)((bt >> 12) & 0xFFFu) <= len + add));
-    const uint64_t okb = __ballot(ok);
-    const int npush = __popcll(okb);
+    // Never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it) --
+    // but only while the queue is long: the check is one more dependent LDS round trip per trip, and with a short queue
+    // (corridors: the searches that make a launch wait) the few useless entries are dropped for free when popped.
+    auto prune = [&]() {
+      const uint32_t bt = L.best[ok ? tcell : 0];
+      ok &= !(((bt >> 24) == epoch) & ((int)((bt >> 12) & 0xFFFu) <= len + add));
+    };
+    const bool lazy = tail - head <= 32;
+    if (!lazy) prune();
+    uint64_t okb = __ballot(ok);
+    int npush = __popcll(okb);
     if (tail + npush > M3_ENT_CAP) {
-      overflow = true;
-      break;
+      if (lazy) {  // (never an overflow that the check would have avoided)
+        prune();
+        okb = __ballot(ok);
+        npush = __popcll(okb);
+      }
+      if (tail + npush > M3_ENT_CAP) {
+        overflow = true;
+        break;
+      }
     }
     if (ok)
       L.ent[tail + __popcll(okb & lt)] =
