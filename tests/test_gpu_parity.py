@@ -1092,6 +1092,26 @@ def _solvable_rooms(n, seed, shape=(16, 16)):
     return g
 
 
+def test_loss_integer_and_float64_forms_agree():
+    """get_loss has an integer form (all static targets integral: every stock problem) and the float64 form; a
+    non-integral target on a zero-weighted statistic switches an engine to the float64 form without changing any reward."""
+    n, k = 512, 300
+    w = {"regions": 1.0, "path-length": 0.0}
+    a = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True, weights=w)
+    b = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True, weights=w,
+             static_trgs={"path-length": 48.5})
+    a.reset()
+    b.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.randint(0, 2, (k, n), generator=g, device="cuda", dtype=torch.int32)
+    for i in range(k):
+        ra = a.step(acts[i])[1].clone()
+        rb = b.step(acts[i])[1]
+        assert torch.equal(ra, rb), i
+    sa, sb = a.get_state(), b.get_state()
+    assert torch.equal(sa.last_loss, sb.last_loss) and torch.equal(sa.ep_return, sb.ep_return) and torch.equal(sa.stats, sb.stats)
+
+
 def test_step_seq_equals_single_steps():
     """pcgrl_step_seq = the same launches as a loop over pcgrl_step (action rows taken round-robin from a pool)"""
     n, pool, k = 300, 7, 23
