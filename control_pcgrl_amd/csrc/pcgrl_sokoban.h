@@ -439,62 +439,54 @@ __device__ __attribute__((always_inline)) inline uint32_t sk_heappop_impl(SokoCt
   const int lane = c.lane;
   tail = sk_u(tail) - 1;
   int pos = 0, depth = 0;
-  int myval = 0, mypos = 0;  // lane d: the value that moves into path position d, and that position
-  uint32_t last = 0, top = 0;
+  uint32_t last = 0, top = 0, root_pick = 0;
   bool leaf = false;
-  // lane j holds node j (level order, j = 0: `pos` itself) of the 6-level subtree below `pos`; lane 63 is spare
+  // lane j stands for node j (level order, j = 0: `pos` itself) of the 6-level subtree below `pos` and reads that node's
+  // two children itself: one memory wait per round; lane 63 is spare
   const int j1 = lane + 1, lvl = 31 - __builtin_clz((unsigned)j1), off = j1 - (1 << lvl);
   const int kids = lane < 31 ? 2 * lane + 1 : 0;  // lanes of my children
   for (int round = 0; !leaf; round++) {
-    int idx = ((pos + 1) << lvl) - 1 + off;
-    if (lane == 63) idx = tail;  // round 0: heap.pop(), the last element, re-inserted from the root
-    const bool in = lane < 63 ? idx < tail : round == 0;
-    const uint32_t v = sk_hq_load<LDSONLY>(c, idx, in);
-    if (round == 0) {
-      top = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);  // the item to return
+    const int idx = ((pos + 1) << lvl) - 1 + off, il = 2 * idx + 1;
+    const bool hasl = lane < 31 && il < tail, hasr = lane < 31 && il + 1 < tail;
+    const uint32_t vl = sk_hq_load<LDSONLY>(c, il, hasl), vr = sk_hq_load<LDSONLY>(c, il + 1, hasr);
+    if (round == 0) {  // the item to return (lane 0) and heap.pop(), the last element, re-inserted from the root (lane 63)
+      const uint32_t v = sk_hq_load<LDSONLY>(c, lane == 63 ? tail : 0, lane == 0 || lane == 63);
+      top = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
       last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
       if (tail == 0) return last;  // it was the only element
     }
     // every inner node picks the child _siftup would move up: the right one unless left < right
-    const uint32_t vl = (uint32_t)__builtin_amdgcn_ds_bpermute(kids << 2, (int)v);
-    const uint32_t vr = (uint32_t)__builtin_amdgcn_ds_bpermute((kids + 1) << 2, (int)v);
-    const int il = 2 * idx + 1;
-    const bool hasl = lane < 31 && il < tail, right = lane < 31 && il + 1 < tail && !sk_key_lt(vl, vr);
+    const bool right = hasr && !sk_key_lt(vl, vr);
     const int sel = hasl ? kids + (right ? 1 : 0) : -1;  // lane of that child, -1: no children
-    const int pickv = (int)(right ? vr : vl);
-    // the walk itself only follows `sel` (one scalar lane read per level); the lanes of the nodes it passed are packed
-    // into a scalar, 6 bits per level, and every lane of the path fetches its own value / position afterwards
-    int loc = 0, steps = 0;
-    uint32_t locs = 0;
+    const uint32_t pickv = right ? vr : vl;
+    if (round == 0) root_pick = (uint32_t)__builtin_amdgcn_readlane((int)pickv, 0);
+    // the walk follows `sel` (one scalar lane read per level) and collects the lanes of the nodes it leaves
+    int loc = 0;
+    uint64_t path = 0;
     for (int step = 0; step < 5; step++) {  // (the children of level 5 are not in this fetch)
       const int sl = __builtin_amdgcn_readlane(sel, loc);
       if (sl < 0) {
         leaf = true;
         break;
       }
+      path |= 1ull << loc;
       loc = sl;
-      steps++;
-      locs |= (uint32_t)sl << (6 * steps);
+      depth++;
     }
-    // heap[pos] = heap[childpos] for the `steps` levels walked: path position depth + t is node ((locs >> 6t) & 63)
-    const int t = lane - depth;
-    const bool on = t >= 0 && t < steps;
-    const int ml = on ? (int)((locs >> (6 * (t < 0 ? 0 : (t > 4 ? 4 : t)))) & 63u) : 0;
-    const int pv = __builtin_amdgcn_ds_bpermute(ml << 2, pickv), pi = __builtin_amdgcn_ds_bpermute(ml << 2, idx);
-    myval = on ? pv : myval;
-    mypos = on ? pi : mypos;
+    sk_hq_store<LDSONLY>(c, idx, pickv, ((path >> lane) & 1ull) != 0);  // heap[pos] = heap[childpos] along the path
     pos = __builtin_amdgcn_readlane(idx, loc);
-    depth += steps;
   }
-  // heap[pos] = newitem; _siftdown(heap, 0, pos): `last` climbs while it is smaller than the parent (= the picks above it)
-  mypos = lane == depth ? pos : mypos;
-  const int myprev = __builtin_amdgcn_ds_bpermute((lane > 0 ? lane - 1 : 0) << 2, myval);  // the pick one level up
-  const uint64_t smaller = __ballot(lane < depth && sk_key_lt(last, (uint32_t)myval));
-  const uint64_t stops = ~smaller & ((1ull << depth) - 1ull);
-  const int m = stops ? depth - 1 - (63 - __builtin_clzll(stops)) : depth;  // levels `last` climbs
-  const uint32_t fin = lane < depth - m ? (uint32_t)myval : (lane == depth - m ? last : (uint32_t)myprev);
-  sk_hq_store<LDSONLY>(c, mypos, fin, lane <= depth);
-  *new_top = (uint32_t)__builtin_amdgcn_readlane((int)fin, 0);
+  // heap[pos] = newitem; _siftdown(heap, 0, pos): `last` climbs while it is smaller than its parent -- rarely more than
+  // a level, it was a leaf
+  while (pos > 0) {
+    const int pp = (pos - 1) >> 1;
+    const uint32_t parent = (uint32_t)sk_u((int)sk_hq_load<LDSONLY>(c, pp, true));
+    if (!sk_key_lt(last, parent)) break;
+    sk_hq_store<LDSONLY>(c, pos, parent, lane == 0);
+    pos = pp;
+  }
+  sk_hq_store<LDSONLY>(c, pos, last, lane == 0);
+  *new_top = (pos == 0) ? last : root_pick;
   return top;
 }
 
