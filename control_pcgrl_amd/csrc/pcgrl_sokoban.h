@@ -207,19 +207,6 @@ struct SkCrates {
     }
     return n;
   }
-  __device__ inline uint32_t hash(int lane, int px, int py) const {
-    // position-dependent mix per crate, xor-combined over the wave (any function of the key will do: internal table)
-    uint32_t a = (c0 + 0x9E3779B9u * (uint32_t)(lane + 1)) * 0x85EBCA6Bu;
-    a ^= a >> 15;
-    if (BIG) {
-      uint32_t b = (c1 + 0x9E3779B9u * (uint32_t)(lane + 65)) * 0xC2B2AE35u;
-      a ^= b ^ (b >> 13);
-    }
-    uint32_t h = sk_wave_xor(a);
-    h = (h ^ (uint32_t)px) * 16777619u;
-    h = (h ^ (uint32_t)py) * 16777619u;
-    return h ^ (h >> 16);
-  }
   __device__ inline bool same(const SkCrates &o) const { return __ballot(c0 != o.c0 || (BIG && c1 != o.c1)) == 0; }
 };
 
