@@ -243,7 +243,6 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     n_order += __popcll(fb);
     const bool acc0 = doit & (d == 0);
     if (acc0) L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
-    mkl |= acc0 ? ((x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z)) : 0u;
     M3_TT(4);  // accept / claim / order / best
     // Successor in direction d (helper_3D._passable :214-319), branch-free on 6-bit windows of the columns: bit i of
     // a window = AIR at height z-2+i (below the floor and above the ceiling read as not-AIR, which is what every rule's
@@ -263,10 +262,6 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     const int tz = z + ((up | jup) ? 1 : 0) - ((down | jdown) ? 1 : 0);
     const int tq = jump ? qj : qn, tx = jump ? jx : nx, ty = jump ? jy : ny;
     const int tcell = tz * YX + tq;
-    // read set: this entry's column, the neighbour's and the landing's
-    rs |= doit ? ((1ull << qc) | (n_in ? 1ull << qn : 0ull) | (j_in ? 1ull << qj : 0ull)) : 0ull;
-    zlo = doit ? min(zlo, z) : zlo;
-    zhi = doit ? max(zhi, z) : zhi;
     M3_TT(5);  // move rules + read set
     // Never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it) --
     // but only while the queue is long: the check is one more dependent LDS round trip per trip, and with a short queue
@@ -299,6 +294,26 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
     M3_TT(6);  // prune read + push
   }
 #undef M3_TT
+  // Coordinate marks, read set and height range of the accepted cells (= L.order: every accepted entry belongs to one of
+  // them), after the loop instead of ~25 instructions in every trip: a cell's moves look at its own column, the four
+  // neighbour columns and the four landing columns two steps away.
+  for (int i = c.lane; i < n_order; i += 64) {
+    const int ci = L.order[i];
+    const int z = ci / YX, q = ci - z * YX, y = q / c.X, x = q - y * c.X;
+    mkl |= (x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z);
+    uint64_t m = 1ull << q;
+    m |= x + 1 < c.X ? 1ull << (q + 1) : 0ull;
+    m |= x + 2 < c.X ? 1ull << (q + 2) : 0ull;
+    m |= x >= 1 ? 1ull << (q - 1) : 0ull;
+    m |= x >= 2 ? 1ull << (q - 2) : 0ull;
+    m |= y + 1 < c.Y ? 1ull << (q + c.X) : 0ull;
+    m |= y + 2 < c.Y ? 1ull << (q + 2 * c.X) : 0ull;
+    m |= y >= 1 ? 1ull << (q - c.X) : 0ull;
+    m |= y >= 2 ? 1ull << (q - 2 * c.X) : 0ull;
+    rs |= m;
+    zlo = min(zlo, z);
+    zhi = max(zhi, z);
+  }
   mk = wave_or(mkl);
 #ifdef PCGRL_PHASE_TIMING
   if (c.lane == 0) {
