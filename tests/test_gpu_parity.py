@@ -1092,6 +1092,20 @@ def _solvable_rooms(n, seed, shape=(16, 16)):
     return g
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (12, 20), (20, 20), (30, 30), (32, 32)])
+def test_sokoban_solver_other_map_shapes_vs_oracle(shape):
+    """the device solver with its helper wavefronts behind the lanes-per-env families it supports (8 / 16 / 32 lanes per
+    env: a bordered level is at most 34 x 34):
+    playable rooms inside maps off the 16x16 point, one level per workgroup (pcgrl_stats_for_grids)"""
+    g = _solvable_rooms(96, 31 + shape[0], shape)
+    want = po.stats_for_grids("sokoban", g, solver_power=2000)
+    assert (want[:, 4] != 8192).mean() > 0.9 and (want[:, 5] > 0).mean() > 0.1, "the solver runs, some levels are solved"
+    env = _vec("sokoban", "narrow", shape, 4, solver_power=2000)
+    got = env.stats_for_grids(torch.as_tensor(g).to(env.device)).cpu().numpy()
+    assert np.array_equal(got, want)
+    env.check_errors()
+
+
 def test_loss_integer_and_float64_forms_agree():
     """get_loss has an integer form (all static targets integral: every stock problem) and the float64 form; a
     non-integral target on a zero-weighted statistic switches an engine to the float64 form without changing any reward."""
