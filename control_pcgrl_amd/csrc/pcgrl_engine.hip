@@ -141,8 +141,8 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
     if (c.representation != PCGRL_REP_NARROW)
       return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze: only the narrow representation is on the accelerated path");
     const int Z = c.dims[0], Y = c.dims[1], X = c.dims[2];
-    if (Z < 1 || Y < 1 || X < 1 || Z > 8 || Y * X > 63 || Z * Y * X > M3_MAXCELLS)
-      return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze: need Z <= 8, Y*X <= 63, Z*Y*X <= 512");
+    if (!m3_supported(Z, Y, X))
+      return fail(PCGRL_EUNSUPPORTED, "minecraft_3D_maze: need 1 <= Z, Y, X <= 16 (the reference's stock map is 15 x 15 x 15)");
     const int64_t cells = (int64_t)c.obs_window[0] * c.obs_window[1] * c.obs_window[2];
     if (cells < 1 || cells % 4) return fail(PCGRL_EUNSUPPORTED, "3-D obs_window volume must be a positive multiple of 4");
     lpe = 64;
@@ -499,8 +499,10 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     }                                                                                                \
   } while (0)
   if (is3d) {
-    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * M3_MAXW * sizeof(uint32_t)));  // [tile bits | path overlay bits]
-    CREATE_CHK(dalloc(&p.m3cache, (size_t)n_envs * M3_SLOTS * sizeof(M3Slot)));      // all slots invalid
+    const int n_slots = std::max(cfg->dims[0] - 2, 0);  // start planes z = 1 .. Z-2
+    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * m3_words(p.n_cells) * sizeof(uint32_t)));  // [tile bits | path overlay bits]
+    CREATE_CHK(dalloc(&p.m3cache, std::max<size_t>((size_t)n_envs * n_slots * m3_slot_words(p.n_cells) * sizeof(uint32_t), 16)));  // all slots invalid
+    CREATE_CHK(dalloc(&p.m3mv, (size_t)n_envs * p.n_cells * 4));
   } else
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
@@ -920,7 +922,7 @@ int pcgrl_poll_error(pcgrl_handle h) {
     HIPCHK(hipMemset(h->p.err, 0, sizeof(flags)));
     if (flags[0] & 1) return fail(PCGRL_EACTION, "an action was outside the action space (the reference raises IndexError)");
     if (flags[0] & 2) return fail(PCGRL_EUNSUPPORTED, "sokoban solver: level exceeds the device solver's limits");
-    if (flags[0] & 4) return fail(PCGRL_EUNSUPPORTED, "3-D maze path search: queue overflow (more than 1536 entries)");
+    if (flags[0] & 4) return fail(PCGRL_EUNSUPPORTED, "3-D maze path search: more live queue entries than the search ring holds (1024 for planes of <= 64 cells, else 4096); the statistics of that step were kept at their previous values");
     return fail(PCGRL_EINVAL, "device error flag set");
   }
   return PCGRL_OK;

@@ -3,6 +3,7 @@
 // Reference (paths relative to control_pcgrl/): envs/probs/minecraft/minecraft_3D_maze_prob.py:143-181 get_stats,
 // :84-93 process_observation; envs/helper_3D.py: _passable :214-319, _flood_fill :354-383, calc_num_regions :396-406,
 // run_dijkstra :422-490, calc_longest_path :503-563, remove_stacked_path_tiles :657-675; envs/pcgrl_env.py:267-342.
+// Map sizes: configs/config.py:153-157 (the stock 15 x 15 x 15) and BASELINE's 7 x 7 x 7.
 //
 // One workgroup per env.  pcgrl_step runs TWO specialised wavefronts over the env (like the 2-D step kernel):
 //   wave 0 "simulate"  action -> statistics (regions, path searches) -> reward / done -> auto-reset -> state write-back
@@ -10,10 +11,16 @@
 //                      path overlay of the PREVIOUS statistics update (pcgrl_env.py:298-299 vs :314-323), so it does
 //                      not depend on this step's searches.
 // Lane roles inside the simulate wave:
-//   lanes 0..Z-1   one z-plane each as a (Y*X)-bit mask: 6-neighbour flood fill = shifts by 1 / X inside the lane and a
-//                  DPP row_shr/row_shl between planes; start-candidate masks for the path search
+//   lanes 0..Z-1   one z-plane each as a (Y*X)-bit mask (1 or 4 64-bit words: size class SC): 6-neighbour flood fill =
+//                  shifts by 1 / X inside the lane and a DPP row_shr/row_shl between planes; start candidates
 //   lane 4*i + d   move direction d of queue entry i of the current trip of the path search (16 entries per trip)
-//   all 64 lanes   farthest-cell arg-max, overlay post-processing, reset RNG (LCG skip-ahead per lane)
+//   all 64 lanes   move-table maintenance, farthest-cell arg-max, overlay post-processing, reset RNG
+//
+// MOVE TABLE.  helper_3D._passable (:214-319) is a pure function of the map around a foothold: for every (cell, direction)
+// at most one of its six rules applies.  The engine keeps that function as a table in HBM (one byte per cell and
+// direction: path cost, height change, jump flag; 0 = no move) and MAINTAINS it: an edit of one cell can change the moves
+// of at most 48 (cell, direction) pairs -- the cells whose rules read the edited cell -- which 48 lanes re-evaluate at
+// once.  The path search then reads one byte per popped entry and direction instead of evaluating the rules.
 //
 // PATH SEARCH.  helper_3D.run_dijkstra is a FIFO label-correcting search whose pop order decides n_jump, the farthest
 // cell and the path drawn into the next observation, so the queue order is kept exactly (see m3_search).
@@ -21,10 +28,10 @@
 // SLOT CACHE.  calc_longest_path (:503-563) starts one pair of searches per start candidate, and its whole-plane visited
 // marking (:531) leaves at most ONE processed candidate per z-plane: the first candidate of the plane in (y, x) order.
 // Everything a plane's pair of searches produces -- the marks, max_dist, n_jump, the path tiles -- is a function of the
-// cells the searches READ.  The engine keeps, per env and plane, that result together with the read set (a superset: the
-// columns the move rules looked at and the range of heights, z-2 .. z+3 around every accepted cell) in HBM.  A step edits one cell: slots whose read set contains it are
-// dropped, every other slot is still exact, and the sequential candidate walk re-runs only the searches it actually
-// needs.  Under random edits most steps re-run no or one pair instead of all of them.
+// start cell and of the move-table rows of the cells the searches ACCEPTED (nothing else of the map is read).  The engine
+// keeps, per env and plane, that result together with the set of accepted cells in HBM.  A step edits one cell: a slot is
+// dropped iff a move-table byte of one of its accepted cells actually changed; every other slot is still exact, and the
+// sequential candidate walk re-runs only the searches it needs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -33,66 +40,102 @@
 
 namespace pcgrl {
 
-constexpr int M3_MAXCELLS = 512;
-constexpr int M3_MAXW = M3_MAXCELLS / 32;  // bit words
-constexpr int M3_ENT_CAP = 1536;           // queue entries per search (LDS)
+// size classes: SC 0 = planes of up to 64 cells, Z <= 8 (BASELINE's 7^3);  SC 1 = planes of up to 256 cells, Z <= 16 (15^3)
+template <int SC>
+struct M3C;
+template <>
+struct M3C<0> {
+  static constexpr int CELLS = 512, NW = 16, PW = 1, RING = 1024, COLS = 64, SLOTS = 6, ZMAX = 8;
+};
+template <>
+struct M3C<1> {
+  static constexpr int CELLS = 4096, NW = 128, PW = 4, RING = 4096, COLS = 256, SLOTS = 14, ZMAX = 16;
+};
 constexpr int M3_NS = 3;
-constexpr int M3_SLOTS = 6;                // start planes z = 1 .. Z-2 (Z <= 8)
+constexpr int M3_SLOT_HDR = 4;  // header words of a cached slot in HBM, followed by the accepted-cell set and the path tiles
 
-// cached result of one start plane (see SLOT CACHE)
-struct alignas(8) M3Slot {
-  uint8_t start;   // bit index (y*X + x) of the start cell in its plane
-  uint8_t valid;
-  uint16_t max_dist;
-  uint16_t n_jump;
-  uint8_t mk;      // z-planes marked visited by the first search (the fancy-index bug, :531)
-  uint8_t zr;      // read set, heights: lowest | highest << 4 plane the move rules looked at
-  uint32_t rs[2];  // read set, columns: bit q = the searches looked at column q = y*X + x
-  uint32_t pathm[M3_MAXW];  // tiles of paths[farthest] of the second search
-};
-static_assert(sizeof(M3Slot) == 80, "slot layout");
-constexpr int M3_SLOT_WORDS = (int)(sizeof(M3Slot) / 4) * M3_SLOTS;
-
-struct M3Lds {
-  uint2 ent[M3_ENT_CAP];        // cell | kind<<9 | njump<<12 | parent<<20 ; len | x<<12 | y<<18 | z<<24 | direction<<28
-  uint32_t best[M3_MAXCELLS];   // per cell: epoch<<24 | len<<12 | accepted entry id (the `paths` dict of the current search)
-  uint16_t order[M3_MAXCELLS];  // cells in first-insertion order
-  uint32_t claim[M3_MAXCELLS];  // scratch of m3_search: lowest trip slot popping a cell (0xFFFFFFFF between trips)
-  uint32_t dirt[M3_MAXW + 2];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
-  uint32_t pathm[M3_MAXW + 2];  // tiles of the best path
-  uint32_t over[M3_MAXW + 2];   // overlay mask (transposed index) for the observation
-  uint8_t col[64];              // per (y,x): AIR bits over z
-  M3Slot slot[M3_SLOTS];
-  uint32_t epoch;               // current search id in `best`
-#ifdef PCGRL_PHASE_TIMING
-  uint32_t dbg[8];              // development counters: trips, queue entries, searches, cycles of search 1 / farthest / search 2 / chain walk
-#endif
-};
-struct M3ObsLds {  // the observe wave's own copy
-  uint32_t dirt[M3_MAXW + 2];
-  uint32_t over[M3_MAXW + 2];
-};
-
-struct M3Ctx {
-  int lane, Z, Y, X, n_cells, nw;
-};
-
-enum { M3_WALK = 0, M3_DOWN = 1, M3_UP = 2, M3_JFLAT = 3, M3_JUP = 4, M3_JDOWN = 5, M3_ROOT = 6 };
-constexpr uint32_t M3_NOPARENT = 0xFFFu;
-
-__device__ inline bool m3_bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
-
-// (Y*X)-bit AIR mask of plane z from the flat bit string
-__device__ inline uint64_t m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int z) {
-  const int pbits = c.Y * c.X, b0 = z * pbits;
-  const int w = b0 >> 5, s = b0 & 31;
-  uint64_t lo = (uint64_t)dirt[w] | ((uint64_t)dirt[w + 1] << 32);
-  uint64_t v = lo >> s;
-  if (s) v |= (uint64_t)dirt[w + 2] << (64 - s);
-  const uint64_t pm = pbits >= 64 ? ~0ull : ((1ull << pbits) - 1ull);
-  return ~v & pm;
+__host__ __device__ inline int m3_size_class(int Z, int Y, int X) { return (Z <= 8 && Y * X <= 64 && Z * Y * X <= 512) ? 0 : 1; }
+__host__ __device__ inline bool m3_supported(int Z, int Y, int X) {
+  return Z >= 1 && Y >= 1 && X >= 1 && Z <= 16 && Y <= 16 && X <= 16 && Y * X <= 256 && Z * Y * X <= 4096;
 }
+// words of one per-cell bit string of an env in HBM (even, so that 64-bit accesses stay aligned)
+__host__ __device__ inline int m3_words(int n_cells) { return (((n_cells + 31) >> 5) + 1) & ~1; }
+__host__ __device__ inline int m3_slot_words(int n_cells) { return M3_SLOT_HDR + 2 * m3_words(n_cells); }
 
+// ---------------------------------------------------------------------------------------------- plane masks
+template <int PW>
+struct PM {
+  uint64_t w[PW];
+};
+template <int PW>
+__device__ inline PM<PW> pm_zero() {
+  PM<PW> r;
+#pragma unroll
+  for (int i = 0; i < PW; i++) r.w[i] = 0;
+  return r;
+}
+template <int PW>
+__device__ inline PM<PW> operator&(PM<PW> a, PM<PW> b) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) a.w[i] &= b.w[i];
+  return a;
+}
+template <int PW>
+__device__ inline PM<PW> operator|(PM<PW> a, PM<PW> b) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) a.w[i] |= b.w[i];
+  return a;
+}
+template <int PW>
+__device__ inline PM<PW> operator~(PM<PW> a) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) a.w[i] = ~a.w[i];
+  return a;
+}
+template <int PW>
+__device__ inline bool pm_any(PM<PW> a) {
+  uint64_t o = 0;
+#pragma unroll
+  for (int i = 0; i < PW; i++) o |= a.w[i];
+  return o != 0;
+}
+template <int PW>
+__device__ inline PM<PW> pm_shl(PM<PW> a, int s) {  // 0 < s < 64
+  PM<PW> r;
+#pragma unroll
+  for (int i = PW - 1; i >= 0; i--) r.w[i] = (a.w[i] << s) | (i > 0 ? a.w[i - 1] >> (64 - s) : 0ull);
+  return r;
+}
+template <int PW>
+__device__ inline PM<PW> pm_shr(PM<PW> a, int s) {
+  PM<PW> r;
+#pragma unroll
+  for (int i = 0; i < PW; i++) r.w[i] = (a.w[i] >> s) | (i + 1 < PW ? a.w[i + 1] << (64 - s) : 0ull);
+  return r;
+}
+template <int PW>
+__device__ inline PM<PW> pm_lowest(PM<PW> a) {  // isolate the lowest set bit
+  PM<PW> r = pm_zero<PW>();
+  bool done = false;
+#pragma unroll
+  for (int i = 0; i < PW; i++) {
+    r.w[i] = done ? 0ull : (a.w[i] & (0ull - a.w[i]));
+    done = done || a.w[i] != 0;
+  }
+  return r;
+}
+template <int PW>
+__device__ inline int pm_ctz(PM<PW> a) {  // index of the lowest set bit (64 * PW if none)
+  int r = 64 * PW;
+#pragma unroll
+  for (int i = PW - 1; i >= 0; i--) r = a.w[i] ? 64 * i + __builtin_ctzll(a.w[i]) : r;
+  return r;
+}
+template <int PW>
+__device__ inline void pm_set(PM<PW> &a, int q) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) a.w[i] |= (q >> 6) == i ? 1ull << (q & 63) : 0ull;
+}
 __device__ inline uint64_t dpp64_up(uint64_t v) {  // from lane-1 (0 into lane 0 of a DPP row)
   uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x111, 0xF, 0xF, true);
   uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x111, 0xF, 0xF, true);
@@ -102,6 +145,18 @@ __device__ inline uint64_t dpp64_down(uint64_t v) {  // from lane+1
   uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x101, 0xF, 0xF, true);
   uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x101, 0xF, 0xF, true);
   return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+template <int PW>
+__device__ inline PM<PW> pm_up(PM<PW> a) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) a.w[i] = dpp64_up(a.w[i]);
+  return a;
+}
+template <int PW>
+__device__ inline PM<PW> pm_down(PM<PW> a) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) a.w[i] = dpp64_down(a.w[i]);
+  return a;
 }
 
 // maximum over the 64 lanes (result uniform): DPP butterfly inside the 16-lane rows, the four rows through SGPRs
@@ -123,74 +178,257 @@ __device__ inline uint32_t wave_or(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
          (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
-// helper_3D.py:396-406 calc_num_regions (6-neighbour components of AIR)
-__device__ inline int m3_regions(const M3Ctx &c, uint64_t air) {
-  uint64_t notx0 = 0, notxl = 0;  // plane bits whose x is not 0 / not X-1
-  for (int y = 0; y < c.Y; y++) {
-    uint64_t rowm = ((1ull << c.X) - 1ull) << (y * c.X);
-    notx0 |= rowm & ~(1ull << (y * c.X));
-    notxl |= rowm & ~(1ull << (y * c.X + c.X - 1));
+
+// ---------------------------------------------------------------------------------------------- LDS
+// cached result of one start plane (see SLOT CACHE); in HBM: 4 header words + racc + pathm, m3_words(n_cells) each
+struct M3SlotHdr {
+  uint16_t start;   // bit index (y*X + x) of the start cell in its plane
+  uint16_t valid;
+  uint16_t max_dist;
+  uint16_t n_jump;
+  uint32_t mk;      // z-planes marked visited by the first search (the fancy-index bug, :531)
+  uint32_t pad_;
+};
+static_assert(sizeof(M3SlotHdr) == 4 * M3_SLOT_HDR, "slot header layout");
+
+// workspace of one search wave
+template <int SC>
+struct M3Work {
+  uint2 ent[M3C<SC>::RING];         // queue ring: cell | njump<<12 | move byte<<24 | direction<<30 ; len
+  uint2 best[M3C<SC>::CELLS];       // per cell: epoch<<24 | len of the accepted path (the `paths` dict) ; trip claim
+  uint32_t info[M3C<SC>::CELLS];    // per cell, of the accepted entry: njump | move byte<<12 | direction<<18
+  uint16_t order[M3C<SC>::CELLS];   // cells in first-insertion order
+  uint32_t racc[M3C<SC>::NW];       // accepted cells of the pair of searches being run (bit per cell)
+  uint32_t pathm[M3C<SC>::NW];      // path tiles of the pair being run
+};
+// the env
+template <int SC>
+struct M3Env {
+  uint32_t dirt[M3C<SC>::NW + 4];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
+  uint32_t pathm[M3C<SC>::NW + 4];  // tiles of the best path
+  uint32_t over[M3C<SC>::NW + 4];   // overlay mask (transposed index) for the observation
+  uint16_t col[M3C<SC>::COLS];      // per (y,x): AIR bits over z
+  alignas(16) uint8_t mv[M3C<SC>::CELLS * 4];  // move table, [cell][direction]
+  M3SlotHdr hdr[M3C<SC>::SLOTS];
+  uint32_t sracc[M3C<SC>::SLOTS][M3C<SC>::NW];
+  uint32_t spath[M3C<SC>::SLOTS][M3C<SC>::NW];
+#ifdef PCGRL_PHASE_TIMING
+  uint32_t dbg[8];                  // development counters: trips, queue entries, searches, cycles ...
+#endif
+};
+template <int SC>
+struct M3ObsLds {  // the observe wave's own copy
+  uint32_t dirt[M3C<SC>::NW + 4];
+  uint32_t over[M3C<SC>::NW + 4];
+};
+
+struct M3Ctx {
+  int lane, Z, Y, X, YX, n_cells, nw;  // nw = m3_words(n_cells)
+};
+
+__device__ inline bool m3_bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+__device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+
+// (Y*X)-bit AIR mask of plane z from the flat bit string (the arrays carry 4 spare zero words at the end)
+template <int PW>
+__device__ inline PM<PW> m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int z) {
+  PM<PW> r;
+  const int b0 = z * c.YX;
+#pragma unroll
+  for (int k = 0; k < PW; k++) {
+    const int b = b0 + 64 * k, w = b >> 5, s = b & 31;
+    const int lim = c.nw + 1;  // (words read stay inside the array)
+    const uint64_t lo = (uint64_t)dirt[min(w, lim)] | ((uint64_t)dirt[min(w + 1, lim)] << 32);
+    uint64_t v = lo >> s;
+    if (s) v |= (uint64_t)dirt[min(w + 2, lim)] << (64 - s);
+    const int left = c.YX - 64 * k;  // plane bits in this word and beyond
+    const uint64_t pm = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
+    r.w[k] = ~v & pm;
   }
-  uint64_t remaining = c.lane < c.Z ? air : 0ull;
+  return r;
+}
+
+// bits [start, start + len) of a plane mask, len < 64
+template <int PW>
+__device__ inline void pm_set_range(PM<PW> &a, int start, int len) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) {
+    const int lo = start - 64 * i, hi = lo + len;  // range in this word's coordinates
+    const int l = lo < 0 ? 0 : lo, h = hi > 64 ? 64 : hi;
+    if (l < h) a.w[i] |= (h - l >= 64 ? ~0ull : ((1ull << (h - l)) - 1ull)) << l;
+  }
+}
+// plane bits whose x is not 0 / not X-1
+template <int PW>
+__device__ inline void m3_edge_masks(const M3Ctx &c, PM<PW> &notx0, PM<PW> &notxl) {
+  notx0 = pm_zero<PW>();
+  notxl = pm_zero<PW>();
+  for (int y = 0; y < c.Y; y++) {
+    pm_set_range(notx0, y * c.X + 1, c.X - 1);
+    pm_set_range(notxl, y * c.X, c.X - 1);
+  }
+}
+
+// helper_3D.py:396-406 calc_num_regions (6-neighbour components of AIR)
+template <int PW>
+__device__ inline int m3_regions(const M3Ctx &c, PM<PW> air, PM<PW> notx0, PM<PW> notxl) {
+  PM<PW> remaining = c.lane < c.Z ? air : pm_zero<PW>();
   int n = 0;
+  auto grow = [&](PM<PW> f) {
+    return pm_shl(f & notxl, 1) | pm_shr(f & notx0, 1) | pm_shl(f, c.X) | pm_shr(f, c.X) | pm_up(f) | pm_down(f);
+  };
   while (true) {
-    uint64_t b = __ballot(remaining != 0);
+    uint64_t b = __ballot(pm_any(remaining));
     if (b == 0) break;
     int fl = __builtin_ctzll(b);
-    uint64_t f = c.lane == fl ? (remaining & (0ull - remaining)) : 0ull;
+    PM<PW> f = c.lane == fl ? pm_lowest(remaining) : pm_zero<PW>();
     while (true) {  // two expansion rounds per trip (one ballot per two rounds)
-      uint64_t d = ((f & notxl) << 1) | ((f & notx0) >> 1) | (f << c.X) | (f >> c.X) | dpp64_up(f) | dpp64_down(f);
-      f |= d & remaining;
-      d = ((f & notxl) << 1) | ((f & notx0) >> 1) | (f << c.X) | (f >> c.X) | dpp64_up(f) | dpp64_down(f);
-      const uint64_t nf = d & remaining & ~f;
-      if (__ballot(nf != 0) == 0) break;
-      f |= nf;
+      f = f | (grow(f) & remaining);
+      const PM<PW> nf = grow(f) & remaining & ~f;
+      if (__ballot(pm_any(nf)) == 0) break;
+      f = f | nf;
     }
-    remaining &= ~f;
+    remaining = remaining & ~f;
     n++;
   }
   return n;
 }
 
-__device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+// ---------------------------------------------------------------------------------------------- move table
+// helper_3D._passable (:214-319) for one (foothold, direction), branch-free on 6-bit windows of the column masks: bit i of a
+// window = AIR at height z-2+i (below the floor and above the ceiling read as not-AIR, which is what every rule's explicit
+// bounds check amounts to).  cc / cn / cj: AIR bits over z of the foothold's column, the neighbour column and the column
+// two steps away (n_in / j_in: inside the map).  The six rules are mutually exclusive.
+// Result: path cost (1..3) | (height change + 1) << 2 | jump << 4;  0 = no move in this direction.
+__device__ inline uint32_t m3_move(uint32_t cc, uint32_t cn, uint32_t cj, int z, bool n_in, bool j_in) {
+  const uint32_t wn = ((cn << 2) >> z) & 0x3Fu, wj = ((cj << 2) >> z) & 0x3Fu, c4 = (cc >> (z + 2)) & 1u;
+  // (bitwise on purpose: `&&` / `||` compile to exec-masked branches, these to mask arithmetic)
+  const bool walk = (wn & 0x0Eu) == 0x0Cu;                                   // stands at z: !n[z-1], n[z], n[z+1]
+  const bool down = (z >= 1) & ((wn & 0x0Fu) == 0x0Eu);                      // stands at z-1: !n[z-2], n[z-1], n[z], n[z+1]
+  const bool up = ((wn & 0x1Cu) == 0x18u) & (c4 != 0u);                      // stands at z+1: !n[z], n[z+1], n[z+2], own z+2 free
+  const bool gap = (z >= 2) & ((wn & 0x1Fu) == 0x1Fu) & (c4 != 0u) & j_in;   // n[z-2..z+2] all AIR: a gap to jump over
+  const bool jflat = gap & ((wj & 0x1Eu) == 0x1Cu);                          // !j[z-1], j[z], j[z+1], j[z+2]
+  const bool jup = gap & ((wj & 0x3Cu) == 0x38u);                            // !j[z], j[z+1], j[z+2], j[z+3]
+  const bool jdown = gap & ((wj & 0x0Fu) == 0x0Eu);                          // !j[z-2], j[z-1], j[z], j[z+1]
+  const bool jump = jflat | jup | jdown;
+  const bool ok = n_in & (walk | down | up | jump);
+  const uint32_t w = walk ? 1u : ((jup | jdown) ? 3u : 2u);
+  const uint32_t dzp = 1u + ((up | jup) ? 1u : 0u) - ((down | jdown) ? 1u : 0u);
+  return ok ? (w | (dzp << 2) | (jump ? 16u : 0u)) : 0u;
+}
+__device__ inline int m3_dx(int d) { return d == 0 ? 1 : (d == 2 ? -1 : 0); }  // helper_3D.py:220 direction order
+__device__ inline int m3_dy(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }
 
-// One search of helper_3D.run_dijkstra from (sx,sy,sz).  Uniform over the wave; returns the number of queue entries.
-// On overflow of the LDS queue sets `overflow`.
+// move byte of (x, y, z, d) from the column masks
+template <int SC>
+__device__ inline uint32_t m3_move_at(const M3Env<SC> &E, const M3Ctx &c, int x, int y, int z, int d) {
+  const int dx = m3_dx(d), dy = m3_dy(d);
+  const int nx = x + dx, ny = y + dy, jx = nx + dx, jy = ny + dy;
+  const bool n_in = ((unsigned)nx < (unsigned)c.X) & ((unsigned)ny < (unsigned)c.Y);
+  const bool j_in = ((unsigned)jx < (unsigned)c.X) & ((unsigned)jy < (unsigned)c.Y);
+  const int q = y * c.X + x, dq = dy * c.X + dx;
+  const uint32_t cc = E.col[q], cn = E.col[n_in ? q + dq : 0], cj = E.col[j_in ? q + 2 * dq : 0];
+  return m3_move(cc, cn, cj, z, n_in, j_in);
+}
+
+// per-(y,x) column masks from the planes: lane q of pass k collects bit q of every plane
+template <int SC>
+__device__ inline void m3_build_cols(M3Env<SC> &E, const M3Ctx &c, PM<M3C<SC>::PW> air) {
+  constexpr int PW = M3C<SC>::PW;
+#pragma unroll
+  for (int k = 0; k < PW; k++) {
+    uint32_t m = 0;
+    for (int z = 0; z < c.Z; z++) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)air.w[k], z);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(air.w[k] >> 32), z);
+      const uint64_t a = (uint64_t)lo | ((uint64_t)hi << 32);
+      m |= (uint32_t)((a >> c.lane) & 1ull) << z;
+    }
+    const int q = 64 * k + c.lane;
+    if (q < M3C<SC>::COLS) E.col[q] = q < c.YX ? (uint16_t)m : (uint16_t)0;
+  }
+}
+
+// the whole table from the column masks (reset, injected maps)
+template <int SC>
+__device__ inline void m3_build_moves(M3Env<SC> &E, const M3Ctx &c) {
+  for (int i = c.lane; i < c.n_cells * 4; i += 64) {
+    const int cell = i >> 2, d = i & 3;
+    const int z = cell / c.YX, q = cell - z * c.YX, y = q / c.X, x = q - y * c.X;
+    E.mv[i] = (uint8_t)m3_move_at(E, c, x, y, z, d);
+  }
+}
+
+// After the edit of cell (ex, ey, ez) (E.col already updated): re-evaluate the <= 48 (cell, direction) pairs whose rules
+// read that cell, and drop the cached slots that accepted a cell whose move changed.  gmv: the table in HBM (or null).
+// Returns the mask of the slots it dropped.
+template <int SC>
+__device__ inline uint32_t m3_update_moves(M3Env<SC> &E, const M3Ctx &c, int ex, int ey, int ez, uint8_t *gmv, int n_slots) {
+  // lane -> (direction, source cell): 0..3 the cell two below (own column at z+2); 4..23 the four neighbours at heights
+  // ez-2..ez+2 (window of the neighbour column); 24..47 the cells two steps away at heights ez-3..ez+2 (landing window)
+  const int L = c.lane;
+  const int d = L & 3;
+  const int grp = L < 4 ? 0 : (L < 24 ? 1 : 2);
+  const int k = grp == 0 ? 0 : (grp == 1 ? (L - 4) >> 2 : (L - 24) >> 2);
+  const int sx = ex - grp * m3_dx(d), sy = ey - grp * m3_dy(d);
+  const int sz = grp == 0 ? ez - 2 : (grp == 1 ? ez - 2 + k : ez - 3 + k);
+  const bool in = (L < 48) & ((unsigned)sx < (unsigned)c.X) & ((unsigned)sy < (unsigned)c.Y) & ((unsigned)sz < (unsigned)c.Z);
+  const int cell = in ? m3_cell(c, sx, sy, sz) : 0;
+  const uint32_t nw_ = m3_move_at(E, c, in ? sx : 0, in ? sy : 0, in ? sz : 0, d);
+  const uint32_t old = E.mv[cell * 4 + d];
+  const bool chg = in & (nw_ != old);
+  if (chg) {
+    E.mv[cell * 4 + d] = (uint8_t)nw_;
+    if (gmv) gmv[cell * 4 + d] = (uint8_t)nw_;
+  }
+  uint32_t dropped = 0;
+  if (__ballot(chg) != 0) {
+    for (int s = 0; s < n_slots; s++) {
+      if (__builtin_amdgcn_readfirstlane((int)E.hdr[s].valid) == 0) continue;
+      const bool hit = chg && m3_bit(E.sracc[s], cell);
+      if (__ballot(hit) != 0) {
+        if (c.lane == 0) E.hdr[s].valid = 0;
+        dropped |= 1u << s;
+      }
+    }
+  }
+  return dropped;
+}
+
+// ---------------------------------------------------------------------------------------------- path search
+// One search of helper_3D.run_dijkstra from `root`.  Uniform over the wave; returns the number of accepted cells
+// (W.order).  `overflow`: more than RING live queue entries.
 //
 // The reference pops one queue entry at a time.  Here up to 16 consecutive entries are taken per trip, lane 4*i + d
 // working on direction d of entry i, which is exact because:
-//   * whether entry i is accepted (:437-445) depends on earlier entries only through `best` of ITS OWN cell.  Every
-//     popped entry registers its trip slot for its cell (an LDS min issued BEFORE the reads of the trip, so one round trip
-//     returns `best`, the columns and the first slot of the cell together); the trip is cut before an accept candidate
-//     that is not the first entry of its cell in the trip (rare), which then runs first in the next trip;
-//   * a successor is queued unless it is known to be a no-op when popped (cell without head-room, or `best` of its cell --
-//     as read at the start of the trip: `best` only decreases -- not longer).  Entries that turn out to be no-ops later are
-//     rejected when popped, like in the reference;
+//   * whether entry i is accepted (:437-440) depends on earlier entries only through `best` of ITS OWN cell.  Every
+//     popped entry registers (trip, slot) for its cell with an LDS min issued BEFORE the reads of the trip -- later trips
+//     have smaller stamps, so nothing is ever reset -- and one round trip returns `best`, the first slot of the cell and
+//     the move byte together; the trip is cut before an accept candidate that is not the first entry of its cell in the
+//     trip (rare), which then runs first in the next trip;
+//   * the head-room test of :443-445 never fails here: every rule of _passable checks the head-room of its target, and
+//     the start cells have it;
+//   * a successor is queued unless it is known to be a no-op when popped (`best` of its cell -- as read in this trip:
+//     `best` only decreases -- not longer); while the queue is short the check is skipped (it is one more dependent LDS
+//     round trip per trip) and such entries are rejected when popped, like in the reference;
 //   * first-visit order and queue order are kept with prefix counts over the lanes (entry-major, direction-minor).
 // `best` entries carry the search's epoch, so nothing is cleared between searches.
-// mk: coordinate values of all reached cells (bit v set if some reached cell has x, y or z == v);  rs: read set (one bit
-// per column) accumulated PER LANE for the slot cache (the caller ORs the lanes together).
-__device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz, int &n_order, uint32_t &mk, uint64_t &rs,
-                                int &zlo, int &zhi, bool &overflow) {
-  constexpr uint32_t NONE = 0xFFFFFFFFu;
-  uint32_t epoch = L.epoch + 1;  // (uniform: every lane reads the same word)
-  if (epoch > 255u) {            // wrapped: clear the table once
-    for (int i = c.lane; i < c.n_cells; i += 64) L.best[i] = 0;
+template <int SC>
+__device__ inline int m3_search(M3Work<SC> &W, const uint8_t *mv, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip,
+                                bool &overflow PHASE_ARG) {
+  constexpr int RING = M3C<SC>::RING, RM = RING - 1;
+  epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch) + 1u;
+  if (epoch > 255u) {  // wrapped: clear the table once
+    for (int i = c.lane; i < c.n_cells; i += 64) W.best[i].x = 0;
     epoch = 1;
   }
-  if (c.lane == 0) {
-    L.epoch = epoch;
-    L.ent[0] = make_uint2((uint32_t)m3_cell(c, sx, sy, sz) | ((uint32_t)M3_ROOT << 9) | (M3_NOPARENT << 20),
-                          1u | ((uint32_t)sx << 12) | ((uint32_t)sy << 18) | ((uint32_t)sz << 24));
-  }
-  int head = 0, tail = 1;
-  n_order = 0;
+  if (c.lane == 0) W.ent[0] = make_uint2((uint32_t)root, 1u);
+  int head = 0, tail = 1, n_order = 0;
   const int slot_i = c.lane >> 2, d = c.lane & 3;
-  const int dxl = d == 0 ? 1 : (d == 2 ? -1 : 0), dyl = d == 1 ? 1 : (d == 3 ? -1 : 0);  // helper_3D.py:220
-  const int dq = dyl * c.X + dxl;  // column-index step of this lane's direction
-  const uint64_t lt = (1ull << c.lane) - 1ull;
-  const int YX = c.Y * c.X;
-  uint32_t mkl = 0;
+  const int dq = m3_dy(d) * c.X + m3_dx(d);  // column-index step of this lane's direction
+  const uint32_t lt_lo = c.lane < 32 ? (1u << c.lane) - 1u : 0xFFFFFFFFu, lt_hi = c.lane < 32 ? 0u : (1u << (c.lane - 32)) - 1u;
+  auto below = [&](uint64_t b) { return __popc((uint32_t)b & lt_lo) + __popc((uint32_t)(b >> 32) & lt_hi); };
+  const uint32_t ep24 = epoch << 24;
 #ifdef PCGRL_PHASE_TIMING
   int dbg_trips = 0;
 #endif
@@ -198,281 +436,209 @@ __device__ inline int m3_search(M3Lds &L, const M3Ctx &c, int sx, int sy, int sz
 #ifdef PCGRL_PHASE_TIMING
     dbg_trips++;
 #endif
-#ifdef PCGRL_PHASE_TIMING
-    uint64_t tt0_ = __builtin_readcyclecounter();
-#define M3_TT(i)                                                    \
-  do {                                                              \
-    uint64_t tt1_ = __builtin_readcyclecounter();                   \
-    if (c.lane == 0) L.dbg[i] += (uint32_t)(tt1_ - tt0_);           \
-    tt0_ = tt1_;                                                    \
-  } while (0)
-#else
-#define M3_TT(i) \
-  do {           \
-  } while (0)
-#endif
+    trip = (uint32_t)__builtin_amdgcn_readfirstlane((int)trip) + 1u;
+    head = __builtin_amdgcn_readfirstlane(head);
+    tail = __builtin_amdgcn_readfirstlane(tail);
     const int nb = min(16, tail - head);
     const bool live = slot_i < nb;
     const int id = head + (live ? slot_i : 0);
-    const uint2 e = L.ent[id];
-    const int ci = e.x & 511, nj = (e.x >> 12) & 255, len = (int)(e.y & 0xFFFu);
-    const int x = (e.y >> 12) & 63, y = (e.y >> 18) & 63, z = (int)((e.y >> 24) & 15u);
-    if (live && d == 0) atomicMin(&L.claim[ci], (uint32_t)slot_i);
-    // everything that depends only on the entry comes back in one LDS round trip: `best` and first slot of its cell, its
-    // column and the columns of this lane's neighbour and jump landing (column 0 stands in for cells outside the map)
-    const int nx = x + dxl, ny = y + dyl, jx = nx + dxl, jy = ny + dyl;
-    const bool n_in = ((unsigned)nx < (unsigned)c.X) & ((unsigned)ny < (unsigned)c.Y);
-    const bool j_in = ((unsigned)jx < (unsigned)c.X) & ((unsigned)jy < (unsigned)c.Y);
-    const int qc = ci - z * YX, qn = n_in ? qc + dq : 0, qj = j_in ? qc + 2 * dq : 0;
-    const uint32_t b = L.best[ci];
-    const uint32_t first_slot = L.claim[ci];
-    const uint32_t cc = L.col[qc], cn = L.col[qn], cj = L.col[qj];
-    const bool seen = (b >> 24) == epoch;
-    M3_TT(3);  // entry read + second round of reads issued (wait happens at first use)
-    // :437-440 (an entry that is not shorter is dropped) and :443-445 (no head-room); cells >= Z read as not-AIR
-    // (bitwise on purpose, here and below: `&&` / `||` compile to exec-masked branches, these to mask arithmetic)
-    const bool accept = live & !(seen & ((int)((b >> 12) & 0xFFFu) <= len)) & (((cc >> (z + 1)) & 1u) != 0u);
+    const uint2 e = W.ent[id & RM];
+    const int cell = (int)(e.x & 0xFFFu);
+    const uint32_t len = e.y;
+    const uint32_t stamp = ((0x0FFFFFFFu - trip) << 4) | (uint32_t)slot_i;
+    if (live && d == 0) atomicMin(&W.best[cell].y, stamp);
+    const uint2 b = W.best[cell];
+    const uint32_t m = mv[cell * 4 + d];
+    const bool seen = (b.x >> 24) == epoch;
+    // :437-440 (an entry that is not shorter is dropped)
+    const bool accept = live & !(seen & ((b.x & 0xFFFFFFu) <= len));
     // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
-    const uint64_t dupb = __ballot(accept & (d == 0) & (first_slot != (uint32_t)slot_i));
+    const uint64_t dupb = __ballot(accept & (d == 0) & (b.y != stamp));
     const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
-    if (live && d == 0) L.claim[ci] = NONE;
     const bool doit = accept & (slot_i < nproc);
-    const bool first = doit & (d == 0) & !seen;
-    const uint64_t fb = __ballot(first);
-    if (first) L.order[n_order + __popcll(fb & lt)] = (uint16_t)ci;
-    n_order += __popcll(fb);
     const bool acc0 = doit & (d == 0);
-    if (acc0) L.best[ci] = (epoch << 24) | ((uint32_t)len << 12) | (uint32_t)id;
-    M3_TT(4);  // accept / claim / order / best
-    // Successor in direction d (helper_3D._passable :214-319), branch-free on 6-bit windows of the columns: bit i of
-    // a window = AIR at height z-2+i (below the floor and above the ceiling read as not-AIR, which is what every rule's
-    // explicit bounds check amounts to).  The six rules are mutually exclusive.
-    const uint32_t wn = ((cn << 2) >> z) & 0x3Fu, wj = ((cj << 2) >> z) & 0x3Fu, c4 = (cc >> (z + 2)) & 1u;
-    const bool walk = (wn & 0x0Eu) == 0x0Cu;                      // stands at z: !n[z-1], n[z], n[z+1]
-    const bool down = (z >= 1) & ((wn & 0x0Fu) == 0x0Eu);            // stands at z-1: !n[z-2], n[z-1], n[z], n[z+1]
-    const bool up = ((wn & 0x1Cu) == 0x18u) & (c4 != 0u);                  // stands at z+1: !n[z], n[z+1], n[z+2], own z+2 free
-    const bool gap = (z >= 2) & ((wn & 0x1Fu) == 0x1Fu) & (c4 != 0u) & j_in;  // n[z-2..z+2] all AIR: a gap to jump over
-    const bool jflat = gap & ((wj & 0x1Eu) == 0x1Cu);              // !j[z-1], j[z], j[z+1], j[z+2]
-    const bool jup = gap & ((wj & 0x3Cu) == 0x38u);                // !j[z], j[z+1], j[z+2], j[z+3]
-    const bool jdown = gap & ((wj & 0x0Fu) == 0x0Eu);              // !j[z-2], j[z-1], j[z], j[z+1]
-    const bool jump = jflat | jup | jdown;
-    bool ok = doit & n_in & (walk | down | up | jump);
-    const int kind = walk ? M3_WALK : (down ? M3_DOWN : (up ? M3_UP : (jflat ? M3_JFLAT : (jup ? M3_JUP : M3_JDOWN))));
-    const int add = walk ? 1 : ((jup | jdown) ? 3 : 2);
-    const int tz = z + ((up | jup) ? 1 : 0) - ((down | jdown) ? 1 : 0);
-    const int tq = jump ? qj : qn, tx = jump ? jx : nx, ty = jump ? jy : ny;
-    const int tcell = tz * YX + tq;
-    M3_TT(5);  // move rules + read set
-    // Never queue what is known to be a no-op when popped (the target always has head-room: every rule checks it) --
-    // but only while the queue is long: the check is one more dependent LDS round trip per trip, and with a short queue
-    // (corridors: the searches that make a launch wait) the few useless entries are dropped for free when popped.
-    auto prune = [&]() {
-      const uint32_t bt = L.best[ok ? tcell : 0];
-      ok &= !(((bt >> 24) == epoch) & ((int)((bt >> 12) & 0xFFFu) <= len + add));
-    };
-    const bool lazy = tail - head <= 32;
-    if (!lazy) prune();
-    uint64_t okb = __ballot(ok);
-    int npush = __popcll(okb);
-    if (tail + npush > M3_ENT_CAP) {
-      if (lazy) {  // (never an overflow that the check would have avoided)
-        prune();
-        okb = __ballot(ok);
-        npush = __popcll(okb);
-      }
-      if (tail + npush > M3_ENT_CAP) {
-        overflow = true;
-        break;
-      }
+    const bool first = acc0 & !seen;
+    const uint64_t fb = __ballot(first);
+    if (first) W.order[n_order + below(fb)] = (uint16_t)cell;
+    n_order += __popcll(fb);
+    if (acc0) {
+      W.best[cell].x = ep24 | len;
+      W.info[cell] = e.x >> 12;
+    }
+    // successor in direction d: one byte of the move table
+    const uint32_t jump = (m >> 4) & 1u;
+    const int tcell = cell + dq + (jump ? dq : 0) + ((int)((m >> 2) & 3u) - 1) * c.YX;
+    const uint32_t tlen = len + (m & 3u);
+    bool ok = doit & (m != 0u);
+    if (tail - head > 32) {  // never queue what is known to be a no-op when popped
+      const uint32_t bt = W.best[ok ? tcell : 0].x;
+      ok &= !(((bt >> 24) == epoch) & ((bt & 0xFFFFFFu) <= tlen));
+    }
+    const uint64_t okb = __ballot(ok);
+    const int npush = __popcll(okb);
+    if (tail + npush - head > RING) {
+      overflow = true;
+      break;
     }
     if (ok)
-      L.ent[tail + __popcll(okb & lt)] =
-          make_uint2((uint32_t)tcell | ((uint32_t)kind << 9) | ((uint32_t)(nj + (jump ? 1 : 0)) << 12) | ((uint32_t)id << 20),
-                     (uint32_t)(len + add) | ((uint32_t)tx << 12) | ((uint32_t)ty << 18) | ((uint32_t)tz << 24) | ((uint32_t)d << 28));
+      W.ent[(tail + below(okb)) & RM] =
+          make_uint2((uint32_t)tcell | ((((e.x >> 12) & 0xFFFu) + jump) << 12) | (m << 24) | ((uint32_t)d << 30), tlen);
     tail += npush;
     head += nproc;
-    M3_TT(6);  // prune read + push
   }
-#undef M3_TT
-  // Coordinate marks, read set and height range of the accepted cells (= L.order: every accepted entry belongs to one of
-  // them), after the loop instead of ~25 instructions in every trip: a cell's moves look at its own column, the four
-  // neighbour columns and the four landing columns two steps away.
-  for (int i = c.lane; i < n_order; i += 64) {
-    const int ci = L.order[i];
-    const int z = ci / YX, q = ci - z * YX, y = q / c.X, x = q - y * c.X;
-    mkl |= (x < 8 ? 1u << x : 0u) | (y < 8 ? 1u << y : 0u) | (1u << z);
-    uint64_t m = 1ull << q;
-    m |= x + 1 < c.X ? 1ull << (q + 1) : 0ull;
-    m |= x + 2 < c.X ? 1ull << (q + 2) : 0ull;
-    m |= x >= 1 ? 1ull << (q - 1) : 0ull;
-    m |= x >= 2 ? 1ull << (q - 2) : 0ull;
-    m |= y + 1 < c.Y ? 1ull << (q + c.X) : 0ull;
-    m |= y + 2 < c.Y ? 1ull << (q + 2 * c.X) : 0ull;
-    m |= y >= 1 ? 1ull << (q - c.X) : 0ull;
-    m |= y >= 2 ? 1ull << (q - 2 * c.X) : 0ull;
-    rs |= m;
-    zlo = min(zlo, z);
-    zhi = max(zhi, z);
-  }
-  mk = wave_or(mkl);
 #ifdef PCGRL_PHASE_TIMING
-  if (c.lane == 0) {
-    L.dbg[0] += (uint32_t)dbg_trips;
-    L.dbg[1] += (uint32_t)tail;
-    L.dbg[2] += 1;
-  }
+  (void)_ph;
+  (void)_t_prev;
 #endif
-  return tail;
+  return n_order;
 }
 
-// first maximum of len(path) in first-insertion order (helper_3D.py:538-541); returns the cell, sets entry id
-__device__ inline int m3_farthest(const M3Lds &L, const M3Ctx &c, int n_order, int &entry) {
+// first maximum of len(path) in first-insertion order (helper_3D.py:538-541); returns the cell
+template <int SC>
+__device__ inline int m3_farthest(const M3Work<SC> &W, const M3Ctx &c, int n_order) {
   uint32_t key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
   for (int k = c.lane; k < n_order; k += 64) {
-    const uint32_t len = (L.best[L.order[k]] >> 12) & 0xFFFu;
+    const uint32_t len = W.best[W.order[k]].x & 0xFFFFu;
     const uint32_t kk = (len << 16) | (uint32_t)(0xFFFF - k);
     key = kk > key ? kk : key;
   }
   key = wave_max(key);
-  const int k = 0xFFFF - (int)(key & 0xFFFF);
-  const int cell = L.order[k];
-  entry = (int)(L.best[cell] & 0xFFFu);
-  return cell;
+  return W.order[0xFFFF - (int)(key & 0xFFFF)];
 }
 
-// The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s (result + read set).
-__device__ inline void m3_fill_slot(M3Lds &L, const M3Ctx &c, int s, int sx, int sy, int sz, bool &overflow) {
-  M3Slot &S = L.slot[s];
-  if (c.lane == 0) S.valid = 0;
-  int n_order = 0, e1 = 0, e2 = 0;
-  uint32_t mk = 0, mk2 = 0;
-  uint64_t rs = 0;
-  int zlo = 15, zhi = 0;
-#ifdef PCGRL_PHASE_TIMING
-  uint64_t t0_ = __builtin_readcyclecounter();
-#define M3_T(i)                                                     \
-  do {                                                              \
-    uint64_t t1_ = __builtin_readcyclecounter();                    \
-    if (c.lane == 0) L.dbg[i] += (uint32_t)(t1_ - t0_);             \
-    t0_ = t1_;                                                      \
-  } while (0)
-#else
-#define M3_T(i) \
-  do {          \
-  } while (0)
-#endif
-  m3_search(L, c, sx, sy, sz, n_order, mk, rs, zlo, zhi, overflow);
+// accepted cells of the search just run -> W.racc; returns the coordinate values of those cells (bit v set if some
+// accepted cell has x, y or z == v: the marks of :531)
+template <int SC>
+__device__ inline uint32_t m3_collect(M3Work<SC> &W, const M3Ctx &c, int n_order) {
+  uint32_t mkl = 0;
+  for (int i = c.lane; i < n_order; i += 64) {
+    const int ci = W.order[i];
+    const int z = ci / c.YX, q = ci - z * c.YX, y = q / c.X, x = q - y * c.X;
+    mkl |= (1u << x) | (1u << y) | (1u << z);
+    atomicOr(&W.racc[ci >> 5], 1u << (ci & 31));
+  }
+  return wave_or(mkl);
+}
+
+// The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s of E (result + accepted cells).
+template <int SC>
+__device__ inline void m3_fill_slot(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch,
+                                    uint32_t &trip, bool &overflow PHASE_ARG) {
+  constexpr int NW = M3C<SC>::NW;
+  if (c.lane == 0) E.hdr[s].valid = 0;
+  for (int i = c.lane; i < c.nw; i += 64) {
+    W.racc[i] = 0;
+    W.pathm[i] = 0;
+  }
+  const int root = sz * c.YX + start_bit;
+  int n_order = m3_search(W, E.mv, c, root, epoch, trip, overflow PHASE_PASS);
   if (overflow) return;
-  const int YX = c.Y * c.X;
-  (void)m3_farthest(L, c, n_order, e1);
-  const uint32_t f1 = L.ent[e1].y;
-  m3_search(L, c, (int)((f1 >> 12) & 63u), (int)((f1 >> 18) & 63u), (int)((f1 >> 24) & 15u), n_order, mk2, rs, zlo, zhi, overflow);
+  const uint32_t mk = m3_collect(W, c, n_order);
+  const int far1 = m3_farthest(W, c, n_order);
+  n_order = m3_search(W, E.mv, c, far1, epoch, trip, overflow PHASE_PASS);
   if (overflow) return;
-  (void)m3_farthest(L, c, n_order, e2);
-  // OR of the lanes' read sets (DPP inside the 16-lane rows, then across); min / max of the heights ride along as a
-  // unary mask of the planes seen
-  // OR of the lanes' read sets; min / max of the heights ride along as a unary mask of the planes seen
-  const uint32_t lo = wave_or((uint32_t)rs), hi = wave_or((uint32_t)(rs >> 32));
-  uint32_t zm = wave_or(zlo <= zhi ? ((2u << zhi) - (1u << zlo)) : 0u);
-  // The tiles of paths[(mx,my,mz)] as a bit mask: every lane walks the parent chain (uniform reads), lane w keeps word
-  // w of the mask.  An entry knows its move kind and direction, so the parent's cell and the intermediate tiles of the
-  // move (helper_3D.py:214-319) follow without reading the parent: +-YX = one plane up / down.
-  uint32_t my = 0;
-  auto mark = [&](int cell) { my |= (cell >> 5) == c.lane ? 1u << (cell & 31) : 0u; };
-  int id = e2;
-  const uint2 fe = L.ent[e2];
-  while (true) {
-    const uint2 e = L.ent[id];
-    const int ci = e.x & 511, kind = (e.x >> 9) & 7, d = (int)(e.y >> 28);
-    mark(ci);
-    if (kind == M3_ROOT) break;
-    const int dq = (d == 0 ? 1 : (d == 2 ? -1 : 0)) + (d == 1 ? c.X : (d == 3 ? -c.X : 0));  // column step of the move
-    const int mid = ci - dq;  // jumps: the jumped-over column, at the landing's height
-    switch (kind) {
-      case M3_DOWN: mark(ci + YX); break;                          // the target column at the parent's height
-      case M3_UP: mark(ci - dq); break;                            // above the parent: (x, y, nz+1)
-      case M3_JFLAT: mark(mid); break;                             // (nx, ny, nz)
-      case M3_JUP: mark(mid - YX); mark(mid); break;               // (nx,ny,nz), (nx,ny,nz+1): landing is one higher
-      case M3_JDOWN: mark(mid + YX); mark(mid); break;             // (nx,ny,nz), (nx,ny,nz-1): landing is one lower
-      default: break;
+  (void)m3_collect(W, c, n_order);
+  const int far2 = m3_farthest(W, c, n_order);
+  // The tiles of paths[(mx,my,mz)] as a bit mask: the accepted entries form a tree (an accepted entry's parent is the
+  // accepted entry of the parent cell: a strictly shorter path to the parent would have produced a strictly shorter,
+  // hence accepted, entry for the child), so the chain is walked over cells.  An entry knows its move byte and direction,
+  // so the parent's cell and the intermediate tiles of the move (helper_3D.py:214-319) follow: +-YX = one plane up / down.
+  {
+    uint32_t my0 = 0, my1 = 0;  // words lane and lane + 64 of the mask
+    auto mark = [&](int cell) {
+      const int w = cell >> 5;
+      my0 |= w == c.lane ? 1u << (cell & 31) : 0u;
+      if (NW > 64) my1 |= w == c.lane + 64 ? 1u << (cell & 31) : 0u;
+    };
+    int cell = far2;
+    while (true) {
+      const uint32_t inf = W.info[cell];
+      mark(cell);
+      const uint32_t m = (inf >> 12) & 63u;
+      if (m == 0u) break;  // the root
+      const int d = (int)((inf >> 18) & 3u);
+      const int dq = m3_dy(d) * c.X + m3_dx(d), dz = (int)((m >> 2) & 3u) - 1;
+      if (m & 16u) {  // jumps: the jumped-over column at the landing's height, and at the take-off's height if they differ
+        const int mid = cell - dq;
+        mark(mid);
+        if (dz != 0) mark(mid - dz * c.YX);
+        cell = cell - 2 * dq - dz * c.YX;
+      } else {
+        if (dz < 0) mark(cell + c.YX);  // step down: the target column at the parent's height
+        if (dz > 0) mark(cell - dq);    // step up: above the parent
+        cell = cell - dq - dz * c.YX;
+      }
     }
-    id = (int)(e.x >> 20);
+    if (c.lane < c.nw) E.spath[s][c.lane] = my0;
+    if (NW > 64 && c.lane + 64 < c.nw) E.spath[s][c.lane + 64] = my1;
   }
-  if (c.lane < M3_MAXW) S.pathm[c.lane] = my;
+  for (int i = c.lane; i < c.nw; i += 64) E.sracc[s][i] = W.racc[i];
   if (c.lane == 0) {
-    S.start = (uint8_t)(sy * c.X + sx);
-    S.valid = 1;
-    S.max_dist = (uint16_t)(fe.y & 0xFFFu);
-    S.n_jump = (uint16_t)((fe.x >> 12) & 255u);
-    S.mk = (uint8_t)(mk & ((1u << c.Z) - 1u));
-    zm &= 0xFFu;
-    S.zr = (uint8_t)((zm ? __builtin_ctz(zm) : 15) | ((zm ? 31 - __builtin_clz(zm) : 0) << 4));
-    S.rs[0] = lo;
-    S.rs[1] = hi;
+    M3SlotHdr h;
+    h.start = (uint16_t)start_bit;
+    h.valid = 1;
+    h.max_dist = (uint16_t)(W.best[far2].x & 0xFFFFu);
+    h.n_jump = (uint16_t)(W.info[far2] & 0xFFFu);
+    h.mk = mk & ((1u << c.Z) - 1u);
+    h.pad_ = 0;
+    E.hdr[s] = h;
   }
-#undef M3_T
+#ifdef PCGRL_PHASE_TIMING
+  if (c.lane == 0) E.dbg[2] += 2;
+#endif
 }
 
 // helper_3D.calc_longest_path + remove_stacked_path_tiles + minecraft_3D_maze_prob.get_stats
-// air: this lane's plane (lanes < Z).  Results uniform over the wave.  L.over receives the new overlay mask.
-// Slots that are still valid (see SLOT CACHE) are reused; pass fresh = true to ignore them (reset, caller-provided maps).
-__device__ inline void m3_stats(M3Lds &L, const M3Ctx &c, uint64_t air, int32_t *st, bool &overflow, bool fresh PHASE_ARG) {
-  const int YX = c.Y * c.X;
-  // per-(y,x) column masks for the move rules: lane q collects bit q of every plane
-  {
-    uint32_t m = 0;
-#pragma unroll
-    for (int z = 0; z < 8; z++) {
-      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)air, z, 64), hi = (uint32_t)__shfl((int)(uint32_t)(air >> 32), z, 64);
-      const uint64_t a = (uint64_t)lo | ((uint64_t)hi << 32);
-      if (z < c.Z) m |= (uint32_t)((a >> (c.lane & 63)) & 1ull) << z;
-    }
-    L.col[c.lane] = c.lane < YX ? (uint8_t)m : (uint8_t)0;
-  }
-  if (fresh && c.lane < M3_SLOTS) L.slot[c.lane].valid = 0;
-  PHASE_MARK(2);  // column masks
-  st[0] = m3_regions(c, air);
+// air: this lane's plane (lanes < Z).  Results uniform over the wave.  E.over receives the new overlay mask.
+// Slots that are still valid (see SLOT CACHE) are reused; the caller invalidates them for fresh maps.
+template <int SC>
+__device__ inline void m3_stats(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<M3C<SC>::PW> air, PM<M3C<SC>::PW> notx0,
+                                PM<M3C<SC>::PW> notxl, int32_t *st, uint32_t &epoch, uint32_t &trip, uint32_t &filled,
+                                bool &overflow PHASE_ARG) {
+  constexpr int PW = M3C<SC>::PW;
+  st[0] = m3_regions<PW>(c, air, notx0, notxl);
   PHASE_MARK(3);  // regions
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
-  const uint64_t above = dpp64_down(air), below = dpp64_up(air);
-  const uint64_t cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : 0ull;
+  const PM<PW> above = pm_down(air), below = pm_up(air);
+  const PM<PW> cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : pm_zero<PW>();
   uint32_t marked = 0;  // z-planes of final_visited_map that are fully set (the fancy-index bug, :531)
   int final_value = 0, n_jump = 0, best_slot = -1;
   while (true) {
-    const bool mine = c.lane < c.Z && cand != 0 && !((marked >> c.lane) & 1u);
+    const bool mine = c.lane < c.Z && pm_any(cand) && !((marked >> c.lane) & 1u);
     const uint64_t b = __ballot(mine);
     if (b == 0) break;
     const int sz = __builtin_ctzll(b);
-    const int bit = (int)__shfl((int)__builtin_ctzll(cand | (1ull << 63)), sz, 64);
+    const int bit = __builtin_amdgcn_readlane(pm_ctz(cand), sz);
     const int s = sz - 1;
-    const M3Slot &S = L.slot[s];
-    if (!(S.valid && S.start == bit)) {
-      const int sy = bit / c.X, sx = bit - sy * c.X;
-      m3_fill_slot(L, c, s, sx, sy, sz, overflow);
+    if (!(E.hdr[s].valid && E.hdr[s].start == bit)) {
+      m3_fill_slot(E, W, c, s, bit, sz, epoch, trip, overflow PHASE_PASS);
+      filled |= 1u << s;
       if (overflow) break;
     }
-    marked |= S.mk;
-    n_jump = S.n_jump;  // :553 overwritten by every processed component
-    if ((int)S.max_dist > final_value) {
-      final_value = S.max_dist;
+    const M3SlotHdr h = E.hdr[s];
+    marked |= h.mk;
+    n_jump = h.n_jump;  // :553 overwritten by every processed component
+    if ((int)h.max_dist > final_value) {
+      final_value = h.max_dist;
       best_slot = s;
     }
   }
   PHASE_MARK(4);  // path searches
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
   // path tile (x,y,z) is drawn at array index [x][y][z]
-  for (int i = c.lane; i < c.nw + 2; i += 64) {
-    L.pathm[i] = (best_slot >= 0 && i < M3_MAXW) ? L.slot[best_slot < 0 ? 0 : best_slot].pathm[i] : 0u;
-    L.over[i] = 0;
+  for (int i = c.lane; i < c.nw + 4; i += 64) {
+    E.pathm[i] = (best_slot >= 0 && i < c.nw) ? E.spath[best_slot < 0 ? 0 : best_slot][i] : 0u;
+    E.over[i] = 0;
   }
-  {
-    const int q = c.lane, y = q / c.X, x = q - y * c.X;  // this lane's column (lanes < YX)
+#pragma unroll
+  for (int k = 0; k < PW; k++) {
+    const int q = 64 * k + c.lane, y = q / c.X, x = q - y * c.X;  // this lane's column (q < YX)
     for (int z = 0; z < c.Z; z++) {
-      const int ci = z * YX + q;
-      const bool in = q < YX && m3_bit(L.pathm, ci) && !(z > 0 && m3_bit(L.pathm, ci - YX));
+      const int ci = z * c.YX + q;
+      const bool in = q < c.YX && m3_bit(E.pathm, ci) && !(z > 0 && m3_bit(E.pathm, ci - c.YX));
       if (in && x < c.Z && z < c.X) {
         const int oi = (x * c.Y + y) * c.X + z;
-        atomicOr(&L.over[oi >> 5], 1u << (oi & 31));
+        atomicOr(&E.over[oi >> 5], 1u << (oi & 31));
       }
     }
   }
@@ -523,7 +689,7 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
 }
 
 // reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order) into `dirt`.
-// rp / rr: the env's streams (in registers); advanced.
+// rp / rr: the env's streams (in registers); advanced.  cpl = cells per lane (<= 64).
 __device__ inline void m3_reset_rng(uint32_t *dirt, const M3Ctx &c, const Params &p, int cpl, Pcg &rp, Pcg &rr) {
   double p0 = rp.next_double(), p1 = rp.next_double();
   double total = 0.0;
@@ -531,30 +697,30 @@ __device__ inline void m3_reset_rng(uint32_t *dirt, const M3Ctx &c, const Params
   total += p1;
   double c0 = p0 / total, c1 = c0 + p1 / total;
   c0 /= c1;  // cdf /= cdf[-1]
-  for (int i = c.lane; i < c.nw + 2; i += 64) dirt[i] = 0;
+  for (int i = c.lane; i < c.nw + 4; i += 64) dirt[i] = 0;
   Pcg end = rr;
   end.jump(p.jump[64]);
   rr.jump(p.jump[c.lane]);
-  uint32_t bits = 0;
+  uint64_t bits = 0;
   const int first = c.lane * cpl;
   for (int k = 0; k < cpl; k++) {
     int ci = first + k;
     if (ci < c.n_cells) {
       double u = rr.next_double();
       int idx = (c0 <= u ? 1 : 0) + (1.0 <= u ? 1 : 0);  // searchsorted(cdf, u, 'right') with cdf[-1] == 1.0
-      if (idx >= 1) bits |= 1u << k;
+      if (idx >= 1) bits |= 1ull << k;
     }
   }
   for (int k = 0; k < cpl; k++) {
     int ci = first + k;
-    if (ci < c.n_cells && ((bits >> k) & 1u)) atomicOr(&dirt[ci >> 5], 1u << (ci & 31));
+    if (ci < c.n_cells && ((bits >> k) & 1ull)) atomicOr(&dirt[ci >> 5], 1u << (ci & 31));
   }
   rr = end;
 }
 
 // bytes -> bit string (caller-provided maps)
 __device__ inline void m3_load_bytes(uint32_t *dirt, const M3Ctx &c, const uint8_t *src) {
-  for (int i = c.lane; i < c.nw + 2; i += 64) dirt[i] = 0;
+  for (int i = c.lane; i < c.nw + 4; i += 64) dirt[i] = 0;
   for (int ci = c.lane; ci < c.n_cells; ci += 64)
     if (src[ci]) atomicOr(&dirt[ci >> 5], 1u << (ci & 31));
 }
@@ -564,43 +730,48 @@ enum M3Mode { M3_STEP = 0, M3_RESET = 1, M3_OBSERVE = 2, M3_STATS_FOR_GRIDS = 3,
 
 // narrow_rep.py:89-102 with Q1 (position of the NEXT edit from the pre-increment counter)
 __device__ inline void m3_advance_pos(const M3Ctx &c, int *pos, int &n_step) {
-  const int YX = c.Y * c.X;
   const int idx = n_step % c.n_cells;
-  pos[0] = idx / YX;
+  pos[0] = idx / c.YX;
   pos[1] = (idx / c.X) % c.Y;
   pos[2] = idx % c.X;
   n_step++;
 }
 
 // D7: the BASELINE map shape 7 x 7 x 7 with compile-time dimensions (the search trip is instruction-bound: constant
-// strides and bounds take a fifth of its instructions away)
-template <int MODE, bool D7 = false>
+// strides and bounds take instructions away)
+template <int MODE, int SC, bool D7 = false>
 __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p, int cpl) {
-  __shared__ M3Lds L;
-  __shared__ M3ObsLds O;
+  constexpr int PW = M3C<SC>::PW;
+  __shared__ M3Env<SC> E;
+  __shared__ M3Work<SC> W;
+  __shared__ M3ObsLds<SC> O;
   M3Ctx c;
   c.lane = (int)__lane_id();
   c.Z = D7 ? 7 : p.cfg.dims[0];
   c.Y = D7 ? 7 : p.cfg.dims[1];
   c.X = D7 ? 7 : p.cfg.dims[2];
   if (D7) cpl = 6;  // ceil(343 / 64)
-  c.n_cells = c.Z * c.Y * c.X;
-  c.nw = (c.n_cells + 31) >> 5;
+  c.YX = c.Y * c.X;
+  c.n_cells = c.Z * c.YX;
+  c.nw = m3_words(c.n_cells);
+  const int n_slots = c.Z - 2 > 0 ? c.Z - 2 : 0;  // start planes z = 1 .. Z-2
+  const int slot_words = M3_SLOT_HDR + 2 * c.nw;
   const int env = blockIdx.x;
   constexpr int NS = M3_NS;
   PHASE_DECL();
   TRACE_DECL();
-  uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * M3_MAXW;  // [dirt words | overlay words]
-  uint32_t *gslot = (uint32_t *)p.m3cache + (size_t)env * M3_SLOT_WORDS;
+  uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * c.nw;  // [dirt words | overlay words]
+  uint32_t *gslot = (uint32_t *)p.m3cache + (size_t)env * slot_words * n_slots;
+  uint8_t *gmv = (uint8_t *)p.m3mv + (size_t)env * c.n_cells * 4;
   EnvState *S = &p.st[env];
 
   if constexpr (MODE == M3_STEP) {
     // ------------------------------------------------------------------------------------------ observe wave
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {  // (readfirstlane: a scalar branch)
       if (p.obs == nullptr) return;  // (the simulate wave skips the barrier in that case, too)
-      for (int i = c.lane; i < c.nw + 2; i += 64) {
+      for (int i = c.lane; i < c.nw + 4; i += 64) {
         O.dirt[i] = i < c.nw ? gd[i] : 0u;
-        O.over[i] = i < c.nw ? gd[M3_MAXW + i] : 0u;
+        O.over[i] = i < c.nw ? gd[c.nw + i] : 0u;
       }
       int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
       int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
@@ -637,22 +808,6 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     __builtin_amdgcn_s_setprio(3);  // the simulate wave's dependent chain issues ahead of the observe wave on its SIMD
   }
 
-  if constexpr (MODE == M3_STATS_FOR_GRIDS) {
-    m3_load_bytes(L.dirt, c, p.init_grids + (size_t)env * c.n_cells);
-    for (int i = c.lane; i < c.n_cells; i += 64) {
-      L.best[i] = 0;
-      L.claim[i] = 0xFFFFFFFFu;
-    }
-    if (c.lane == 0) L.epoch = 0;
-    uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
-    int32_t st[NS];
-    bool ovf = false;
-    m3_stats(L, c, air, st, ovf, true PHASE_PASS);
-    if (ovf && c.lane == 0) atomicOr(p.err, 4);
-    if (c.lane == 0)
-      for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = st[k];
-    return;
-  }
   if constexpr (MODE == M3_GET_STATE) {
     if (p.out_grids)
       for (int ci = c.lane; ci < c.n_cells; ci += 64) p.out_grids[(size_t)env * c.n_cells + ci] = (gd[ci >> 5] >> (ci & 31)) & 1u;
@@ -673,35 +828,87 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     return;
   }
 
-  // load grid + overlay (+ the slot cache) and prepare the search tables
-  for (int i = c.lane; i < c.nw + 2; i += 64) {
-    L.dirt[i] = i < c.nw ? gd[i] : 0u;
-    L.over[i] = i < c.nw ? gd[M3_MAXW + i] : 0u;
+  // search tables of this wave
+  uint32_t epoch = 0, trip = 0;
+  uint32_t dirty_hdr = 0, dirty_full = 0;  // slots whose header / whose whole record differs from the copy in HBM
+  auto init_work = [&]() {
+    for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
+  };
+  PM<PW> notx0, notxl;
+  m3_edge_masks<PW>(c, notx0, notxl);
+  auto plane_of = [&](const uint32_t *dirt) { return c.lane < c.Z ? m3_plane_air<PW>(dirt, c, c.lane) : pm_zero<PW>(); };
+  // statistics of a map the kernel has not seen before: columns, move table, no cached slots
+  auto fresh_stats = [&](int32_t *st, bool &ovf) {
+    const PM<PW> air = plane_of(E.dirt);
+    m3_build_cols<SC>(E, c, air);
+    m3_build_moves<SC>(E, c);
+    if (c.lane < M3C<SC>::SLOTS) E.hdr[c.lane].valid = 0;
+    dirty_hdr = (1u << n_slots) - 1u;
+    PHASE_MARK(2);  // column masks + move table
+    m3_stats<SC>(E, W, c, air, notx0, notxl, st, epoch, trip, dirty_full, ovf PHASE_PASS);
+  };
+  auto store_moves = [&]() {
+    const int n4 = c.n_cells;  // 4 bytes per cell
+    for (int i = c.lane; i < n4; i += 64) ((uint32_t *)gmv)[i] = ((const uint32_t *)E.mv)[i];
+  };
+  auto store_slots = [&]() {
+    for (int s = 0; s < n_slots; s++) {
+      if ((((dirty_hdr | dirty_full) >> s) & 1u) == 0u) continue;
+      uint32_t *g = gslot + (size_t)s * slot_words;
+      if (c.lane < M3_SLOT_HDR) g[c.lane] = ((const uint32_t *)&E.hdr[s])[c.lane];
+      if ((dirty_full >> s) & 1u)
+        for (int i = c.lane; i < c.nw; i += 64) {
+          g[M3_SLOT_HDR + i] = E.sracc[s][i];
+          g[M3_SLOT_HDR + c.nw + i] = E.spath[s][i];
+        }
+    }
+  };
+
+  if constexpr (MODE == M3_STATS_FOR_GRIDS) {
+    m3_load_bytes(E.dirt, c, p.init_grids + (size_t)env * c.n_cells);
+    init_work();
+    int32_t st[NS] = {0, 0, 0};
+    bool ovf = false;
+    fresh_stats(st, ovf);
+    if (ovf && c.lane == 0) atomicOr(p.err, 4);
+    if (c.lane == 0)
+      for (int k = 0; k < NS; k++) p.stats_out[(size_t)env * NS + k] = ovf ? -1 : st[k];
+    return;
+  }
+
+  // load grid + overlay
+  for (int i = c.lane; i < c.nw + 4; i += 64) {
+    E.dirt[i] = i < c.nw ? gd[i] : 0u;
+    E.over[i] = i < c.nw ? gd[c.nw + i] : 0u;
   }
   int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
 
   if constexpr (MODE == M3_OBSERVE) {
     // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
-    m3_encode_obs(L.dirt, L.over, c, p, env, pos, false);
+    m3_encode_obs(E.dirt, E.over, c, p, env, pos, false);
     return;
   }
-  if constexpr (MODE != M3_RESET) {
-    for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) ((uint32_t *)L.slot)[i] = gslot[i];
+  if constexpr (MODE != M3_RESET) {  // the move table and the slot cache
+    for (int i = c.lane; i < c.n_cells; i += 64) ((uint32_t *)E.mv)[i] = ((const uint32_t *)gmv)[i];
+    for (int s = 0; s < n_slots; s++) {
+      const uint32_t *g = gslot + (size_t)s * slot_words;
+      if (c.lane < M3_SLOT_HDR) ((uint32_t *)&E.hdr[s])[c.lane] = g[c.lane];
+      for (int i = c.lane; i < c.nw; i += 64) {
+        E.sracc[s][i] = g[M3_SLOT_HDR + i];
+        E.spath[s][i] = g[M3_SLOT_HDR + c.nw + i];
+      }
+    }
   }
-  for (int i = c.lane; i < c.n_cells; i += 64) {
-    L.best[i] = 0;
-    L.claim[i] = 0xFFFFFFFFu;
-  }
-  if (c.lane == 0) L.epoch = 0;
+  init_work();
 #ifdef PCGRL_PHASE_TIMING
-  if (c.lane < 8) L.dbg[c.lane] = 0;
+  if (c.lane < 8) E.dbg[c.lane] = 0;
 #endif
 
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
   double last_loss = S->last_loss, ep_return = S->ep_return;
   int32_t st[NS];
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
-  bool ovf = false, slots_dirty = false;
+  bool ovf = false, moves_dirty = false;
   EnvTargets<NS> trg;
   trg.load(p, env, false);
   Pcg rp, rr;
@@ -709,11 +916,11 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
   if constexpr (MODE == M3_RESET) {
     if (p.mask != nullptr && p.mask[env] == 0) return;
     if (p.refresh_only) {  // statistics (and the path overlay) of the current map, nothing else
-      uint64_t air0 = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
-      m3_stats(L, c, air0, st, ovf, true PHASE_PASS);
+      fresh_stats(st, ovf);
       if (ovf && c.lane == 0) atomicOr(p.err, 4);
-      for (int i = c.lane; i < c.nw; i += 64) gd[M3_MAXW + i] = L.over[i];
-      for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) gslot[i] = ((uint32_t *)L.slot)[i];
+      for (int i = c.lane; i < c.nw; i += 64) gd[c.nw + i] = E.over[i];
+      store_moves();
+      store_slots();
       if (c.lane == 0) {
         S->last_loss = trg.loss(p.cfg, st);
         S->flags = 0;
@@ -725,23 +932,22 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       return;
     }
     if (p.init_grids) {
-      m3_load_bytes(L.dirt, c, p.init_grids + (size_t)env * c.n_cells);
+      m3_load_bytes(E.dirt, c, p.init_grids + (size_t)env * c.n_cells);
       pos[0] = pos[1] = pos[2] = 0;
       if (p.init_pos)
         for (int d = 0; d < 3; d++) pos[d] = p.init_pos[(size_t)env * 3 + d];
     } else {
       rp.load(p.rng[env].prob);
       rr.load(p.rng[env].rep);
-      m3_reset_rng(L.dirt, c, p, cpl, rp, rr);
+      m3_reset_rng(E.dirt, c, p, cpl, rp, rr);
       if (c.lane == 0) {
         rr.store(p.rng[env].rep);
         rp.store(p.rng[env].prob);
       }
       pos[0] = pos[1] = pos[2] = 0;
     }
-    uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
-    m3_stats(L, c, air, st, ovf, true PHASE_PASS);
-    slots_dirty = true;
+    fresh_stats(st, ovf);
+    moves_dirty = true;
     n_step = iteration = changes = 0;
     ep_return = 0.0;
     if (p.set_state) {  // pcgrl_set_state: injected map, the caller's counters / return
@@ -761,6 +967,10 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
    rr.load(p.rng[env].rep);
    bool any_reset = false;
    if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();  // the observe wave has taken its copy of the old state
+   {  // column masks of the current map (the move rules of an edit read them)
+     const PM<PW> air0 = plane_of(E.dirt);
+     m3_build_cols<SC>(E, c, air0);
+   }
    for (int k = 0; k < K; k++) {
     const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
     uint8_t *obs_k = p.obs == nullptr ? nullptr
@@ -774,27 +984,23 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     bool change = false;
     if (!bad) {
       const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
-      const bool old = m3_bit(L.dirt, ci);
+      const bool old = m3_bit(E.dirt, ci);
       change = old != (action != 0);
       if (change) {
-        if (c.lane == 0) L.dirt[ci >> 5] ^= 1u << (ci & 31);
-        // the edit invalidates exactly the cached slots whose searches read this cell
-        const int q = pos[1] * c.X + pos[2];
-        if (c.lane < M3_SLOTS) {
-          const M3Slot &T = L.slot[c.lane];
-          const int zr = T.zr;
-          if (((T.rs[q >> 5] >> (q & 31)) & 1u) && pos[0] >= (zr & 15) - 2 && pos[0] <= (zr >> 4) + 3) L.slot[c.lane].valid = 0;
+        if (c.lane == 0) {
+          E.dirt[ci >> 5] ^= 1u << (ci & 31);
+          E.col[pos[1] * c.X + pos[2]] ^= (uint16_t)(1u << pos[0]);
         }
-        slots_dirty = true;
+        // the edit changes at most 48 bytes of the move table and drops exactly the slots that accepted one of their cells
+        dirty_hdr |= m3_update_moves<SC>(E, c, pos[2], pos[1], pos[0], gmv, n_slots);
       }
       m3_advance_pos(c, pos, n_step);
     } else if (c.lane == 0) {
       atomicOr(p.err, 1);
     }
     if (upd_only) {  // rep.update() only: map, position (the observe wave shows the stale overlay)
-      for (int i = c.lane; i < c.nw; i += 64) gd[i] = L.dirt[i];
-      if (slots_dirty)
-        for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) gslot[i] = ((uint32_t *)L.slot)[i];
+      for (int i = c.lane; i < c.nw; i += 64) gd[i] = E.dirt[i];
+      store_slots();  // (headers of the dropped slots)
       if (c.lane == 0) {
         S->pos[0] = pos[0];
         S->pos[1] = pos[1];
@@ -810,11 +1016,14 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
     // the previous stats update on the already edited map
     PHASE_MARK(0);  // loads + action
-    if (!do_reset && want_obs) m3_encode_obs(L.dirt, L.over, c, p, env, pos, true, obs_k);
+    if (!do_reset && want_obs) m3_encode_obs(E.dirt, E.over, c, p, env, pos, true, obs_k);
     PHASE_MARK(1);  // observation
     if (change) {
-      uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
-      m3_stats(L, c, air, st, ovf, false PHASE_PASS);
+      const PM<PW> air = plane_of(E.dirt);
+      const int32_t st_old[NS] = {st[0], st[1], st[2]};
+      m3_stats<SC>(E, W, c, air, notx0, notxl, st, epoch, trip, dirty_full, ovf PHASE_PASS);
+      if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
+        for (int i = 0; i < NS; i++) st[i] = st_old[i];
     }
     const double loss = trg.loss(p.cfg, st);
     const double rew = loss - last_loss;
@@ -832,17 +1041,16 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
         latch_episode<NS>(p, env, S, ep_return, iteration, st);
         accumulate_episode<NS>(S);
       }
-      m3_reset_rng(L.dirt, c, p, cpl, rp, rr);
+      m3_reset_rng(E.dirt, c, p, cpl, rp, rr);
       any_reset = true;
       pos[0] = pos[1] = pos[2] = 0;
-      uint64_t air = c.lane < c.Z ? m3_plane_air(L.dirt, c, c.lane) : 0ull;
-      m3_stats(L, c, air, st, ovf, true PHASE_PASS);
-      slots_dirty = true;
+      fresh_stats(st, ovf);
+      moves_dirty = true;
       n_step = iteration = changes = 0;
       ep_return = 0.0;
       trg.load(p, env, true);
       last_loss = trg.loss(p.cfg, st);
-      if (want_obs) m3_encode_obs(L.dirt, L.over, c, p, env, pos, false, obs_k);
+      if (want_obs) m3_encode_obs(E.dirt, E.over, c, p, env, pos, false, obs_k);
     }
    }
    if (any_reset && c.lane == 0) {
@@ -853,11 +1061,11 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
   if (ovf && c.lane == 0) atomicOr(p.err, 4);
   // write back
   for (int i = c.lane; i < c.nw; i += 64) {
-    gd[i] = L.dirt[i];
-    gd[M3_MAXW + i] = L.over[i];
+    gd[i] = E.dirt[i];
+    gd[c.nw + i] = E.over[i];
   }
-  if (slots_dirty)
-    for (int i = c.lane; i < M3_SLOT_WORDS; i += 64) gslot[i] = ((uint32_t *)L.slot)[i];
+  if (moves_dirty) store_moves();
+  store_slots();
   if (c.lane == 0) {
     trg.write_ctrl_obs(p, env, st);
     trg.commit(p, env);
@@ -873,14 +1081,6 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
   }
   PHASE_MARK(6);
-#ifdef PCGRL_PHASE_TIMING
-  _ph[0] = L.dbg[0];  // (development: trips / queue entries / searches of this launch replace the first phases)
-  _ph[1] = L.dbg[6];  // (farthest 2 + path materialisation)
-  _ph[2] = L.dbg[2];
-  _ph[3] = L.dbg[3];  // cycles: first search, farthest, second search, farthest + path materialisation
-  _ph[5] = L.dbg[4];
-  _ph[6] = L.dbg[5];
-#endif
   PHASE_FLUSH();
   TRACE_PUT(0, _tr0);
   TRACE_PUT(1, TRACE_NOW());
