@@ -84,8 +84,6 @@ struct Params {
   int32_t int_targets;
   int32_t spread;         // sokoban step: one env per wave pair (see step_kernel)
   int32_t sk_helpers;     // sokoban: helper wavefronts per workgroup for the solver's A* stages (0 or 3, see pcgrl_sokoban.h)
-  void *m3cache;          // u32[N][Z-2][m3_slot_words]: cached path-search results per start plane (3-D maze), else null
-  void *m3mv;             // u8[N][n_cells][4]: the maintained move table of helper_3D._passable (3-D maze), else null
   // per-call I/O
   const int32_t *actions;
   uint8_t *obs;

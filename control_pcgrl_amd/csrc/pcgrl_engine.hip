@@ -499,10 +499,8 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     }                                                                                                \
   } while (0)
   if (is3d) {
-    const int n_slots = std::max(cfg->dims[0] - 2, 0);  // start planes z = 1 .. Z-2
-    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * 2 * m3_words(p.n_cells) * sizeof(uint32_t)));  // [tile bits | path overlay bits]
-    CREATE_CHK(dalloc(&p.m3cache, std::max<size_t>((size_t)n_envs * n_slots * m3_slot_words(p.n_cells) * sizeof(uint32_t), 16)));  // all slots invalid
-    CREATE_CHK(dalloc(&p.m3mv, (size_t)n_envs * p.n_cells * 4));
+    // one record per env: tile bits, overlay bits, column masks, cached start-plane results, move table (M3Lay)
+    CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * m3_layout(cfg->dims[0], cfg->dims[1], cfg->dims[2]).rec_words * sizeof(uint32_t)));
   } else
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));

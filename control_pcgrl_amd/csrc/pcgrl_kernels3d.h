@@ -40,16 +40,30 @@
 
 namespace pcgrl {
 
+// Development builds (-DPCGRL_PHASE_TIMING): the eight per-workgroup counters hold either the search counters
+// ([0] trips [1] queue entries [2] searches [3] search-loop cycles [4] regions [5] everything else [6] candidate walk incl.
+// the search loops) or, with -DPCGRL_M3_PHASES, the phases of the simulate wave ([0] loads until the barrier [1] columns +
+// move-table update [2] regions [3] candidate walk [4] overlay [5] outputs + write-back [6] fresh tables); [7] = wall clock.
+#if defined(PCGRL_M3_TRIPS)  // [0] chain trips [1] general trips [2] / [3] their cycles; the first four phases land in [6]
+#define M3_MARK(coarse, fine) PHASE_MARK((coarse) < 4 ? 6 : (coarse))
+#elif defined(PCGRL_M3_PHASES)
+#define M3_MARK(coarse, fine) PHASE_MARK(coarse)
+#else
+#define M3_MARK(coarse, fine) PHASE_MARK(fine)
+#endif
+
 // size classes: SC 0 = planes of up to 64 cells, Z <= 8 (BASELINE's 7^3);  SC 1 = planes of up to 256 cells, Z <= 16 (15^3)
 template <int SC>
 struct M3C;
 template <>
 struct M3C<0> {
   static constexpr int CELLS = 512, NW = 16, PW = 1, RING = 1024, COLS = 64, SLOTS = 6, ZMAX = 8;
+  static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + CELLS + 4;  // upper bound of m3_layout().rec_words
 };
 template <>
 struct M3C<1> {
   static constexpr int CELLS = 4096, NW = 128, PW = 4, RING = 4096, COLS = 256, SLOTS = 14, ZMAX = 16;
+  static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + CELLS + 4;
 };
 constexpr int M3_NS = 3;
 constexpr int M3_SLOT_HDR = 4;  // header words of a cached slot in HBM, followed by the accepted-cell set and the path tiles
@@ -60,7 +74,29 @@ __host__ __device__ inline bool m3_supported(int Z, int Y, int X) {
 }
 // words of one per-cell bit string of an env in HBM (even, so that 64-bit accesses stay aligned)
 __host__ __device__ inline int m3_words(int n_cells) { return (((n_cells + 31) >> 5) + 1) & ~1; }
-__host__ __device__ inline int m3_slot_words(int n_cells) { return M3_SLOT_HDR + 2 * m3_words(n_cells); }
+// One env = one contiguous record of 32-bit words in HBM (Params::planes), mirrored word for word in LDS, so a step reads
+// it with a handful of 16-byte loads issued together:
+//   [0, nw)            tile bits (1 = DIRT), flat cell index (z*Y + y)*X + x
+//   [o_over, +nw)      path-overlay bits of the last statistics update (transposed index, see m3_stats)
+//   [o_col, +cw)       per-(y,x) column masks: AIR bits over z, 16 bits per column
+//   [o_slots, ...)     Z-2 cached start-plane results: 4 header words + accepted cells (nw) + path tiles (nw) each
+//   [o_mv, +n_cells)   the move table, 4 bytes (directions) per cell
+struct M3Lay {
+  int nw, n_slots, slot_words, o_over, o_col, o_slots, o_mv, rec_words;
+};
+__host__ __device__ inline M3Lay m3_layout(int Z, int Y, int X) {
+  M3Lay L;
+  const int n_cells = Z * Y * X;
+  L.nw = m3_words(n_cells);
+  L.n_slots = Z > 2 ? Z - 2 : 0;  // start planes z = 1 .. Z-2
+  L.slot_words = M3_SLOT_HDR + 2 * L.nw;
+  L.o_over = L.nw;
+  L.o_col = 2 * L.nw;
+  L.o_slots = L.o_col + ((((Y * X + 1) >> 1) + 1) & ~1);
+  L.o_mv = L.o_slots + L.n_slots * L.slot_words;
+  L.rec_words = (L.o_mv + n_cells + 3) & ~3;
+  return L;
+}
 
 // ---------------------------------------------------------------------------------------------- plane masks
 template <int PW>
@@ -180,7 +216,7 @@ __device__ inline uint32_t wave_or(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------- LDS
-// cached result of one start plane (see SLOT CACHE); in HBM: 4 header words + racc + pathm, m3_words(n_cells) each
+// header of a cached start-plane result (see SLOT CACHE)
 struct M3SlotHdr {
   uint16_t start;   // bit index (y*X + x) of the start cell in its plane
   uint16_t valid;
@@ -194,42 +230,44 @@ static_assert(sizeof(M3SlotHdr) == 4 * M3_SLOT_HDR, "slot header layout");
 // workspace of one search wave
 template <int SC>
 struct M3Work {
-  uint2 ent[M3C<SC>::RING];         // queue ring: cell | njump<<12 | move byte<<24 | direction<<30 ; len
+  uint2 ent[M3C<SC>::RING];         // queue ring: cell | njump<<12 | move byte<<24 | direction<<30 ; len | parent cell<<12
   uint2 best[M3C<SC>::CELLS];       // per cell: epoch<<24 | len of the accepted path (the `paths` dict) ; trip claim
   uint32_t info[M3C<SC>::CELLS];    // per cell, of the accepted entry: njump | move byte<<12 | direction<<18
   uint16_t order[M3C<SC>::CELLS];   // cells in first-insertion order
   uint32_t racc[M3C<SC>::NW];       // accepted cells of the pair of searches being run (bit per cell)
-  uint32_t pathm[M3C<SC>::NW];      // path tiles of the pair being run
 };
-// the env
+// the env: its record (M3Lay)
 template <int SC>
 struct M3Env {
-  uint32_t dirt[M3C<SC>::NW + 4];   // tile bit per cell (1 = DIRT), flat index (z*Y + y)*X + x
-  uint32_t pathm[M3C<SC>::NW + 4];  // tiles of the best path
-  uint32_t over[M3C<SC>::NW + 4];   // overlay mask (transposed index) for the observation
-  uint16_t col[M3C<SC>::COLS];      // per (y,x): AIR bits over z
-  alignas(16) uint8_t mv[M3C<SC>::CELLS * 4];  // move table, [cell][direction]
-  M3SlotHdr hdr[M3C<SC>::SLOTS];
-  uint32_t sracc[M3C<SC>::SLOTS][M3C<SC>::NW];
-  uint32_t spath[M3C<SC>::SLOTS][M3C<SC>::NW];
-#ifdef PCGRL_PHASE_TIMING
-  uint32_t dbg[8];                  // development counters: trips, queue entries, searches, cycles ...
-#endif
+  alignas(16) uint32_t rec[M3C<SC>::REC + 4];
 };
 template <int SC>
-struct M3ObsLds {  // the observe wave's own copy
-  uint32_t dirt[M3C<SC>::NW + 4];
-  uint32_t over[M3C<SC>::NW + 4];
+struct M3ObsLds {  // the observe wave's own copy of the tile and overlay bits
+  alignas(16) uint32_t bits[2 * M3C<SC>::NW];
 };
 
 struct M3Ctx {
-  int lane, Z, Y, X, YX, n_cells, nw;  // nw = m3_words(n_cells)
+  int lane, Z, Y, X, YX, n_cells;
+  M3Lay L;
+  // views into the env's record in LDS
+  uint32_t *dirt, *over, *slots;
+  uint16_t *col;
+  uint8_t *mv;
+  __device__ inline M3SlotHdr *hdr(int s) const { return (M3SlotHdr *)(slots + s * L.slot_words); }
+  __device__ inline uint32_t *racc(int s) const { return slots + s * L.slot_words + M3_SLOT_HDR; }
+  __device__ inline uint32_t *spath(int s) const { return slots + s * L.slot_words + M3_SLOT_HDR + L.nw; }
 };
 
 __device__ inline bool m3_bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 __device__ inline int m3_cell(const M3Ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+// number of set bits of `mask` in lanes below this one
+__device__ inline int m3_below(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+#define M3_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
 
-// (Y*X)-bit AIR mask of plane z from the flat bit string (the arrays carry 4 spare zero words at the end)
+// (Y*X)-bit AIR mask of plane z from the flat bit string.  Words past the string are whatever follows it in the record:
+// the plane mask removes them.
 template <int PW>
 __device__ inline PM<PW> m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int z) {
   PM<PW> r;
@@ -237,10 +275,9 @@ __device__ inline PM<PW> m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int 
 #pragma unroll
   for (int k = 0; k < PW; k++) {
     const int b = b0 + 64 * k, w = b >> 5, s = b & 31;
-    const int lim = c.nw + 1;  // (words read stay inside the array)
-    const uint64_t lo = (uint64_t)dirt[min(w, lim)] | ((uint64_t)dirt[min(w + 1, lim)] << 32);
+    const uint64_t lo = (uint64_t)dirt[w] | ((uint64_t)dirt[w + 1] << 32);
     uint64_t v = lo >> s;
-    if (s) v |= (uint64_t)dirt[min(w + 2, lim)] << (64 - s);
+    if (s) v |= (uint64_t)dirt[w + 2] << (64 - s);
     const int left = c.YX - 64 * k;  // plane bits in this word and beyond
     const uint64_t pm = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
     r.w[k] = ~v & pm;
@@ -269,29 +306,64 @@ __device__ inline void m3_edge_masks(const M3Ctx &c, PM<PW> &notx0, PM<PW> &notx
   }
 }
 
+// the 6-neighbourhood of a set of cells (lane = plane)
+template <int PW>
+__device__ inline PM<PW> m3_grow(const M3Ctx &c, PM<PW> f, PM<PW> notx0, PM<PW> notxl) {
+  return pm_shl(f & notxl, 1) | pm_shr(f & notx0, 1) | pm_shl(f, c.X) | pm_shr(f, c.X) | pm_up(f) | pm_down(f);
+}
+
 // helper_3D.py:396-406 calc_num_regions (6-neighbour components of AIR)
 template <int PW>
 __device__ inline int m3_regions(const M3Ctx &c, PM<PW> air, PM<PW> notx0, PM<PW> notxl) {
   PM<PW> remaining = c.lane < c.Z ? air : pm_zero<PW>();
   int n = 0;
-  auto grow = [&](PM<PW> f) {
-    return pm_shl(f & notxl, 1) | pm_shr(f & notx0, 1) | pm_shl(f, c.X) | pm_shr(f, c.X) | pm_up(f) | pm_down(f);
-  };
   while (true) {
-    uint64_t b = __ballot(pm_any(remaining));
+    uint64_t b = M3_BALLOT(pm_any(remaining));
     if (b == 0) break;
     int fl = __builtin_ctzll(b);
     PM<PW> f = c.lane == fl ? pm_lowest(remaining) : pm_zero<PW>();
     while (true) {  // two expansion rounds per trip (one ballot per two rounds)
-      f = f | (grow(f) & remaining);
-      const PM<PW> nf = grow(f) & remaining & ~f;
-      if (__ballot(pm_any(nf)) == 0) break;
+      f = f | (m3_grow(c, f, notx0, notxl) & remaining);
+      const PM<PW> nf = m3_grow(c, f, notx0, notxl) & remaining & ~f;
+      if (M3_BALLOT(pm_any(nf)) == 0) break;
       f = f | nf;
     }
     remaining = remaining & ~f;
     n++;
   }
   return n;
+}
+
+// The region count after the edit of one cell e = (plane ez, bit eq), from the count before it.  A = the AIR planes
+// WITHOUT e (the map before e became AIR / after it became DIRT).  The AIR face neighbours of e fall into `pieces`
+// components of A: a new AIR cell joins them into one (count - pieces + 1; + 1 without neighbours), a removed one leaves
+// them behind (count - 1 + pieces).  Each flood stops as soon as it holds every neighbour not yet accounted for -- around
+// one cell that is after two or three rounds unless the cell really was a bridge.
+template <int PW>
+__device__ inline int m3_regions_update(const M3Ctx &c, PM<PW> A, PM<PW> notx0, PM<PW> notxl, int eq, int ez, bool added,
+                                        int regions_old) {
+  PM<PW> e = pm_zero<PW>();
+  if (c.lane == ez) pm_set(e, eq);
+  A = c.lane < c.Z ? A : pm_zero<PW>();
+  PM<PW> remaining = m3_grow(c, e, notx0, notxl) & A;
+  int pieces = 0;
+  while (true) {
+    const uint64_t b = M3_BALLOT(pm_any(remaining));
+    if (b == 0) break;
+    const int fl = __builtin_ctzll(b);
+    PM<PW> f = c.lane == fl ? pm_lowest(remaining) : pm_zero<PW>();
+    while (true) {
+      f = f | (m3_grow(c, f, notx0, notxl) & A);
+      if (M3_BALLOT(pm_any(remaining & ~f)) == 0) break;  // every neighbour left is in this component
+      const PM<PW> nf = m3_grow(c, f, notx0, notxl) & A & ~f;
+      if (M3_BALLOT(pm_any(nf)) == 0) break;
+      f = f | nf;
+    }
+    remaining = remaining & ~f;
+    pieces++;
+  }
+  if (pieces == 0) return regions_old + (added ? 1 : -1);
+  return added ? regions_old - (pieces - 1) : regions_old + (pieces - 1);
 }
 
 // ---------------------------------------------------------------------------------------------- move table
@@ -320,21 +392,19 @@ __device__ inline int m3_dx(int d) { return d == 0 ? 1 : (d == 2 ? -1 : 0); }  /
 __device__ inline int m3_dy(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }
 
 // move byte of (x, y, z, d) from the column masks
-template <int SC>
-__device__ inline uint32_t m3_move_at(const M3Env<SC> &E, const M3Ctx &c, int x, int y, int z, int d) {
+__device__ inline uint32_t m3_move_at(const M3Ctx &c, int x, int y, int z, int d) {
   const int dx = m3_dx(d), dy = m3_dy(d);
   const int nx = x + dx, ny = y + dy, jx = nx + dx, jy = ny + dy;
   const bool n_in = ((unsigned)nx < (unsigned)c.X) & ((unsigned)ny < (unsigned)c.Y);
   const bool j_in = ((unsigned)jx < (unsigned)c.X) & ((unsigned)jy < (unsigned)c.Y);
   const int q = y * c.X + x, dq = dy * c.X + dx;
-  const uint32_t cc = E.col[q], cn = E.col[n_in ? q + dq : 0], cj = E.col[j_in ? q + 2 * dq : 0];
+  const uint32_t cc = c.col[q], cn = c.col[n_in ? q + dq : 0], cj = c.col[j_in ? q + 2 * dq : 0];
   return m3_move(cc, cn, cj, z, n_in, j_in);
 }
 
 // per-(y,x) column masks from the planes: lane q of pass k collects bit q of every plane
-template <int SC>
-__device__ inline void m3_build_cols(M3Env<SC> &E, const M3Ctx &c, PM<M3C<SC>::PW> air) {
-  constexpr int PW = M3C<SC>::PW;
+template <int PW>
+__device__ inline void m3_build_cols(const M3Ctx &c, PM<PW> air) {
 #pragma unroll
   for (int k = 0; k < PW; k++) {
     uint32_t m = 0;
@@ -345,25 +415,23 @@ __device__ inline void m3_build_cols(M3Env<SC> &E, const M3Ctx &c, PM<M3C<SC>::P
       m |= (uint32_t)((a >> c.lane) & 1ull) << z;
     }
     const int q = 64 * k + c.lane;
-    if (q < M3C<SC>::COLS) E.col[q] = q < c.YX ? (uint16_t)m : (uint16_t)0;
+    if (q < c.YX) c.col[q] = (uint16_t)m;
   }
 }
 
 // the whole table from the column masks (reset, injected maps)
-template <int SC>
-__device__ inline void m3_build_moves(M3Env<SC> &E, const M3Ctx &c) {
+__device__ inline void m3_build_moves(const M3Ctx &c) {
   for (int i = c.lane; i < c.n_cells * 4; i += 64) {
     const int cell = i >> 2, d = i & 3;
     const int z = cell / c.YX, q = cell - z * c.YX, y = q / c.X, x = q - y * c.X;
-    E.mv[i] = (uint8_t)m3_move_at(E, c, x, y, z, d);
+    c.mv[i] = (uint8_t)m3_move_at(c, x, y, z, d);
   }
 }
 
-// After the edit of cell (ex, ey, ez) (E.col already updated): re-evaluate the <= 48 (cell, direction) pairs whose rules
-// read that cell, and drop the cached slots that accepted a cell whose move changed.  gmv: the table in HBM (or null).
-// Returns the mask of the slots it dropped.
-template <int SC>
-__device__ inline uint32_t m3_update_moves(M3Env<SC> &E, const M3Ctx &c, int ex, int ey, int ez, uint8_t *gmv, int n_slots) {
+// After the edit of cell (ex, ey, ez) (c.col already updated): re-evaluate the <= 48 (cell, direction) pairs whose rules
+// read that cell, and drop the cached slots that accepted a cell whose move changed.
+// Returns the mask of the slots it dropped; chg / chg_cell: this lane changed a byte of that cell's table row.
+__device__ inline uint32_t m3_update_moves(const M3Ctx &c, int ex, int ey, int ez, bool &chg, int &chg_cell) {
   // lane -> (direction, source cell): 0..3 the cell two below (own column at z+2); 4..23 the four neighbours at heights
   // ez-2..ez+2 (window of the neighbour column); 24..47 the cells two steps away at heights ez-3..ez+2 (landing window)
   const int L = c.lane;
@@ -374,20 +442,18 @@ __device__ inline uint32_t m3_update_moves(M3Env<SC> &E, const M3Ctx &c, int ex,
   const int sz = grp == 0 ? ez - 2 : (grp == 1 ? ez - 2 + k : ez - 3 + k);
   const bool in = (L < 48) & ((unsigned)sx < (unsigned)c.X) & ((unsigned)sy < (unsigned)c.Y) & ((unsigned)sz < (unsigned)c.Z);
   const int cell = in ? m3_cell(c, sx, sy, sz) : 0;
-  const uint32_t nw_ = m3_move_at(E, c, in ? sx : 0, in ? sy : 0, in ? sz : 0, d);
-  const uint32_t old = E.mv[cell * 4 + d];
-  const bool chg = in & (nw_ != old);
-  if (chg) {
-    E.mv[cell * 4 + d] = (uint8_t)nw_;
-    if (gmv) gmv[cell * 4 + d] = (uint8_t)nw_;
-  }
+  const uint32_t nw_ = m3_move_at(c, in ? sx : 0, in ? sy : 0, in ? sz : 0, d);
+  const uint32_t old = c.mv[cell * 4 + d];
+  chg = in & (nw_ != old);
+  chg_cell = cell;
+  if (chg) c.mv[cell * 4 + d] = (uint8_t)nw_;
   uint32_t dropped = 0;
-  if (__ballot(chg) != 0) {
-    for (int s = 0; s < n_slots; s++) {
-      if (__builtin_amdgcn_readfirstlane((int)E.hdr[s].valid) == 0) continue;
-      const bool hit = chg && m3_bit(E.sracc[s], cell);
-      if (__ballot(hit) != 0) {
-        if (c.lane == 0) E.hdr[s].valid = 0;
+  if (M3_BALLOT(chg) != 0) {
+    for (int s = 0; s < c.L.n_slots; s++) {
+      if (__builtin_amdgcn_readfirstlane((int)c.hdr(s)->valid) == 0) continue;
+      const bool hit = chg && m3_bit(c.racc(s), cell);
+      if (M3_BALLOT(hit) != 0) {
+        if (c.lane == 0) c.hdr(s)->valid = 0;
         dropped |= 1u << s;
       }
     }
@@ -408,137 +474,225 @@ __device__ inline uint32_t m3_update_moves(M3Env<SC> &E, const M3Ctx &c, int ex,
 //     trip (rare), which then runs first in the next trip;
 //   * the head-room test of :443-445 never fails here: every rule of _passable checks the head-room of its target, and
 //     the start cells have it;
-//   * a successor is queued unless it is known to be a no-op when popped (`best` of its cell -- as read in this trip:
-//     `best` only decreases -- not longer); while the queue is short the check is skipped (it is one more dependent LDS
-//     round trip per trip) and such entries are rejected when popped, like in the reference;
+//   * a successor is queued unless it is known to be a no-op when popped: the move straight back to the cell the entry
+//     came from (its `best` is at most the parent's length, which is below the entry's), and -- while the queue is long;
+//     the check is one more dependent LDS round trip -- any target whose `best`, as read in this trip (`best` only
+//     decreases), is not longer.  Entries that turn out to be no-ops later are rejected when popped, like in the reference;
 //   * first-visit order and queue order are kept with prefix counts over the lanes (entry-major, direction-minor).
+// CHAIN MODE.  With a single entry in the queue (corridors: where a search spends its trips) the entry stays in scalar
+// registers: one LDS round trip returns `best` and the four move bytes of its cell, the accept test is scalar, lanes
+// 0..3 evaluate the directions, and a single successor is handed to the next trip by a lane read instead of through the
+// queue.
 // `best` entries carry the search's epoch, so nothing is cleared between searches.
 template <int SC>
-__device__ inline int m3_search(M3Work<SC> &W, const uint8_t *mv, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip,
-                                bool &overflow PHASE_ARG) {
+__device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip, bool &overflow PHASE_ARG) {
   constexpr int RING = M3C<SC>::RING, RM = RING - 1;
-  epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch) + 1u;
-  if (epoch > 255u) {  // wrapped: clear the table once
+  const uint8_t *mv = c.mv;
+  uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch) + 1u;
+  if (ep > 255u) {  // wrapped: clear the table once
     for (int i = c.lane; i < c.n_cells; i += 64) W.best[i].x = 0;
-    epoch = 1;
+    ep = 1;
   }
-  if (c.lane == 0) W.ent[0] = make_uint2((uint32_t)root, 1u);
-  int head = 0, tail = 1, n_order = 0;
+  ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+  epoch = ep;
+  uint32_t tr = (uint32_t)__builtin_amdgcn_readfirstlane((int)trip);
+  int head = 0, tail = 0, n_order = 0;
   const int slot_i = c.lane >> 2, d = c.lane & 3;
   const int dq = m3_dy(d) * c.X + m3_dx(d);  // column-index step of this lane's direction
-  const uint32_t lt_lo = c.lane < 32 ? (1u << c.lane) - 1u : 0xFFFFFFFFu, lt_hi = c.lane < 32 ? 0u : (1u << (c.lane - 32)) - 1u;
-  auto below = [&](uint64_t b) { return __popc((uint32_t)b & lt_lo) + __popc((uint32_t)(b >> 32) & lt_hi); };
-  const uint32_t ep24 = epoch << 24;
+  const uint32_t ep24 = ep << 24;
 #ifdef PCGRL_PHASE_TIMING
-  int dbg_trips = 0;
+  int dbg_trips = 0, dbg_pushed = 1;
+  const uint64_t dbg_t0 = __builtin_readcyclecounter();
+#ifdef PCGRL_M3_TRIPS
+  uint64_t dbg_tt = dbg_t0;
+  int dbg_kind = -1;
+#define M3_TRIP_KIND(kind)                                                      \
+  do {                                                                          \
+    const uint64_t t_ = __builtin_readcyclecounter();                           \
+    if (dbg_kind >= 0) _ph[2 + dbg_kind] += (uint32_t)(t_ - dbg_tt);            \
+    dbg_tt = t_;                                                                \
+    dbg_kind = (kind);                                                          \
+    _ph[dbg_kind] += 1;                                                         \
+  } while (0)
+#else
+#define M3_TRIP_KIND(kind) dbg_trips++
 #endif
-  while (head < tail) {
+#else
+#define M3_TRIP_KIND(kind) \
+  do {                     \
+  } while (0)
+#endif
+  // the entry in hand (chain mode), in scalar registers; the root has no parent
+  // (loop-carried in vector registers, read back with v_readfirstlane at the top of a trip: that keeps the trip's
+  // arithmetic and, above all, its branches on the scalar unit)
+  uint32_t exv = (uint32_t)root, eyv = 1u | (0xFFFFFu << 12);
+  bool in_hand = true;
+  for (;;) {
+    // ---- chain trips: everything about the entry is scalar, the queue is empty
+    while (in_hand) {
+      M3_TRIP_KIND(0);
+      const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)exv), ey = (uint32_t)__builtin_amdgcn_readfirstlane((int)eyv);
+      const int cell = (int)(ex & 0xFFFu), parent = (int)(ey >> 12);
+      const uint32_t len = ey & 0xFFFu;
+      const uint32_t bxv = W.best[cell].x, mwv = ((const uint32_t *)mv)[cell];  // (one LDS round trip)
+      const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)bxv);
+      const uint32_t mw = (uint32_t)__builtin_amdgcn_readfirstlane((int)mwv);
+      const bool seen = (bx >> 24) == ep;
+      in_hand = false;
+      if (seen && (bx & 0xFFFFFFu) <= len) break;  // :437-440 not shorter: dropped; the queue is empty, the search is over
+      if (c.lane == 0) {
+        if (!seen) W.order[n_order] = (uint16_t)cell;
+        W.best[cell].x = ep24 | len;
+        W.info[cell] = ex >> 12;
+      }
+      n_order += seen ? 0 : 1;
+      const uint32_t m = c.lane < 4 ? (mw >> (8 * c.lane)) & 0xFFu : 0u;
+      const int tcell = cell + dq + ((m & 16u) ? dq : 0) + ((int)((m >> 2) & 3u) - 1) * c.YX;
+      const bool ok = (m != 0u) & (tcell != parent);
+      const uint32_t okb = (uint32_t)M3_BALLOT(ok);
+      const uint32_t nj = (ex >> 12) & 0xFFFu;
+      const uint32_t cx = (uint32_t)tcell | ((nj + ((m >> 4) & 1u)) << 12) | (m << 24) | ((uint32_t)d << 30);
+      const uint32_t cy = (len + (m & 3u)) | ((uint32_t)cell << 12);
+      if (okb == 0u) break;
+      if ((okb & (okb - 1u)) != 0u) {  // several successors: through the queue
+        const int npush = __popc(okb);
+        tail = __builtin_amdgcn_readfirstlane(tail);
+        if (ok) W.ent[(tail + m3_below((uint64_t)okb)) & RM] = make_uint2(cx, cy);
+        tail += npush;
 #ifdef PCGRL_PHASE_TIMING
-    dbg_trips++;
+        dbg_pushed += npush;
 #endif
-    trip = (uint32_t)__builtin_amdgcn_readfirstlane((int)trip) + 1u;
+        break;
+      }
+      const int l = __builtin_ctz(okb);  // one successor: it is the next entry
+      exv = (uint32_t)__builtin_amdgcn_readlane((int)cx, l);
+      eyv = (uint32_t)__builtin_amdgcn_readlane((int)cy, l);
+      in_hand = true;
+#ifdef PCGRL_PHASE_TIMING
+      dbg_pushed++;
+#endif
+    }
     head = __builtin_amdgcn_readfirstlane(head);
     tail = __builtin_amdgcn_readfirstlane(tail);
+    if (head >= tail) break;
+    if (tail - head == 1) {  // take the only entry in hand
+      const uint2 e = W.ent[head & RM];
+      exv = e.x;
+      eyv = e.y;
+      head++;
+      in_hand = true;
+      continue;
+    }
+    // ---- general trip: up to 16 entries
+    M3_TRIP_KIND(1);
+    tr++;
     const int nb = min(16, tail - head);
     const bool live = slot_i < nb;
     const int id = head + (live ? slot_i : 0);
     const uint2 e = W.ent[id & RM];
-    const int cell = (int)(e.x & 0xFFFu);
-    const uint32_t len = e.y;
-    const uint32_t stamp = ((0x0FFFFFFFu - trip) << 4) | (uint32_t)slot_i;
+    const int cell = (int)(e.x & 0xFFFu), parent = (int)(e.y >> 12);
+    const uint32_t len = e.y & 0xFFFu;
+    const uint32_t stamp = ((0x0FFFFFFFu - tr) << 4) | (uint32_t)slot_i;
     if (live && d == 0) atomicMin(&W.best[cell].y, stamp);
     const uint2 b = W.best[cell];
     const uint32_t m = mv[cell * 4 + d];
-    const bool seen = (b.x >> 24) == epoch;
+    const bool seen = (b.x >> 24) == ep;
     // :437-440 (an entry that is not shorter is dropped)
     const bool accept = live & !(seen & ((b.x & 0xFFFFFFu) <= len));
     // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
-    const uint64_t dupb = __ballot(accept & (d == 0) & (b.y != stamp));
+    const uint64_t dupb = M3_BALLOT(accept & (d == 0) & (b.y != stamp));
     const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
     const bool doit = accept & (slot_i < nproc);
     const bool acc0 = doit & (d == 0);
     const bool first = acc0 & !seen;
-    const uint64_t fb = __ballot(first);
-    if (first) W.order[n_order + below(fb)] = (uint16_t)cell;
+    const uint64_t fb = M3_BALLOT(first);
+    if (first) W.order[n_order + m3_below(fb)] = (uint16_t)cell;
     n_order += __popcll(fb);
     if (acc0) {
       W.best[cell].x = ep24 | len;
       W.info[cell] = e.x >> 12;
     }
     // successor in direction d: one byte of the move table
-    const uint32_t jump = (m >> 4) & 1u;
-    const int tcell = cell + dq + (jump ? dq : 0) + ((int)((m >> 2) & 3u) - 1) * c.YX;
+    const int tcell = cell + dq + ((m & 16u) ? dq : 0) + ((int)((m >> 2) & 3u) - 1) * c.YX;
     const uint32_t tlen = len + (m & 3u);
-    bool ok = doit & (m != 0u);
+    bool ok = doit & (m != 0u) & (tcell != parent);
     if (tail - head > 32) {  // never queue what is known to be a no-op when popped
       const uint32_t bt = W.best[ok ? tcell : 0].x;
-      ok &= !(((bt >> 24) == epoch) & ((bt & 0xFFFFFFu) <= tlen));
+      ok &= !(((bt >> 24) == ep) & ((bt & 0xFFFFFFu) <= tlen));
     }
-    const uint64_t okb = __ballot(ok);
+    const uint64_t okb = M3_BALLOT(ok);
     const int npush = __popcll(okb);
     if (tail + npush - head > RING) {
       overflow = true;
       break;
     }
     if (ok)
-      W.ent[(tail + below(okb)) & RM] =
-          make_uint2((uint32_t)tcell | ((((e.x >> 12) & 0xFFFu) + jump) << 12) | (m << 24) | ((uint32_t)d << 30), tlen);
+      W.ent[(tail + m3_below(okb)) & RM] = make_uint2(
+          (uint32_t)tcell | ((((e.x >> 12) & 0xFFFu) + ((m >> 4) & 1u)) << 12) | (m << 24) | ((uint32_t)d << 30), tlen | ((uint32_t)cell << 12));
     tail += npush;
     head += nproc;
-  }
 #ifdef PCGRL_PHASE_TIMING
-  (void)_ph;
-  (void)_t_prev;
+    dbg_pushed += npush;
 #endif
+  }
+  trip = tr;
+#if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_TRIPS)
+  if (dbg_kind >= 0) _ph[2 + dbg_kind] += (uint32_t)(__builtin_readcyclecounter() - dbg_tt);
+  (void)_t_prev;
+  (void)dbg_trips;
+  (void)dbg_pushed;
+#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES)
+  (void)_t_prev;
+  _ph[0] += (uint32_t)dbg_trips;
+  _ph[1] += (uint32_t)dbg_pushed;
+  _ph[2] += 1;
+  _ph[3] += (uint32_t)(__builtin_readcyclecounter() - dbg_t0);
+#elif defined(PCGRL_PHASE_TIMING)
+  (void)_t_prev;
+  (void)_ph;
+  (void)dbg_trips;
+  (void)dbg_pushed;
+  (void)dbg_t0;
+#endif
+#undef M3_TRIP_KIND
   return n_order;
 }
 
-// first maximum of len(path) in first-insertion order (helper_3D.py:538-541); returns the cell
+// After a search: the first maximum of len(path) in first-insertion order (helper_3D.py:538-541) -> far; the accepted
+// cells -> W.racc; returns the coordinate values of those cells (bit v set if some accepted cell has x, y or z == v: the
+// marks of :531).
 template <int SC>
-__device__ inline int m3_farthest(const M3Work<SC> &W, const M3Ctx &c, int n_order) {
-  uint32_t key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
+__device__ inline uint32_t m3_collect(M3Work<SC> &W, const M3Ctx &c, int n_order, int &far) {
+  uint32_t mkl = 0, key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
   for (int k = c.lane; k < n_order; k += 64) {
-    const uint32_t len = W.best[W.order[k]].x & 0xFFFFu;
+    const int ci = W.order[k];
+    const uint32_t len = W.best[ci].x & 0xFFFFu;
     const uint32_t kk = (len << 16) | (uint32_t)(0xFFFF - k);
     key = kk > key ? kk : key;
-  }
-  key = wave_max(key);
-  return W.order[0xFFFF - (int)(key & 0xFFFF)];
-}
-
-// accepted cells of the search just run -> W.racc; returns the coordinate values of those cells (bit v set if some
-// accepted cell has x, y or z == v: the marks of :531)
-template <int SC>
-__device__ inline uint32_t m3_collect(M3Work<SC> &W, const M3Ctx &c, int n_order) {
-  uint32_t mkl = 0;
-  for (int i = c.lane; i < n_order; i += 64) {
-    const int ci = W.order[i];
     const int z = ci / c.YX, q = ci - z * c.YX, y = q / c.X, x = q - y * c.X;
     mkl |= (1u << x) | (1u << y) | (1u << z);
     atomicOr(&W.racc[ci >> 5], 1u << (ci & 31));
   }
+  key = wave_max(key);
+  far = W.order[0xFFFF - (int)(key & 0xFFFF)];
   return wave_or(mkl);
 }
 
-// The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s of E (result + accepted cells).
+// The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s of the env (result + accepted cells).
 template <int SC>
-__device__ inline void m3_fill_slot(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch,
-                                    uint32_t &trip, bool &overflow PHASE_ARG) {
+__device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch, uint32_t &trip,
+                                    bool &overflow PHASE_ARG) {
   constexpr int NW = M3C<SC>::NW;
-  if (c.lane == 0) E.hdr[s].valid = 0;
-  for (int i = c.lane; i < c.nw; i += 64) {
-    W.racc[i] = 0;
-    W.pathm[i] = 0;
-  }
+  if (c.lane == 0) c.hdr(s)->valid = 0;
+  for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
   const int root = sz * c.YX + start_bit;
-  int n_order = m3_search(W, E.mv, c, root, epoch, trip, overflow PHASE_PASS);
+  int n_order = m3_search(W, c, root, epoch, trip, overflow PHASE_PASS);
   if (overflow) return;
-  const uint32_t mk = m3_collect(W, c, n_order);
-  const int far1 = m3_farthest(W, c, n_order);
-  n_order = m3_search(W, E.mv, c, far1, epoch, trip, overflow PHASE_PASS);
+  int far1 = 0, far2 = 0;
+  const uint32_t mk = m3_collect(W, c, n_order, far1);
+  n_order = m3_search(W, c, far1, epoch, trip, overflow PHASE_PASS);
   if (overflow) return;
-  (void)m3_collect(W, c, n_order);
-  const int far2 = m3_farthest(W, c, n_order);
+  (void)m3_collect(W, c, n_order, far2);
   // The tiles of paths[(mx,my,mz)] as a bit mask: the accepted entries form a tree (an accepted entry's parent is the
   // accepted entry of the parent cell: a strictly shorter path to the parent would have produced a strictly shorter,
   // hence accepted, entry for the child), so the chain is walked over cells.  An entry knows its move byte and direction,
@@ -552,7 +706,7 @@ __device__ inline void m3_fill_slot(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c,
     };
     int cell = far2;
     while (true) {
-      const uint32_t inf = W.info[cell];
+      const uint32_t inf = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.info[cell]);
       mark(cell);
       const uint32_t m = (inf >> 12) & 63u;
       if (m == 0u) break;  // the root
@@ -569,10 +723,12 @@ __device__ inline void m3_fill_slot(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c,
         cell = cell - dq - dz * c.YX;
       }
     }
-    if (c.lane < c.nw) E.spath[s][c.lane] = my0;
-    if (NW > 64 && c.lane + 64 < c.nw) E.spath[s][c.lane + 64] = my1;
+    uint32_t *sp = c.spath(s);
+    if (c.lane < c.L.nw) sp[c.lane] = my0;
+    if (NW > 64 && c.lane + 64 < c.L.nw) sp[c.lane + 64] = my1;
   }
-  for (int i = c.lane; i < c.nw; i += 64) E.sracc[s][i] = W.racc[i];
+  uint32_t *ra = c.racc(s);
+  for (int i = c.lane; i < c.L.nw; i += 64) ra[i] = W.racc[i];
   if (c.lane == 0) {
     M3SlotHdr h;
     h.start = (uint16_t)start_bit;
@@ -581,23 +737,18 @@ __device__ inline void m3_fill_slot(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c,
     h.n_jump = (uint16_t)(W.info[far2] & 0xFFFu);
     h.mk = mk & ((1u << c.Z) - 1u);
     h.pad_ = 0;
-    E.hdr[s] = h;
+    *c.hdr(s) = h;
   }
-#ifdef PCGRL_PHASE_TIMING
-  if (c.lane == 0) E.dbg[2] += 2;
-#endif
 }
 
-// helper_3D.calc_longest_path + remove_stacked_path_tiles + minecraft_3D_maze_prob.get_stats
-// air: this lane's plane (lanes < Z).  Results uniform over the wave.  E.over receives the new overlay mask.
+// helper_3D.calc_longest_path + remove_stacked_path_tiles (path-length, n_jump and the overlay of
+// minecraft_3D_maze_prob.get_stats; the caller supplies the region count).
+// air: this lane's plane (lanes < Z).  Results uniform over the wave.  c.over receives the new overlay mask.
 // Slots that are still valid (see SLOT CACHE) are reused; the caller invalidates them for fresh maps.
 template <int SC>
-__device__ inline void m3_stats(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<M3C<SC>::PW> air, PM<M3C<SC>::PW> notx0,
-                                PM<M3C<SC>::PW> notxl, int32_t *st, uint32_t &epoch, uint32_t &trip, uint32_t &filled,
-                                bool &overflow PHASE_ARG) {
+__device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<M3C<SC>::PW> air, int32_t *st, uint32_t &epoch,
+                                uint32_t &trip, uint32_t &filled, bool &overflow PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
-  st[0] = m3_regions<PW>(c, air, notx0, notxl);
-  PHASE_MARK(3);  // regions
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
   const PM<PW> above = pm_down(air), below = pm_up(air);
   const PM<PW> cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : pm_zero<PW>();
@@ -605,46 +756,54 @@ __device__ inline void m3_stats(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
   int final_value = 0, n_jump = 0, best_slot = -1;
   while (true) {
     const bool mine = c.lane < c.Z && pm_any(cand) && !((marked >> c.lane) & 1u);
-    const uint64_t b = __ballot(mine);
+    const uint64_t b = M3_BALLOT(mine);
     if (b == 0) break;
     const int sz = __builtin_ctzll(b);
     const int bit = __builtin_amdgcn_readlane(pm_ctz(cand), sz);
     const int s = sz - 1;
-    if (!(E.hdr[s].valid && E.hdr[s].start == bit)) {
-      m3_fill_slot(E, W, c, s, bit, sz, epoch, trip, overflow PHASE_PASS);
-      filled |= 1u << s;
-      if (overflow) break;
+    {
+      const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t *)c.hdr(s));  // start | valid << 16
+      if (!((h0 >> 16) != 0u && (int)(h0 & 0xFFFFu) == bit)) {
+        m3_fill_slot(W, c, s, bit, sz, epoch, trip, overflow PHASE_PASS);
+        filled |= 1u << s;
+        if (overflow) break;
+      }
     }
-    const M3SlotHdr h = E.hdr[s];
-    marked |= h.mk;
-    n_jump = h.n_jump;  // :553 overwritten by every processed component
-    if ((int)h.max_dist > final_value) {
-      final_value = h.max_dist;
+    const uint32_t h1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t *)c.hdr(s))[1]);  // max_dist | n_jump << 16
+    marked |= (uint32_t)__builtin_amdgcn_readfirstlane((int)c.hdr(s)->mk);
+    n_jump = (int)(h1 >> 16);  // :553 overwritten by every processed component
+    if ((int)(h1 & 0xFFFFu) > final_value) {
+      final_value = (int)(h1 & 0xFFFFu);
       best_slot = s;
     }
   }
-  PHASE_MARK(4);  // path searches
+  M3_MARK(3, 6);  // path searches (incl. the search loops counted in [3])
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
   // path tile (x,y,z) is drawn at array index [x][y][z]
-  for (int i = c.lane; i < c.nw + 4; i += 64) {
-    E.pathm[i] = (best_slot >= 0 && i < c.nw) ? E.spath[best_slot < 0 ? 0 : best_slot][i] : 0u;
-    E.over[i] = 0;
-  }
+  for (int i = c.lane; i < c.L.nw; i += 64) c.over[i] = 0;
+  if (best_slot >= 0) {
+    const uint32_t *pathm = c.spath(best_slot);
 #pragma unroll
-  for (int k = 0; k < PW; k++) {
-    const int q = 64 * k + c.lane, y = q / c.X, x = q - y * c.X;  // this lane's column (q < YX)
-    for (int z = 0; z < c.Z; z++) {
-      const int ci = z * c.YX + q;
-      const bool in = q < c.YX && m3_bit(E.pathm, ci) && !(z > 0 && m3_bit(E.pathm, ci - c.YX));
-      if (in && x < c.Z && z < c.X) {
-        const int oi = (x * c.Y + y) * c.X + z;
-        atomicOr(&E.over[oi >> 5], 1u << (oi & 31));
+    for (int k = 0; k < PW; k++) {
+      const int q = 64 * k + c.lane, y = q / c.X, x = q - y * c.X;  // this lane's column (q < YX)
+      // tiles of the column as a bit mask over z, then "no path tile directly below"
+      uint32_t colp = 0;
+      for (int z = 0; z < c.Z; z++) colp |= (q < c.YX && m3_bit(pathm, z * c.YX + q)) ? 1u << z : 0u;
+      uint32_t keep = colp & ~(colp << 1);
+      if (x >= c.Z) keep = 0;
+      while (keep) {
+        const int z = __builtin_ctz(keep);
+        keep &= keep - 1u;
+        if (z < c.X) {
+          const int oi = (x * c.Y + y) * c.X + z;
+          atomicOr(&c.over[oi >> 5], 1u << (oi & 31));
+        }
       }
     }
   }
   st[1] = final_value;
   st[2] = n_jump;
-  PHASE_MARK(5);  // overlay post-processing
+  M3_MARK(4, 5);  // overlay post-processing
 }
 
 // observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay
@@ -697,7 +856,7 @@ __device__ inline void m3_reset_rng(uint32_t *dirt, const M3Ctx &c, const Params
   total += p1;
   double c0 = p0 / total, c1 = c0 + p1 / total;
   c0 /= c1;  // cdf /= cdf[-1]
-  for (int i = c.lane; i < c.nw + 4; i += 64) dirt[i] = 0;
+  for (int i = c.lane; i < c.L.nw; i += 64) dirt[i] = 0;
   Pcg end = rr;
   end.jump(p.jump[64]);
   rr.jump(p.jump[c.lane]);
@@ -720,7 +879,7 @@ __device__ inline void m3_reset_rng(uint32_t *dirt, const M3Ctx &c, const Params
 
 // bytes -> bit string (caller-provided maps)
 __device__ inline void m3_load_bytes(uint32_t *dirt, const M3Ctx &c, const uint8_t *src) {
-  for (int i = c.lane; i < c.nw + 4; i += 64) dirt[i] = 0;
+  for (int i = c.lane; i < c.L.nw; i += 64) dirt[i] = 0;
   for (int ci = c.lane; ci < c.n_cells; ci += 64)
     if (src[ci]) atomicOr(&dirt[ci >> 5], 1u << (ci & 31));
 }
@@ -753,56 +912,58 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
   if (D7) cpl = 6;  // ceil(343 / 64)
   c.YX = c.Y * c.X;
   c.n_cells = c.Z * c.YX;
-  c.nw = m3_words(c.n_cells);
-  const int n_slots = c.Z - 2 > 0 ? c.Z - 2 : 0;  // start planes z = 1 .. Z-2
-  const int slot_words = M3_SLOT_HDR + 2 * c.nw;
+  c.L = m3_layout(c.Z, c.Y, c.X);
+  c.dirt = E.rec;
+  c.over = E.rec + c.L.o_over;
+  c.col = (uint16_t *)(E.rec + c.L.o_col);
+  c.slots = E.rec + c.L.o_slots;
+  c.mv = (uint8_t *)(E.rec + c.L.o_mv);
+  const int nw = c.L.nw, n_slots = c.L.n_slots;
   const int env = blockIdx.x;
   constexpr int NS = M3_NS;
   PHASE_DECL();
   TRACE_DECL();
-  uint32_t *gd = (uint32_t *)p.planes + (size_t)env * 2 * c.nw;  // [dirt words | overlay words]
-  uint32_t *gslot = (uint32_t *)p.m3cache + (size_t)env * slot_words * n_slots;
-  uint8_t *gmv = (uint8_t *)p.m3mv + (size_t)env * c.n_cells * 4;
+  uint32_t *grec = (uint32_t *)p.planes + (size_t)env * c.L.rec_words;
   EnvState *S = &p.st[env];
 
   if constexpr (MODE == M3_STEP) {
     // ------------------------------------------------------------------------------------------ observe wave
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {  // (readfirstlane: a scalar branch)
       if (p.obs == nullptr) return;  // (the simulate wave skips the barrier in that case, too)
-      for (int i = c.lane; i < c.nw + 4; i += 64) {
-        O.dirt[i] = i < c.nw ? gd[i] : 0u;
-        O.over[i] = i < c.nw ? gd[c.nw + i] : 0u;
-      }
+      // everything this wave needs of the old state is requested at once; an auto-reset replays the env's RNG streams in
+      // both waves, so it takes its copy of them, too
+      for (int i = c.lane; i < 2 * nw; i += 64) O.bits[i] = grec[i];
       int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
       int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
       const int action = p.actions[env];
       const bool upd_only = p.update_only != 0;
-      // an auto-reset replays the env's RNG streams in both waves; this wave takes its copy before the barrier
       Pcg rp, rr;
-      if (p.auto_reset != 0 && (iteration + 1 > p.cfg.max_iterations || p.cfg.max_changes >= 0)) {
-        rp.load(p.rng[env].prob);
-        rr.load(p.rng[env].rep);
-      }
-      __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
+      rp.load(p.rng[env].prob);
+      rr.load(p.rng[env].rep);
+      uint32_t *odirt = O.bits, *oover = O.bits + nw;
       iteration += upd_only ? 0 : 1;
       bool change = false;
       if (action >= 0 && action < 2) {
         const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
-        change = m3_bit(O.dirt, ci) != (action != 0);
-        if (change && c.lane == 0) O.dirt[ci >> 5] ^= 1u << (ci & 31);
+        change = m3_bit(odirt, ci) != (action != 0);
+        if (change && c.lane == 0) odirt[ci >> 5] ^= 1u << (ci & 31);
         m3_advance_pos(c, pos, n_step);
       }
       changes += (change && !upd_only) ? 1 : 0;
       bool done = !upd_only && iteration > p.cfg.max_iterations;
       if (p.cfg.max_changes >= 0) done = done || (!upd_only && changes > p.cfg.max_changes);
       if (done && p.auto_reset != 0) {  // first observation of the new episode: no overlay (PcgrlEnv.reset)
-        m3_reset_rng(O.dirt, c, p, cpl, rp, rr);
+        m3_reset_rng(odirt, c, p, cpl, rp, rr);
         pos[0] = pos[1] = pos[2] = 0;
-        m3_encode_obs(O.dirt, O.over, c, p, env, pos, false);
+        m3_encode_obs(odirt, oover, c, p, env, pos, false);
       } else {
-        m3_encode_obs(O.dirt, O.over, c, p, env, pos, true);
+        m3_encode_obs(odirt, oover, c, p, env, pos, true);
       }
       TRACE_PUT(3, TRACE_NOW());
+      // the simulate wave overwrites the env's state only after this wave has read it: it waits at the same barrier just
+      // before its write-back, by which time this wave is long done (the barrier is at the END of both so that neither
+      // wave's work waits for the other's loads)
+      __syncthreads();
       return;
     }
     __builtin_amdgcn_s_setprio(3);  // the simulate wave's dependent chain issues ahead of the observe wave on its SIMD
@@ -810,7 +971,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
 
   if constexpr (MODE == M3_GET_STATE) {
     if (p.out_grids)
-      for (int ci = c.lane; ci < c.n_cells; ci += 64) p.out_grids[(size_t)env * c.n_cells + ci] = (gd[ci >> 5] >> (ci & 31)) & 1u;
+      for (int ci = c.lane; ci < c.n_cells; ci += 64) p.out_grids[(size_t)env * c.n_cells + ci] = (grec[ci >> 5] >> (ci & 31)) & 1u;
     if (c.lane == 0) {
       if (p.out_pos)
         for (int d = 0; d < 3; d++) p.out_pos[(size_t)env * 3 + d] = S->pos[d];
@@ -827,6 +988,13 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     }
     return;
   }
+  if constexpr (MODE == M3_OBSERVE) {
+    // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
+    for (int i = c.lane; i < 2 * nw; i += 64) E.rec[i] = grec[i];
+    const int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
+    m3_encode_obs(c.dirt, c.over, c, p, env, pos, false);
+    return;
+  }
 
   // search tables of this wave
   uint32_t epoch = 0, trip = 0;
@@ -839,33 +1007,23 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
   auto plane_of = [&](const uint32_t *dirt) { return c.lane < c.Z ? m3_plane_air<PW>(dirt, c, c.lane) : pm_zero<PW>(); };
   // statistics of a map the kernel has not seen before: columns, move table, no cached slots
   auto fresh_stats = [&](int32_t *st, bool &ovf) {
-    const PM<PW> air = plane_of(E.dirt);
-    m3_build_cols<SC>(E, c, air);
-    m3_build_moves<SC>(E, c);
-    if (c.lane < M3C<SC>::SLOTS) E.hdr[c.lane].valid = 0;
+    const PM<PW> air = plane_of(c.dirt);
+    for (int i = c.lane; i < c.L.o_slots - c.L.o_col; i += 64) E.rec[c.L.o_col + i] = 0;
+    m3_build_cols<PW>(c, air);
+    m3_build_moves(c);
+    if (c.lane < n_slots) c.hdr(c.lane)->valid = 0;
     dirty_hdr = (1u << n_slots) - 1u;
-    PHASE_MARK(2);  // column masks + move table
-    m3_stats<SC>(E, W, c, air, notx0, notxl, st, epoch, trip, dirty_full, ovf PHASE_PASS);
+    M3_MARK(6, 5);  // column masks + move table
+    st[0] = m3_regions<PW>(c, air, notx0, notxl);
+    M3_MARK(2, 4);  // regions
+    m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf PHASE_PASS);
   };
-  auto store_moves = [&]() {
-    const int n4 = c.n_cells;  // 4 bytes per cell
-    for (int i = c.lane; i < n4; i += 64) ((uint32_t *)gmv)[i] = ((const uint32_t *)E.mv)[i];
-  };
-  auto store_slots = [&]() {
-    for (int s = 0; s < n_slots; s++) {
-      if ((((dirty_hdr | dirty_full) >> s) & 1u) == 0u) continue;
-      uint32_t *g = gslot + (size_t)s * slot_words;
-      if (c.lane < M3_SLOT_HDR) g[c.lane] = ((const uint32_t *)&E.hdr[s])[c.lane];
-      if ((dirty_full >> s) & 1u)
-        for (int i = c.lane; i < c.nw; i += 64) {
-          g[M3_SLOT_HDR + i] = E.sracc[s][i];
-          g[M3_SLOT_HDR + c.nw + i] = E.spath[s][i];
-        }
-    }
+  auto store_record = [&]() {  // the whole record
+    for (int i = c.lane; i < c.L.rec_words / 4; i += 64) ((uint4 *)grec)[i] = ((const uint4 *)E.rec)[i];
   };
 
   if constexpr (MODE == M3_STATS_FOR_GRIDS) {
-    m3_load_bytes(E.dirt, c, p.init_grids + (size_t)env * c.n_cells);
+    m3_load_bytes(c.dirt, c, p.init_grids + (size_t)env * c.n_cells);
     init_work();
     int32_t st[NS] = {0, 0, 0};
     bool ovf = false;
@@ -876,51 +1034,20 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     return;
   }
 
-  // load grid + overlay
-  for (int i = c.lane; i < c.nw + 4; i += 64) {
-    E.dirt[i] = i < c.nw ? gd[i] : 0u;
-    E.over[i] = i < c.nw ? gd[c.nw + i] : 0u;
-  }
-  int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
-
-  if constexpr (MODE == M3_OBSERVE) {
-    // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
-    m3_encode_obs(E.dirt, E.over, c, p, env, pos, false);
-    return;
-  }
-  if constexpr (MODE != M3_RESET) {  // the move table and the slot cache
-    for (int i = c.lane; i < c.n_cells; i += 64) ((uint32_t *)E.mv)[i] = ((const uint32_t *)gmv)[i];
-    for (int s = 0; s < n_slots; s++) {
-      const uint32_t *g = gslot + (size_t)s * slot_words;
-      if (c.lane < M3_SLOT_HDR) ((uint32_t *)&E.hdr[s])[c.lane] = g[c.lane];
-      for (int i = c.lane; i < c.nw; i += 64) {
-        E.sracc[s][i] = g[M3_SLOT_HDR + i];
-        E.spath[s][i] = g[M3_SLOT_HDR + c.nw + i];
-      }
-    }
-  }
-  init_work();
-#ifdef PCGRL_PHASE_TIMING
-  if (c.lane < 8) E.dbg[c.lane] = 0;
-#endif
-
-  int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
-  double last_loss = S->last_loss, ep_return = S->ep_return;
   int32_t st[NS];
-  for (int k = 0; k < NS; k++) st[k] = S->stats[k];
-  bool ovf = false, moves_dirty = false;
+  bool ovf = false;
   EnvTargets<NS> trg;
-  trg.load(p, env, false);
   Pcg rp, rr;
 
   if constexpr (MODE == M3_RESET) {
     if (p.mask != nullptr && p.mask[env] == 0) return;
+    for (int i = c.lane; i < 2 * nw; i += 64) E.rec[i] = grec[i];
+    init_work();
+    trg.load(p, env, false);
     if (p.refresh_only) {  // statistics (and the path overlay) of the current map, nothing else
       fresh_stats(st, ovf);
       if (ovf && c.lane == 0) atomicOr(p.err, 4);
-      for (int i = c.lane; i < c.nw; i += 64) gd[c.nw + i] = E.over[i];
-      store_moves();
-      store_slots();
+      store_record();
       if (c.lane == 0) {
         S->last_loss = trg.loss(p.cfg, st);
         S->flags = 0;
@@ -931,25 +1058,23 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       }
       return;
     }
+    int pos[3] = {0, 0, 0};
     if (p.init_grids) {
-      m3_load_bytes(E.dirt, c, p.init_grids + (size_t)env * c.n_cells);
-      pos[0] = pos[1] = pos[2] = 0;
+      m3_load_bytes(c.dirt, c, p.init_grids + (size_t)env * c.n_cells);
       if (p.init_pos)
         for (int d = 0; d < 3; d++) pos[d] = p.init_pos[(size_t)env * 3 + d];
     } else {
       rp.load(p.rng[env].prob);
       rr.load(p.rng[env].rep);
-      m3_reset_rng(E.dirt, c, p, cpl, rp, rr);
+      m3_reset_rng(c.dirt, c, p, cpl, rp, rr);
       if (c.lane == 0) {
         rr.store(p.rng[env].rep);
         rp.store(p.rng[env].prob);
       }
-      pos[0] = pos[1] = pos[2] = 0;
     }
     fresh_stats(st, ovf);
-    moves_dirty = true;
-    n_step = iteration = changes = 0;
-    ep_return = 0.0;
+    int n_step = 0, iteration = 0, changes = 0;
+    double ep_return = 0.0;
     if (p.set_state) {  // pcgrl_set_state: injected map, the caller's counters / return
       if (p.in_counters) {
         iteration = p.in_counters[(size_t)env * 4 + 0];
@@ -959,133 +1084,205 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       if (p.in_ep_return) ep_return = p.in_ep_return[env];
     }
     trg.load(p, env, true);
-    last_loss = trg.loss(p.cfg, st);
-  } else {
-   const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;
-   const size_t N = (size_t)p.n_envs;
-   rp.load(p.rng[env].prob);  // (only advanced by an auto-reset)
-   rr.load(p.rng[env].rep);
-   bool any_reset = false;
-   if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();  // the observe wave has taken its copy of the old state
-   {  // column masks of the current map (the move rules of an edit read them)
-     const PM<PW> air0 = plane_of(E.dirt);
-     m3_build_cols<SC>(E, c, air0);
-   }
-   for (int k = 0; k < K; k++) {
-    const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
-    uint8_t *obs_k = p.obs == nullptr ? nullptr
-                     : (MODE == M3_ROLLOUT && !p.obs_last_only ? p.obs + (size_t)k * N * (size_t)p.obs_env_bytes : p.obs);
-    const bool want_obs = MODE == M3_ROLLOUT && (!p.obs_last_only || k == K - 1);  // (M3_STEP: the observe wave)
-    // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
-    const int action = p.actions[o];
-    const bool bad = action < 0 || action >= 2;
-    const bool upd_only = p.update_only != 0;
-    iteration += upd_only ? 0 : 1;
-    bool change = false;
-    if (!bad) {
-      const int ci = m3_cell(c, pos[2], pos[1], pos[0]);  // pos = (z, y, x)
-      const bool old = m3_bit(E.dirt, ci);
-      change = old != (action != 0);
-      if (change) {
-        if (c.lane == 0) {
-          E.dirt[ci >> 5] ^= 1u << (ci & 31);
-          E.col[pos[1] * c.X + pos[2]] ^= (uint16_t)(1u << pos[0]);
-        }
-        // the edit changes at most 48 bytes of the move table and drops exactly the slots that accepted one of their cells
-        dirty_hdr |= m3_update_moves<SC>(E, c, pos[2], pos[1], pos[0], gmv, n_slots);
-      }
-      m3_advance_pos(c, pos, n_step);
-    } else if (c.lane == 0) {
-      atomicOr(p.err, 1);
-    }
-    if (upd_only) {  // rep.update() only: map, position (the observe wave shows the stale overlay)
-      for (int i = c.lane; i < c.nw; i += 64) gd[i] = E.dirt[i];
-      store_slots();  // (headers of the dropped slots)
-      if (c.lane == 0) {
-        S->pos[0] = pos[0];
-        S->pos[1] = pos[1];
-        S->pos[2] = pos[2];
-        S->n_step = n_step;
-      }
-      return;
-    }
-    changes += change ? 1 : 0;
-    bool done = iteration > p.cfg.max_iterations;
-    if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
-    const bool do_reset = done && p.auto_reset != 0;
-    // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
-    // the previous stats update on the already edited map
-    PHASE_MARK(0);  // loads + action
-    if (!do_reset && want_obs) m3_encode_obs(E.dirt, E.over, c, p, env, pos, true, obs_k);
-    PHASE_MARK(1);  // observation
-    if (change) {
-      const PM<PW> air = plane_of(E.dirt);
-      const int32_t st_old[NS] = {st[0], st[1], st[2]};
-      m3_stats<SC>(E, W, c, air, notx0, notxl, st, epoch, trip, dirty_full, ovf PHASE_PASS);
-      if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
-        for (int i = 0; i < NS; i++) st[i] = st_old[i];
-    }
-    const double loss = trg.loss(p.cfg, st);
-    const double rew = loss - last_loss;
-    last_loss = loss;
-    ep_return += rew;
+    const double last_loss = trg.loss(p.cfg, st);
+    if (ovf && c.lane == 0) atomicOr(p.err, 4);
+    store_record();
     if (c.lane == 0) {
-      if (p.reward) p.reward[o] = (float)rew;
-      if (p.reward64) p.reward64[o] = rew;
-      if (p.done) p.done[o] = done ? 1 : 0;
-      if (p.stats_out)
-        for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
+      trg.write_ctrl_obs(p, env, st);
+      trg.commit(p, env);
+      S->pos[0] = pos[0];
+      S->pos[1] = pos[1];
+      S->pos[2] = pos[2];
+      S->n_step = n_step;
+      S->iteration = iteration;
+      S->changes = changes;
+      S->flags = 0;
+      S->last_loss = last_loss;
+      S->ep_return = ep_return;
+      for (int k = 0; k < NS; k++) S->stats[k] = st[k];
     }
-    if (do_reset) {
-      if (c.lane == 0) {
-        latch_episode<NS>(p, env, S, ep_return, iteration, st);
-        accumulate_episode<NS>(S);
+    return;
+  }
+
+  if constexpr (MODE == M3_STEP || MODE == M3_ROLLOUT) {
+    // ---- everything of the old state is requested before anything is waited for
+    constexpr int CH = SC == 0 ? (M3C<0>::REC / 4 + 63) / 64 : 1;  // 16-byte chunks of the record per lane (size class 0)
+    uint4 rch[CH];
+    if (SC == 0) {
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const int i = c.lane + 64 * k;
+        rch[k] = i < c.L.rec_words / 4 ? ((const uint4 *)grec)[i] : make_uint4(0u, 0u, 0u, 0u);
       }
-      m3_reset_rng(E.dirt, c, p, cpl, rp, rr);
-      any_reset = true;
-      pos[0] = pos[1] = pos[2] = 0;
-      fresh_stats(st, ovf);
-      moves_dirty = true;
-      n_step = iteration = changes = 0;
-      ep_return = 0.0;
-      trg.load(p, env, true);
-      last_loss = trg.loss(p.cfg, st);
-      if (want_obs) m3_encode_obs(E.dirt, E.over, c, p, env, pos, false, obs_k);
     }
-   }
-   if (any_reset && c.lane == 0) {
-     rr.store(p.rng[env].rep);
-     rp.store(p.rng[env].prob);
-   }
+    int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
+    int n_step = S->n_step, iteration = S->iteration, changes = S->changes, flags = S->flags;
+    double last_loss = S->last_loss, ep_return = S->ep_return;
+    for (int k = 0; k < NS; k++) st[k] = S->stats[k];
+    int action0 = p.actions[env];
+    trg.load(p, env, false);
+    init_work();
+    if (SC == 0) {
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const int i = c.lane + 64 * k;
+        if (i < c.L.rec_words / 4) ((uint4 *)E.rec)[i] = rch[k];
+      }
+    } else {
+      for (int i = c.lane; i < c.L.rec_words / 4; i += 64) ((uint4 *)E.rec)[i] = ((const uint4 *)grec)[i];
+    }
+    M3_MARK(0, 5);  // loads
+    const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;
+    const size_t N = (size_t)p.n_envs;
+    bool any_reset = false, whole_record = false, edited = false, mv_chg = false, upd_exit = false, over_dirty = false;
+    int mv_cell = 0, col_word = 0;
+    for (int k = 0; k < K; k++) {
+      const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
+      uint8_t *obs_k = p.obs == nullptr ? nullptr
+                       : (MODE == M3_ROLLOUT && !p.obs_last_only ? p.obs + (size_t)k * N * (size_t)p.obs_env_bytes : p.obs);
+      const bool want_obs = MODE == M3_ROLLOUT && (!p.obs_last_only || k == K - 1);  // (M3_STEP: the observe wave)
+      // ---- step (envs/pcgrl_env.py:267-342 with narrow_rep.py:89-102)
+      const int action = k == 0 ? action0 : p.actions[o];
+      const bool bad = action < 0 || action >= 2;
+      const bool upd_only = p.update_only != 0;
+      iteration += upd_only ? 0 : 1;
+      bool change = false;
+      int ex = 0, ey = 0, ez = 0;
+      if (!bad) {
+        ez = pos[0], ey = pos[1], ex = pos[2];  // pos = (z, y, x)
+        const int ci = m3_cell(c, ex, ey, ez);
+        const bool old = m3_bit(c.dirt, ci);
+        change = old != (action != 0);
+        if (change) {
+          if (c.lane == 0) {
+            c.dirt[ci >> 5] ^= 1u << (ci & 31);
+            c.col[ey * c.X + ex] ^= (uint16_t)(1u << ez);
+          }
+          col_word = (ey * c.X + ex) >> 1;
+          // the edit changes at most 48 bytes of the move table and drops exactly the slots that accepted one of their cells
+          if (edited) whole_record = true;  // (rollout: more than one edit per launch)
+          edited = true;
+          dirty_hdr |= m3_update_moves(c, ex, ey, ez, mv_chg, mv_cell);
+        }
+        m3_advance_pos(c, pos, n_step);
+      } else if (c.lane == 0) {
+        atomicOr(p.err, 1);
+      }
+      if (upd_only) {  // rep.update() only: map, position (the observe wave shows the stale overlay)
+        if (change) flags |= ENV_STATS_DIRTY;  // the region count is no longer that of the map
+        upd_exit = true;
+        break;
+      }
+      changes += change ? 1 : 0;
+      bool done = iteration > p.cfg.max_iterations;
+      if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
+      const bool do_reset = done && p.auto_reset != 0;
+      // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
+      // the previous stats update on the already edited map
+      M3_MARK(1, 5);  // action + move-table update
+      if (!do_reset && want_obs) m3_encode_obs(c.dirt, c.over, c, p, env, pos, true, obs_k);
+      M3_MARK(1, 5);  // observation (rollout mode)
+      if (change) {
+        const PM<PW> air = plane_of(c.dirt);
+        const int32_t st_old[NS] = {st[0], st[1], st[2]};
+        if (flags & ENV_STATS_DIRTY) {  // after pcgrl_update: from scratch, like the reference's get_stats
+          st[0] = m3_regions<PW>(c, air, notx0, notxl);
+        } else {
+          PM<PW> A = air;  // the planes without the edited cell
+          if (c.lane == ez) {
+            PM<PW> e = pm_zero<PW>();
+            pm_set(e, ey * c.X + ex);
+            A = A & ~e;
+          }
+          st[0] = m3_regions_update<PW>(c, A, notx0, notxl, ey * c.X + ex, ez, action == 0, st[0]);
+        }
+        flags &= ~ENV_STATS_DIRTY;
+        M3_MARK(2, 4);  // regions
+        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf PHASE_PASS);
+        over_dirty = true;
+        if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
+          for (int i = 0; i < NS; i++) st[i] = st_old[i];
+      }
+      const double loss = trg.loss(p.cfg, st);
+      const double rew = loss - last_loss;
+      last_loss = loss;
+      ep_return += rew;
+      if (c.lane == 0) {
+        if (p.reward) p.reward[o] = (float)rew;
+        if (p.reward64) p.reward64[o] = rew;
+        if (p.done) p.done[o] = done ? 1 : 0;
+        if (p.stats_out)
+          for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
+      }
+      if (do_reset) {
+        if (!any_reset) {
+          rp.load(p.rng[env].prob);  // (only this wave writes them, at the end)
+          rr.load(p.rng[env].rep);
+        }
+        if (c.lane == 0) {
+          latch_episode<NS>(p, env, S, ep_return, iteration, st);
+          accumulate_episode<NS>(S);
+        }
+        m3_reset_rng(c.dirt, c, p, cpl, rp, rr);
+        any_reset = true;
+        whole_record = true;
+        pos[0] = pos[1] = pos[2] = 0;
+        fresh_stats(st, ovf);
+        flags = 0;
+        n_step = iteration = changes = 0;
+        ep_return = 0.0;
+        trg.load(p, env, true);
+        last_loss = trg.loss(p.cfg, st);
+        if (want_obs) m3_encode_obs(c.dirt, c.over, c, p, env, pos, false, obs_k);
+      }
+    }
+    if (ovf && c.lane == 0) atomicOr(p.err, 4);
+    // ---- write back, once the observe wave has read the old state
+    if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();
+    if (whole_record) {
+      store_record();
+    } else {
+      if (edited) {  // the tile bits, one column mask, the changed rows of the move table
+        for (int i = c.lane; i < nw; i += 64) grec[i] = c.dirt[i];
+        if (c.lane == 0) grec[c.L.o_col + col_word] = E.rec[c.L.o_col + col_word];
+        if (mv_chg) grec[c.L.o_mv + mv_cell] = E.rec[c.L.o_mv + mv_cell];
+      }
+      if (over_dirty)  // new statistics: the overlay
+        for (int i = c.lane; i < nw; i += 64) grec[c.L.o_over + i] = c.over[i];
+      for (int s = 0; s < n_slots; s++) {
+        if ((((dirty_hdr | dirty_full) >> s) & 1u) == 0u) continue;
+        const int o0 = c.L.o_slots + s * c.L.slot_words;
+        const int n = ((dirty_full >> s) & 1u) ? c.L.slot_words : M3_SLOT_HDR;
+        for (int i = c.lane; i < n; i += 64) grec[o0 + i] = E.rec[o0 + i];
+      }
+    }
+    if (any_reset && c.lane == 0) {
+      rr.store(p.rng[env].rep);
+      rp.store(p.rng[env].prob);
+    }
+    if (c.lane == 0) {
+      S->pos[0] = pos[0];
+      S->pos[1] = pos[1];
+      S->pos[2] = pos[2];
+      S->n_step = n_step;
+      S->flags = flags;
+      if (!upd_exit) {
+        trg.write_ctrl_obs(p, env, st);
+        trg.commit(p, env);
+        S->iteration = iteration;
+        S->changes = changes;
+        S->last_loss = last_loss;
+        S->ep_return = ep_return;
+        for (int k = 0; k < NS; k++) S->stats[k] = st[k];
+      }
+    }
+    M3_MARK(5, 5);
+    PHASE_FLUSH();
+    TRACE_PUT(0, _tr0);
+    TRACE_PUT(1, TRACE_NOW());
+    TRACE_DRAIN();
+    TRACE_PUT(2, TRACE_NOW());
   }
-  if (ovf && c.lane == 0) atomicOr(p.err, 4);
-  // write back
-  for (int i = c.lane; i < c.nw; i += 64) {
-    gd[i] = E.dirt[i];
-    gd[c.nw + i] = E.over[i];
-  }
-  if (moves_dirty) store_moves();
-  store_slots();
-  if (c.lane == 0) {
-    trg.write_ctrl_obs(p, env, st);
-    trg.commit(p, env);
-    S->pos[0] = pos[0];
-    S->pos[1] = pos[1];
-    S->pos[2] = pos[2];
-    S->n_step = n_step;
-    S->iteration = iteration;
-    S->changes = changes;
-    S->flags = 0;
-    S->last_loss = last_loss;
-    S->ep_return = ep_return;
-    for (int k = 0; k < NS; k++) S->stats[k] = st[k];
-  }
-  PHASE_MARK(6);
-  PHASE_FLUSH();
-  TRACE_PUT(0, _tr0);
-  TRACE_PUT(1, TRACE_NOW());
-  TRACE_DRAIN();
-  TRACE_PUT(2, TRACE_NOW());
 }
 
 }  // namespace pcgrl

@@ -15,7 +15,7 @@ NAMES = ["loads+barrier", "action+state", "stats refresh (total)", "  flood", " 
          "loss/outputs/write-back"]
 
 if "--build" in sys.argv:
-    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",))
+    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",) + (("PCGRL_M3_PHASES",) if "--m3-phases" in sys.argv else ()) + (("PCGRL_M3_PHASES", "PCGRL_M3_TRIPS") if "--m3-trips" in sys.argv else ()))
     print("built", TIMING_LIB)
     sys.exit(0)
 
@@ -29,7 +29,12 @@ three_d = "--3d" in sys.argv
 soko = "--sokoban" in sys.argv  # sokoban-wide 16x16, 2048 envs (BASELINE C4)
 n, iters = (1024, 1000) if three_d else ((2048, 2000) if soko else (4096, 2000))
 if three_d:
-    NAMES = ["loads+action", "observation", "column masks", "regions", "path searches", "overlay", "loss/outputs/write-back"]
+    if "--m3-trips" in sys.argv:
+        NAMES = ["(count) chain trips", "(count) general trips", "chain-trip cycles", "general-trip cycles", "overlay", "outputs + write-back", "fresh tables"]
+    elif "--m3-phases" in sys.argv:
+        NAMES = ["loads until the barrier", "columns + move-table update", "regions", "candidate walk", "overlay", "outputs + write-back", "fresh tables (reset)"]
+    else:
+      NAMES = ["(count) trips", "(count) queue entries", "(count) searches", "  search loops", "regions", "everything else", "candidate walk incl. search loops"]
     env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
 elif soko:
     env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
@@ -55,7 +60,7 @@ for i, nm in enumerate(NAMES):
     cyc = float(out[i]) / (iters * blocks)
     if not nm.startswith("  "):
         tot += cyc
-    print(f"{nm:28s} {cyc:9.0f} cycles/launch/wave")
+    print(f"{nm:28s} {cyc:11.3f} cycles/launch/wave")
 print(f"{'sum of top-level phases':28s} {tot:9.0f}")
 wall = float(out[7]) / (iters * blocks)  # 100 MHz constant clock ticks
 print(f"simulate wave lifetime: {wall * 10:.0f} ns  => effective shader clock {sum(out[:7]) / (iters * blocks) / (wall * 10):.2f} GHz")

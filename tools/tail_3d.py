@@ -14,14 +14,14 @@ g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
 out = np.zeros(8 * n, np.uint64)
-names = ["trips", "trip:push", "n_searches", "trip:reads", "searches", "trip:accept", "trip:rules", "wall"]
+names = ["trips", "entries", "n_searches", "search loops", "regions", "everything else", "candidate walk", "wall"]
 rows = []
 for k in range(700):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
     if k >= 500:
         env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * n)
         a = out.reshape(n, 8).astype(np.float64)
-        tot = a[:, 4]
+        tot = a[:, 3:7].sum(1) - a[:, 3]  # regions + rest + candidate walk (which contains the search loops)
         i = int(tot.argmax())
         rows.append((tot.mean(), tot.max(), a[i, :8]))
     elif k == 499:
