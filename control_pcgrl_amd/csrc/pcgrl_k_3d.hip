@@ -24,7 +24,8 @@ static hipError_t launch_3d_sc(KernelId id, const Params &p, int cpl, hipStream_
 
 hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
-  const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7;
+  const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7 && p.cfg.obs_window[0] == 14 &&
+                  p.cfg.obs_window[1] == 14 && p.cfg.obs_window[2] == 14;
   if (d7 && id == K_STEP) {
     hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, true>), grid, dim3(128), 0, s, p, cpl);
     return hipGetLastError();

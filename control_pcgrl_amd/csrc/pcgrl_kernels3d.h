@@ -17,10 +17,10 @@
 //   all 64 lanes   move-table maintenance, farthest-cell arg-max, overlay post-processing, reset RNG
 //
 // MOVE TABLE.  helper_3D._passable (:214-319) is a pure function of the map around a foothold: for every (cell, direction)
-// at most one of its six rules applies.  The engine keeps that function as a table in HBM (one byte per cell and
-// direction: path cost, height change, jump flag; 0 = no move) and MAINTAINS it: an edit of one cell can change the moves
+// at most one of its six rules applies.  The engine keeps that function as a table in HBM (16 bits per cell and
+// direction: path cost, jump flag, height change, target cell - cell; 0 = no move) and MAINTAINS it: an edit of one cell can change the moves
 // of at most 48 (cell, direction) pairs -- the cells whose rules read the edited cell -- which 48 lanes re-evaluate at
-// once.  The path search then reads one byte per popped entry and direction instead of evaluating the rules.
+// once.  The path search then reads one entry per popped queue entry and direction instead of evaluating the rules.
 //
 // PATH SEARCH.  helper_3D.run_dijkstra is a FIFO label-correcting search whose pop order decides n_jump, the farthest
 // cell and the path drawn into the next observation, so the queue order is kept exactly (see m3_search).
@@ -58,12 +58,12 @@ struct M3C;
 template <>
 struct M3C<0> {
   static constexpr int CELLS = 512, NW = 16, PW = 1, RING = 1024, COLS = 64, SLOTS = 6, ZMAX = 8;
-  static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + CELLS + 4;  // upper bound of m3_layout().rec_words
+  static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + 2 * CELLS + 4;  // upper bound of m3_layout().rec_words
 };
 template <>
 struct M3C<1> {
   static constexpr int CELLS = 4096, NW = 128, PW = 4, RING = 4096, COLS = 256, SLOTS = 14, ZMAX = 16;
-  static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + CELLS + 4;
+  static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + 2 * CELLS + 4;
 };
 constexpr int M3_NS = 3;
 constexpr int M3_SLOT_HDR = 4;  // header words of a cached slot in HBM, followed by the accepted-cell set and the path tiles
@@ -80,7 +80,7 @@ __host__ __device__ inline int m3_words(int n_cells) { return (((n_cells + 31) >
 //   [o_over, +nw)      path-overlay bits of the last statistics update (transposed index, see m3_stats)
 //   [o_col, +cw)       per-(y,x) column masks: AIR bits over z, 16 bits per column
 //   [o_slots, ...)     Z-2 cached start-plane results: 4 header words + accepted cells (nw) + path tiles (nw) each
-//   [o_mv, +n_cells)   the move table, 4 bytes (directions) per cell
+//   [o_mv, +2*n_cells) the move table, 4 x 16 bits (directions) per cell
 struct M3Lay {
   int nw, n_slots, slot_words, o_over, o_col, o_slots, o_mv, rec_words;
 };
@@ -94,7 +94,7 @@ __host__ __device__ inline M3Lay m3_layout(int Z, int Y, int X) {
   L.o_col = 2 * L.nw;
   L.o_slots = L.o_col + ((((Y * X + 1) >> 1) + 1) & ~1);
   L.o_mv = L.o_slots + L.n_slots * L.slot_words;
-  L.rec_words = (L.o_mv + n_cells + 3) & ~3;
+  L.rec_words = (L.o_mv + 2 * n_cells + 3) & ~3;
   return L;
 }
 
@@ -230,9 +230,9 @@ static_assert(sizeof(M3SlotHdr) == 4 * M3_SLOT_HDR, "slot header layout");
 // workspace of one search wave
 template <int SC>
 struct M3Work {
-  uint2 ent[M3C<SC>::RING];         // queue ring: cell | njump<<12 | move byte<<24 | direction<<30 ; len | parent cell<<12
+  uint2 ent[M3C<SC>::RING];         // queue ring: cell | parent cell<<12 (0x1FFF: none) | move code<<25 | direction<<30 ; len
   uint2 best[M3C<SC>::CELLS];       // per cell: epoch<<24 | len of the accepted path (the `paths` dict) ; trip claim
-  uint32_t info[M3C<SC>::CELLS];    // per cell, of the accepted entry: njump | move byte<<12 | direction<<18
+  uint32_t info[M3C<SC>::CELLS];    // per cell, of the accepted entry: parent cell | move code<<13 | direction<<18
   uint16_t order[M3C<SC>::CELLS];   // cells in first-insertion order
   uint32_t racc[M3C<SC>::NW];       // accepted cells of the pair of searches being run (bit per cell)
 };
@@ -242,8 +242,9 @@ struct M3Env {
   alignas(16) uint32_t rec[M3C<SC>::REC + 4];
 };
 template <int SC>
-struct M3ObsLds {  // the observe wave's own copy of the tile and overlay bits
-  alignas(16) uint32_t bits[2 * M3C<SC>::NW];
+struct M3ObsLds {  // the observe wave's own copy of the tile and overlay bits + the row masks of its encoder
+  alignas(16) uint32_t bits[2 * M3C<SC>::NW + 2];
+  uint2 rows[SC == 0 ? 16 * 16 + 1 : 32 * 32 + 1];
 };
 
 struct M3Ctx {
@@ -252,7 +253,7 @@ struct M3Ctx {
   // views into the env's record in LDS
   uint32_t *dirt, *over, *slots;
   uint16_t *col;
-  uint8_t *mv;
+  int16_t *mv;  // [cell][direction]
   __device__ inline M3SlotHdr *hdr(int s) const { return (M3SlotHdr *)(slots + s * L.slot_words); }
   __device__ inline uint32_t *racc(int s) const { return slots + s * L.slot_words + M3_SLOT_HDR; }
   __device__ inline uint32_t *spath(int s) const { return slots + s * L.slot_words + M3_SLOT_HDR + L.nw; }
@@ -371,7 +372,7 @@ __device__ inline int m3_regions_update(const M3Ctx &c, PM<PW> A, PM<PW> notx0, 
 // window = AIR at height z-2+i (below the floor and above the ceiling read as not-AIR, which is what every rule's explicit
 // bounds check amounts to).  cc / cn / cj: AIR bits over z of the foothold's column, the neighbour column and the column
 // two steps away (n_in / j_in: inside the map).  The six rules are mutually exclusive.
-// Result: path cost (1..3) | (height change + 1) << 2 | jump << 4;  0 = no move in this direction.
+// Result: path cost (1..3) | jump << 2 | (height change + 1) << 3;  0 = no move in this direction.
 __device__ inline uint32_t m3_move(uint32_t cc, uint32_t cn, uint32_t cj, int z, bool n_in, bool j_in) {
   const uint32_t wn = ((cn << 2) >> z) & 0x3Fu, wj = ((cj << 2) >> z) & 0x3Fu, c4 = (cc >> (z + 2)) & 1u;
   // (bitwise on purpose: `&&` / `||` compile to exec-masked branches, these to mask arithmetic)
@@ -386,20 +387,22 @@ __device__ inline uint32_t m3_move(uint32_t cc, uint32_t cn, uint32_t cj, int z,
   const bool ok = n_in & (walk | down | up | jump);
   const uint32_t w = walk ? 1u : ((jup | jdown) ? 3u : 2u);
   const uint32_t dzp = 1u + ((up | jup) ? 1u : 0u) - ((down | jdown) ? 1u : 0u);
-  return ok ? (w | (dzp << 2) | (jump ? 16u : 0u)) : 0u;
+  return ok ? (w | (jump ? 4u : 0u) | (dzp << 3)) : 0u;
 }
 __device__ inline int m3_dx(int d) { return d == 0 ? 1 : (d == 2 ? -1 : 0); }  // helper_3D.py:220 direction order
 __device__ inline int m3_dy(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }
 
-// move byte of (x, y, z, d) from the column masks
-__device__ inline uint32_t m3_move_at(const M3Ctx &c, int x, int y, int z, int d) {
+// move-table entry of (x, y, z, d) from the column masks: code of m3_move | (target cell - cell) << 5, as int16
+__device__ inline int m3_move_at(const M3Ctx &c, int x, int y, int z, int d) {
   const int dx = m3_dx(d), dy = m3_dy(d);
   const int nx = x + dx, ny = y + dy, jx = nx + dx, jy = ny + dy;
   const bool n_in = ((unsigned)nx < (unsigned)c.X) & ((unsigned)ny < (unsigned)c.Y);
   const bool j_in = ((unsigned)jx < (unsigned)c.X) & ((unsigned)jy < (unsigned)c.Y);
   const int q = y * c.X + x, dq = dy * c.X + dx;
   const uint32_t cc = c.col[q], cn = c.col[n_in ? q + dq : 0], cj = c.col[j_in ? q + 2 * dq : 0];
-  return m3_move(cc, cn, cj, z, n_in, j_in);
+  const uint32_t m = m3_move(cc, cn, cj, z, n_in, j_in);
+  const int delta = dq + ((m & 4u) ? dq : 0) + ((int)((m >> 3) & 3u) - 1) * c.YX;
+  return m ? (int)(int16_t)((delta << 5) | (int)m) : 0;
 }
 
 // per-(y,x) column masks from the planes: lane q of pass k collects bit q of every plane
@@ -424,7 +427,7 @@ __device__ inline void m3_build_moves(const M3Ctx &c) {
   for (int i = c.lane; i < c.n_cells * 4; i += 64) {
     const int cell = i >> 2, d = i & 3;
     const int z = cell / c.YX, q = cell - z * c.YX, y = q / c.X, x = q - y * c.X;
-    c.mv[i] = (uint8_t)m3_move_at(c, x, y, z, d);
+    c.mv[i] = (int16_t)m3_move_at(c, x, y, z, d);
   }
 }
 
@@ -442,16 +445,25 @@ __device__ inline uint32_t m3_update_moves(const M3Ctx &c, int ex, int ey, int e
   const int sz = grp == 0 ? ez - 2 : (grp == 1 ? ez - 2 + k : ez - 3 + k);
   const bool in = (L < 48) & ((unsigned)sx < (unsigned)c.X) & ((unsigned)sy < (unsigned)c.Y) & ((unsigned)sz < (unsigned)c.Z);
   const int cell = in ? m3_cell(c, sx, sy, sz) : 0;
-  const uint32_t nw_ = m3_move_at(c, in ? sx : 0, in ? sy : 0, in ? sz : 0, d);
-  const uint32_t old = c.mv[cell * 4 + d];
+  const int nw_ = m3_move_at(c, in ? sx : 0, in ? sy : 0, in ? sz : 0, d);
+  const int old = c.mv[cell * 4 + d];
   chg = in & (nw_ != old);
   chg_cell = cell;
-  if (chg) c.mv[cell * 4 + d] = (uint8_t)nw_;
+  if (chg) c.mv[cell * 4 + d] = (int16_t)nw_;
   uint32_t dropped = 0;
   if (M3_BALLOT(chg) != 0) {
-    for (int s = 0; s < c.L.n_slots; s++) {
-      if (__builtin_amdgcn_readfirstlane((int)c.hdr(s)->valid) == 0) continue;
-      const bool hit = chg && m3_bit(c.racc(s), cell);
+    // (all reads first: one LDS round trip for the whole loop)
+    constexpr int MAXS = 14;
+    uint32_t hv[MAXS], rw[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+      hv[s] = s < c.L.n_slots ? *(const uint32_t *)c.hdr(s) : 0u;  // start | valid << 16
+      rw[s] = s < c.L.n_slots ? c.racc(s)[cell >> 5] : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+      if (s >= c.L.n_slots) break;
+      const bool hit = chg & ((hv[s] >> 16) != 0u) & (((rw[s] >> (cell & 31)) & 1u) != 0u);
       if (M3_BALLOT(hit) != 0) {
         if (c.lane == 0) c.hdr(s)->valid = 0;
         dropped |= 1u << s;
@@ -479,15 +491,16 @@ __device__ inline uint32_t m3_update_moves(const M3Ctx &c, int ex, int ey, int e
 //     the check is one more dependent LDS round trip -- any target whose `best`, as read in this trip (`best` only
 //     decreases), is not longer.  Entries that turn out to be no-ops later are rejected when popped, like in the reference;
 //   * first-visit order and queue order are kept with prefix counts over the lanes (entry-major, direction-minor).
-// CHAIN MODE.  With a single entry in the queue (corridors: where a search spends its trips) the entry stays in scalar
-// registers: one LDS round trip returns `best` and the four move bytes of its cell, the accept test is scalar, lanes
-// 0..3 evaluate the directions, and a single successor is handed to the next trip by a lane read instead of through the
-// queue.
+// SHORT QUEUES (corridors: where a search spends its trips) are popped one entry at a time, like the reference does: the
+// entry sits in scalar registers, one LDS round trip returns `best` and the four move bytes of its cell, the accept test is
+// scalar, lanes 0..3 evaluate the directions, and a single successor of a lone entry is handed to the next trip by a lane
+// read instead of through the queue.  (A wave issues a DEPENDENT instruction every 8 cycles whatever its width and pipe --
+// tools/ubench/latency.hip -- so a trip costs its instruction count: ~60 here, ~100 in the 16-entry trip.)
 // `best` entries carry the search's epoch, so nothing is cleared between searches.
 template <int SC>
 __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip, bool &overflow PHASE_ARG) {
   constexpr int RING = M3C<SC>::RING, RM = RING - 1;
-  const uint8_t *mv = c.mv;
+  const int16_t *mv = c.mv;
   uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch) + 1u;
   if (ep > 255u) {  // wrapped: clear the table once
     for (int i = c.lane; i < c.n_cells; i += 64) W.best[i].x = 0;
@@ -498,7 +511,6 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
   uint32_t tr = (uint32_t)__builtin_amdgcn_readfirstlane((int)trip);
   int head = 0, tail = 0, n_order = 0;
   const int slot_i = c.lane >> 2, d = c.lane & 3;
-  const int dq = m3_dy(d) * c.X + m3_dx(d);  // column-index step of this lane's direction
   const uint32_t ep24 = ep << 24;
 #ifdef PCGRL_PHASE_TIMING
   int dbg_trips = 0, dbg_pushed = 1;
@@ -522,80 +534,91 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
   do {                     \
   } while (0)
 #endif
-  // the entry in hand (chain mode), in scalar registers; the root has no parent
+  // the entry being processed one at a time, in scalar registers; the root has no parent
   // (loop-carried in vector registers, read back with v_readfirstlane at the top of a trip: that keeps the trip's
   // arithmetic and, above all, its branches on the scalar unit)
-  uint32_t exv = (uint32_t)root, eyv = 1u | (0xFFFFFu << 12);
+  uint32_t exv = (uint32_t)root | (0x1FFFu << 12), eyv = 1u;
   bool in_hand = true;
+  constexpr int WIDE_MIN = 2;  // queue lengths from which the 16-entry trip pays (measured: 5 is slower, a scalar trip costs ~700 cycles)
   for (;;) {
-    // ---- chain trips: everything about the entry is scalar, the queue is empty
-    while (in_hand) {
+    if (!in_hand) {
+      head = __builtin_amdgcn_readfirstlane(head);
+      tail = __builtin_amdgcn_readfirstlane(tail);
+      if (head >= tail) break;
+      if (tail - head < WIDE_MIN) {  // a short queue is popped like the reference pops it
+        const uint2 e = W.ent[head & RM];
+        exv = e.x;
+        eyv = e.y;
+        head++;
+        in_hand = true;
+      }
+    }
+    if (in_hand) {
+      // ---- one entry: everything about it is scalar
       M3_TRIP_KIND(0);
       const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)exv), ey = (uint32_t)__builtin_amdgcn_readfirstlane((int)eyv);
-      const int cell = (int)(ex & 0xFFFu), parent = (int)(ey >> 12);
-      const uint32_t len = ey & 0xFFFu;
-      const uint32_t bxv = W.best[cell].x, mwv = ((const uint32_t *)mv)[cell];  // (one LDS round trip)
+      const int cell = (int)(ex & 0xFFFu), parent = (int)((ex >> 12) & 0x1FFFu);
+      const uint32_t len = ey;
+      const uint32_t bxv = W.best[cell].x;
+      const int mvl = mv[cell * 4 + d];  // (one LDS round trip; lanes 0..3 keep theirs)
       const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)bxv);
-      const uint32_t mw = (uint32_t)__builtin_amdgcn_readfirstlane((int)mwv);
       const bool seen = (bx >> 24) == ep;
       in_hand = false;
-      if (seen && (bx & 0xFFFFFFu) <= len) break;  // :437-440 not shorter: dropped; the queue is empty, the search is over
+      if (seen && (bx & 0xFFFFFFu) <= len) continue;  // :437-440 not shorter: dropped
       if (c.lane == 0) {
         if (!seen) W.order[n_order] = (uint16_t)cell;
         W.best[cell].x = ep24 | len;
         W.info[cell] = ex >> 12;
       }
       n_order += seen ? 0 : 1;
-      const uint32_t m = c.lane < 4 ? (mw >> (8 * c.lane)) & 0xFFu : 0u;
-      const int tcell = cell + dq + ((m & 16u) ? dq : 0) + ((int)((m >> 2) & 3u) - 1) * c.YX;
-      const bool ok = (m != 0u) & (tcell != parent);
+      const int m = c.lane < 4 ? mvl : 0;
+      const int tcell = cell + (m >> 5);
+      const bool ok = (m != 0) & (tcell != parent);
       const uint32_t okb = (uint32_t)M3_BALLOT(ok);
-      const uint32_t nj = (ex >> 12) & 0xFFFu;
-      const uint32_t cx = (uint32_t)tcell | ((nj + ((m >> 4) & 1u)) << 12) | (m << 24) | ((uint32_t)d << 30);
-      const uint32_t cy = (len + (m & 3u)) | ((uint32_t)cell << 12);
-      if (okb == 0u) break;
-      if ((okb & (okb - 1u)) != 0u) {  // several successors: through the queue
-        const int npush = __popc(okb);
-        tail = __builtin_amdgcn_readfirstlane(tail);
-        if (ok) W.ent[(tail + m3_below((uint64_t)okb)) & RM] = make_uint2(cx, cy);
-        tail += npush;
+      const uint32_t cx = (uint32_t)tcell | ((uint32_t)cell << 12) | (((uint32_t)m & 31u) << 25) | ((uint32_t)d << 30);
+      const uint32_t cy = len + ((uint32_t)m & 3u);
+      if (okb == 0u) continue;
+      head = __builtin_amdgcn_readfirstlane(head);
+      tail = __builtin_amdgcn_readfirstlane(tail);
+      if ((okb & (okb - 1u)) == 0u && head >= tail) {  // one successor and nothing waiting: it is the next entry
+        const int l = __builtin_ctz(okb);
+        exv = (uint32_t)__builtin_amdgcn_readlane((int)cx, l);
+        eyv = (uint32_t)__builtin_amdgcn_readlane((int)cy, l);
+        in_hand = true;
 #ifdef PCGRL_PHASE_TIMING
-        dbg_pushed += npush;
+        dbg_pushed++;
 #endif
+        continue;
+      }
+      const int npush = __popc(okb);
+      if (tail + npush - head > RING) {
+        overflow = true;
         break;
       }
-      const int l = __builtin_ctz(okb);  // one successor: it is the next entry
-      exv = (uint32_t)__builtin_amdgcn_readlane((int)cx, l);
-      eyv = (uint32_t)__builtin_amdgcn_readlane((int)cy, l);
-      in_hand = true;
+      if (ok) W.ent[(tail + m3_below((uint64_t)okb)) & RM] = make_uint2(cx, cy);
+      tail += npush;
 #ifdef PCGRL_PHASE_TIMING
-      dbg_pushed++;
+      dbg_pushed += npush;
 #endif
-    }
-    head = __builtin_amdgcn_readfirstlane(head);
-    tail = __builtin_amdgcn_readfirstlane(tail);
-    if (head >= tail) break;
-    if (tail - head == 1) {  // take the only entry in hand
-      const uint2 e = W.ent[head & RM];
-      exv = e.x;
-      eyv = e.y;
-      head++;
-      in_hand = true;
       continue;
     }
     // ---- general trip: up to 16 entries
     M3_TRIP_KIND(1);
     tr++;
     const int nb = min(16, tail - head);
+    if (tail - head > RING - 64) {  // (a trip pushes at most 64 entries)
+      overflow = true;
+      break;
+    }
     const bool live = slot_i < nb;
     const int id = head + (live ? slot_i : 0);
     const uint2 e = W.ent[id & RM];
-    const int cell = (int)(e.x & 0xFFFu), parent = (int)(e.y >> 12);
-    const uint32_t len = e.y & 0xFFFu;
+    const int cell = (int)(e.x & 0xFFFu), parent = (int)((e.x >> 12) & 0x1FFFu);
+    const uint32_t len = e.y;
     const uint32_t stamp = ((0x0FFFFFFFu - tr) << 4) | (uint32_t)slot_i;
     if (live && d == 0) atomicMin(&W.best[cell].y, stamp);
     const uint2 b = W.best[cell];
-    const uint32_t m = mv[cell * 4 + d];
+    const int m = mv[cell * 4 + d];
     const bool seen = (b.x >> 24) == ep;
     // :437-440 (an entry that is not shorter is dropped)
     const bool accept = live & !(seen & ((b.x & 0xFFFFFFu) <= len));
@@ -612,23 +635,19 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
       W.best[cell].x = ep24 | len;
       W.info[cell] = e.x >> 12;
     }
-    // successor in direction d: one byte of the move table
-    const int tcell = cell + dq + ((m & 16u) ? dq : 0) + ((int)((m >> 2) & 3u) - 1) * c.YX;
-    const uint32_t tlen = len + (m & 3u);
-    bool ok = doit & (m != 0u) & (tcell != parent);
+    // successor in direction d: one entry of the move table
+    const int tcell = cell + (m >> 5);
+    const uint32_t tlen = len + ((uint32_t)m & 3u);
+    bool ok = doit & (m != 0) & (tcell != parent);
     if (tail - head > 32) {  // never queue what is known to be a no-op when popped
       const uint32_t bt = W.best[ok ? tcell : 0].x;
       ok &= !(((bt >> 24) == ep) & ((bt & 0xFFFFFFu) <= tlen));
     }
     const uint64_t okb = M3_BALLOT(ok);
-    const int npush = __popcll(okb);
-    if (tail + npush - head > RING) {
-      overflow = true;
-      break;
-    }
     if (ok)
-      W.ent[(tail + m3_below(okb)) & RM] = make_uint2(
-          (uint32_t)tcell | ((((e.x >> 12) & 0xFFFu) + ((m >> 4) & 1u)) << 12) | (m << 24) | ((uint32_t)d << 30), tlen | ((uint32_t)cell << 12));
+      W.ent[(tail + m3_below(okb)) & RM] =
+          make_uint2((uint32_t)tcell | ((uint32_t)cell << 12) | (((uint32_t)m & 31u) << 25) | ((uint32_t)d << 30), tlen);
+    const int npush = __popcll(okb);
     tail += npush;
     head += nproc;
 #ifdef PCGRL_PHASE_TIMING
@@ -682,50 +701,56 @@ __device__ inline uint32_t m3_collect(M3Work<SC> &W, const M3Ctx &c, int n_order
 template <int SC>
 __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch, uint32_t &trip,
                                     bool &overflow PHASE_ARG) {
-  constexpr int NW = M3C<SC>::NW;
   if (c.lane == 0) c.hdr(s)->valid = 0;
   for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
   const int root = sz * c.YX + start_bit;
   int n_order = m3_search(W, c, root, epoch, trip, overflow PHASE_PASS);
   if (overflow) return;
-  int far1 = 0, far2 = 0;
+  int far1 = 0, far2 = 0, n_jump = 0;
   const uint32_t mk = m3_collect(W, c, n_order, far1);
   n_order = m3_search(W, c, far1, epoch, trip, overflow PHASE_PASS);
   if (overflow) return;
   (void)m3_collect(W, c, n_order, far2);
   // The tiles of paths[(mx,my,mz)] as a bit mask: the accepted entries form a tree (an accepted entry's parent is the
   // accepted entry of the parent cell: a strictly shorter path to the parent would have produced a strictly shorter,
-  // hence accepted, entry for the child), so the chain is walked over cells.  An entry knows its move byte and direction,
-  // so the parent's cell and the intermediate tiles of the move (helper_3D.py:214-319) follow: +-YX = one plane up / down.
+  // hence accepted, entry for the child).  The chain of parent cells is walked first -- one dependent LDS read per hop and
+  // nothing else, hop h parked in lane h -- then the lanes mark their hop's cell and the intermediate tiles of its move in
+  // parallel: an entry knows its move byte and direction (helper_3D.py:214-319; +-YX = one plane up / down).
   {
-    uint32_t my0 = 0, my1 = 0;  // words lane and lane + 64 of the mask
-    auto mark = [&](int cell) {
-      const int w = cell >> 5;
-      my0 |= w == c.lane ? 1u << (cell & 31) : 0u;
-      if (NW > 64) my1 |= w == c.lane + 64 ? 1u << (cell & 31) : 0u;
-    };
+    uint32_t *sp = c.spath(s);
+    for (int i = c.lane; i < c.L.nw; i += 64) sp[i] = 0;
     int cell = far2;
-    while (true) {
-      const uint32_t inf = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.info[cell]);
-      mark(cell);
-      const uint32_t m = (inf >> 12) & 63u;
-      if (m == 0u) break;  // the root
-      const int d = (int)((inf >> 18) & 3u);
-      const int dq = m3_dy(d) * c.X + m3_dx(d), dz = (int)((m >> 2) & 3u) - 1;
-      if (m & 16u) {  // jumps: the jumped-over column at the landing's height, and at the take-off's height if they differ
-        const int mid = cell - dq;
-        mark(mid);
-        if (dz != 0) mark(mid - dz * c.YX);
-        cell = cell - 2 * dq - dz * c.YX;
-      } else {
-        if (dz < 0) mark(cell + c.YX);  // step down: the target column at the parent's height
-        if (dz > 0) mark(cell - dq);    // step up: above the parent
-        cell = cell - dq - dz * c.YX;
+    bool more = true;
+    n_jump = 0;
+    while (more) {
+      int mine = -1;
+      int h = 0;
+      for (; h < 64; h++) {  // up to 64 hops per batch
+        mine = c.lane == h ? cell : mine;
+        const int par = __builtin_amdgcn_readfirstlane((int)W.info[cell]) & 0x1FFF;
+        if (par == 0x1FFF) break;
+        cell = par;
+      }
+      more = h == 64;  // (the batch ended on a cell that is not the root: it continues there)
+      const uint32_t inf = mine >= 0 ? W.info[mine] : 0u;
+      const uint32_t m = (inf >> 13) & 31u;  // move code of the hop INTO this cell (0: the root)
+      n_jump += __popcll(M3_BALLOT((m & 4u) != 0u));  // n_j of the accepted entry = jumps along its chain (:283-319)
+      if (mine >= 0) {
+        const int d = (int)((inf >> 18) & 3u);
+        const int dq = m3_dy(d) * c.X + m3_dx(d), dz = (int)((m >> 3) & 3u) - 1;
+        auto mark = [&](int t) { atomicOr(&sp[t >> 5], 1u << (t & 31)); };
+        mark(mine);
+        if (m != 0u) {
+          if (m & 4u) {  // jumps: the jumped-over column at the landing's height, and at the take-off's height if they differ
+            mark(mine - dq);
+            if (dz != 0) mark(mine - dq - dz * c.YX);
+          } else {
+            if (dz < 0) mark(mine + c.YX);  // step down: the target column at the parent's height
+            if (dz > 0) mark(mine - dq);    // step up: above the parent
+          }
+        }
       }
     }
-    uint32_t *sp = c.spath(s);
-    if (c.lane < c.L.nw) sp[c.lane] = my0;
-    if (NW > 64 && c.lane + 64 < c.L.nw) sp[c.lane + 64] = my1;
   }
   uint32_t *ra = c.racc(s);
   for (int i = c.lane; i < c.L.nw; i += 64) ra[i] = W.racc[i];
@@ -734,7 +759,7 @@ __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int st
     h.start = (uint16_t)start_bit;
     h.valid = 1;
     h.max_dist = (uint16_t)(W.best[far2].x & 0xFFFFu);
-    h.n_jump = (uint16_t)(W.info[far2] & 0xFFFu);
+    h.n_jump = (uint16_t)n_jump;
     h.mk = mk & ((1u << c.Z) - 1u);
     h.pad_ = 0;
     *c.hdr(s) = h;
@@ -806,11 +831,10 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
   M3_MARK(4, 5);  // overlay post-processing
 }
 
-// observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay
-__device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over, const M3Ctx &c, const Params &p, int env, const int *pos,
-                                     bool show_path, uint8_t *obs_base = nullptr) {
-  if (p.obs == nullptr) return;
-  if (obs_base == nullptr) obs_base = p.obs;
+// observation: (o0, o1, o2, 4) uint8, channel 0 = out of bounds, 1 = AIR, 2 = DIRT, 3 = path overlay.
+// Cell-by-cell form (any window).
+__device__ inline void m3_encode_obs_cells(const uint32_t *dirt, const uint32_t *over, const M3Ctx &c, const Params &p, int env,
+                                           const int *pos, bool show_path, uint8_t *obs_base) {
   const int o0 = p.cfg.obs_window[0], o1 = p.cfg.obs_window[1], o2 = p.cfg.obs_window[2];
   const int total = o0 * o1 * o2, chunks = total >> 2;
   uint4 *dst = (uint4 *)(obs_base + (size_t)env * total * 4);
@@ -843,6 +867,59 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
         }
       }
     }
+    store_obs16(dst + ch, make_uint4(w[0], w[1], w[2], w[3]));
+  }
+}
+
+// Row form: the window is a crop of the (conceptually padded) map, so a row of it along x is a shifted copy of one map row.
+// Pass 1: per window row (i, j) two o2-bit masks -- bit k = low / high bit of the channel of cell (i, j, k) -- into
+// `scratch` (o0 * o1 + 1 entries).  Pass 2: every 16-byte chunk (4 cells, possibly across a row end) picks its bits from
+// the masks of two consecutive rows; chunk ch = lane + 64 * t, so a store instruction covers 1 KiB of consecutive bytes.
+// W14: the BASELINE window 14 x 14 x 14 with compile-time sizes.
+template <bool W14>
+__device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over, const M3Ctx &c, const Params &p, int env, const int *pos,
+                                     bool show_path, uint2 *scratch, int scratch_rows, uint8_t *obs_base = nullptr) {
+  if (p.obs == nullptr) return;
+  if (obs_base == nullptr) obs_base = p.obs;
+  const int o0 = W14 ? 14 : p.cfg.obs_window[0], o1 = W14 ? 14 : p.cfg.obs_window[1], o2 = W14 ? 14 : p.cfg.obs_window[2];
+  const int rows = o0 * o1;
+  if (!W14 && (rows + 1 > scratch_rows || o2 > 32)) {
+    m3_encode_obs_cells(dirt, over, c, p, env, pos, show_path, obs_base);
+    return;
+  }
+  const int total = rows * o2, chunks = total >> 2;
+  uint4 *dst = (uint4 *)(obs_base + (size_t)env * total * 4);
+  const int t0 = pos[0] - o0 / 2, t1 = pos[1] - o1 / 2, t2 = pos[2] - o2 / 2;
+  const uint32_t xmask = (1u << c.X) - 1u, omask = o2 >= 32 ? 0xFFFFFFFFu : (1u << o2) - 1u;
+  const float inv1 = 1.0f / (float)o1, inv2 = 1.0f / (float)o2;
+  for (int r = c.lane; r <= rows; r += 64) {
+    const int i = (int)(((float)r + 0.5f) * inv1), j = r - i * o1;  // (exact in fp32 for these sizes)
+    const int a = t0 + i, b = t1 + j;
+    const bool inb = (r < rows) & ((unsigned)a < (unsigned)c.Z) & ((unsigned)b < (unsigned)c.Y);
+    const int f = inb ? (a * c.Y + b) * c.X : 0, w = f >> 5, sh = f & 31;
+    uint64_t db = (((uint64_t)dirt[w] | ((uint64_t)dirt[w + 1] << 32)) >> sh) & xmask;
+    uint64_t ob = show_path ? (((uint64_t)over[w] | ((uint64_t)over[w + 1] << 32)) >> sh) & xmask : 0ull;
+    uint64_t xin = xmask;
+    if (t2 >= 0) {  // window cell k shows map column t2 + k
+      db >>= t2;
+      ob >>= t2;
+      xin >>= t2;
+    } else {
+      db <<= -t2;
+      ob <<= -t2;
+      xin <<= -t2;
+    }
+    const uint32_t in = inb ? (uint32_t)xin & omask : 0u;
+    scratch[r] = make_uint2(in & (~(uint32_t)db | (uint32_t)ob), in & ((uint32_t)db | (uint32_t)ob));
+  }
+  for (int ch = c.lane; ch < chunks; ch += 64) {
+    const int q0 = ch * 4;
+    const int r = (int)(((float)q0 + 0.5f) * inv2), k0 = q0 - r * o2;
+    const uint2 ra = scratch[r], rb = scratch[r + 1];
+    const uint64_t m0 = ((uint64_t)ra.x | ((uint64_t)rb.x << o2)) >> k0, m1 = ((uint64_t)ra.y | ((uint64_t)rb.y << o2)) >> k0;
+    uint32_t w[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) w[t] = 1u << (8 * (((uint32_t)(m0 >> t) & 1u) + 2u * ((uint32_t)(m1 >> t) & 1u)));
     store_obs16(dst + ch, make_uint4(w[0], w[1], w[2], w[3]));
   }
 }
@@ -896,8 +973,8 @@ __device__ inline void m3_advance_pos(const M3Ctx &c, int *pos, int &n_step) {
   n_step++;
 }
 
-// D7: the BASELINE map shape 7 x 7 x 7 with compile-time dimensions (the search trip is instruction-bound: constant
-// strides and bounds take instructions away)
+// D7: the BASELINE map shape 7 x 7 x 7 and observation window 14 x 14 x 14 with compile-time dimensions (the search trip
+// and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
 template <int MODE, int SC, bool D7 = false>
 __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p, int cpl) {
   constexpr int PW = M3C<SC>::PW;
@@ -917,7 +994,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
   c.over = E.rec + c.L.o_over;
   c.col = (uint16_t *)(E.rec + c.L.o_col);
   c.slots = E.rec + c.L.o_slots;
-  c.mv = (uint8_t *)(E.rec + c.L.o_mv);
+  c.mv = (int16_t *)(E.rec + c.L.o_mv);
   const int nw = c.L.nw, n_slots = c.L.n_slots;
   const int env = blockIdx.x;
   constexpr int NS = M3_NS;
@@ -955,10 +1032,11 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       if (done && p.auto_reset != 0) {  // first observation of the new episode: no overlay (PcgrlEnv.reset)
         m3_reset_rng(odirt, c, p, cpl, rp, rr);
         pos[0] = pos[1] = pos[2] = 0;
-        m3_encode_obs(odirt, oover, c, p, env, pos, false);
+        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, false, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)));
       } else {
-        m3_encode_obs(odirt, oover, c, p, env, pos, true);
+        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, true, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)));
       }
+      TRACE_PUT(4, _tr0);
       TRACE_PUT(3, TRACE_NOW());
       // the simulate wave overwrites the env's state only after this wave has read it: it waits at the same barrier just
       // before its write-back, by which time this wave is long done (the barrier is at the END of both so that neither
@@ -992,7 +1070,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
     for (int i = c.lane; i < 2 * nw; i += 64) E.rec[i] = grec[i];
     const int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
-    m3_encode_obs(c.dirt, c.over, c, p, env, pos, false);
+    m3_encode_obs<false>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2);
     return;
   }
 
@@ -1180,7 +1258,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
       // the previous stats update on the already edited map
       M3_MARK(1, 5);  // action + move-table update
-      if (!do_reset && want_obs) m3_encode_obs(c.dirt, c.over, c, p, env, pos, true, obs_k);
+      if (!do_reset && want_obs) m3_encode_obs<D7>(c.dirt, c.over, c, p, env, pos, true, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       M3_MARK(1, 5);  // observation (rollout mode)
       if (change) {
         const PM<PW> air = plane_of(c.dirt);
@@ -1233,7 +1311,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
         ep_return = 0.0;
         trg.load(p, env, true);
         last_loss = trg.loss(p.cfg, st);
-        if (want_obs) m3_encode_obs(c.dirt, c.over, c, p, env, pos, false, obs_k);
+        if (want_obs) m3_encode_obs<D7>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       }
     }
     if (ovf && c.lane == 0) atomicOr(p.err, 4);
@@ -1245,7 +1323,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
       if (edited) {  // the tile bits, one column mask, the changed rows of the move table
         for (int i = c.lane; i < nw; i += 64) grec[i] = c.dirt[i];
         if (c.lane == 0) grec[c.L.o_col + col_word] = E.rec[c.L.o_col + col_word];
-        if (mv_chg) grec[c.L.o_mv + mv_cell] = E.rec[c.L.o_mv + mv_cell];
+        if (mv_chg) ((uint2 *)(grec + c.L.o_mv))[mv_cell] = ((const uint2 *)(E.rec + c.L.o_mv))[mv_cell];
       }
       if (over_dirty)  // new statistics: the overlay
         for (int i = c.lane; i < nw; i += 64) grec[c.L.o_over + i] = c.over[i];

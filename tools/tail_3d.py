@@ -16,7 +16,7 @@ sp = torch.cuda.current_stream().cuda_stream
 out = np.zeros(8 * n, np.uint64)
 names = ["trips", "entries", "n_searches", "search loops", "regions", "everything else", "candidate walk", "wall"]
 rows = []
-for k in range(700):
+for k in range(1500):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
     if k >= 500:
         env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * n)
@@ -33,3 +33,8 @@ print("phases of the slowest wave (mean over launches):", dict(zip(names[:8], ph
 # distribution of the search work per launch (all waves)
 print("per-wave means over the last launch: trips %.1f entries %.1f searches %.2f; max trips %d entries %d searches %d" % (
     a[:, 0].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 0].max(), a[:, 1].max(), a[:, 2].max()))
+
+# the slowest wave of each launch, by how slow the launch was
+order = np.argsort(mx)
+for name, sel in (("median launches", order[len(order) // 2 - 10: len(order) // 2 + 10]), ("slowest 10 %", order[-len(order) // 10:]), ("slowest 2 %", order[-max(4, len(order) // 50):])):
+    print(f"{name:16s} slowest wave: cycles {mx[sel].mean():8.0f}  " + "  ".join(f"{n} {ph[sel, i].mean():.0f}" for i, n in enumerate(names[:7])))

@@ -48,9 +48,10 @@ for it in range(200):
     out = np.zeros(8 * blocks, np.uint64)
     env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
     t = out.reshape(blocks, 8).astype(np.int64)
-    if three_d:  # one wave per env: slots 0 start, 1 end, 2 end after the stores were acknowledged
+    if three_d:  # simulate wave: slots 0 start, 1 end, 2 end after the stores were acknowledged; observe wave: 4 start, 3 stores issued
         t0 = t[:, 0].min()
-        rows.append(dict(start=t[:, 0] - t0, end=t[:, 1] - t0, acked=t[:, 2] - t0, per_launch_us=ev0.elapsed_time(ev1) * 1e3 / 8))
+        rows.append(dict(start=t[:, 0] - t0, end=t[:, 1] - t0, acked=t[:, 2] - t0, obs_start=t[:, 4] - t0, obs_issued=t[:, 3] - t0,
+                         per_launch_us=ev0.elapsed_time(ev1) * 1e3 / 8))
         continue
     t0 = min(t[:, 0].min(), t[:, 2].min())
     rows.append(dict(sim_start=(t[:, 0] - t0), sim_end=(t[:, 1] - t0), obs_start=(t[:, 2] - t0),
@@ -63,7 +64,7 @@ def q(a, f):
 
 print("all numbers in ns relative to the first wave start of the launch; median over 200 traced launches")
 if three_d:
-    for key in ("start", "end", "acked"):
+    for key in ("start", "end", "acked", "obs_start", "obs_issued"):
         print(f"{key:8s} median wave {np.median([q(r[key], 0.5) for r in rows]):8.0f}   p95 {np.median([q(r[key], 0.95) for r in rows]):8.0f}"
               f"   last wave {np.median([q(r[key], 1.0) for r in rows]):8.0f}")
     print(f"wave lifetime mean {np.median([np.mean(r['end'] - r['start']) * 10.0 for r in rows]):.0f} max "
