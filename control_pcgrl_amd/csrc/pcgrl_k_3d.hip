@@ -8,7 +8,7 @@ template <int SC>
 static hipError_t launch_3d_sc(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
   switch (id) {
-    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(128), 0, s, p, cpl); break;  // simulate + observe wave
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(SC == 0 ? 192 : 128), 0, s, p, cpl); break;  // simulate + observe (+ helper) wave
     case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET, SC>), grid, block, 0, s, p, cpl); break;
     case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE, SC>), grid, block, 0, s, p, cpl); break;
     case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE, SC>), grid, block, 0, s, p, cpl); break;
@@ -27,7 +27,7 @@ hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s
   const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7 && p.cfg.obs_window[0] == 14 &&
                   p.cfg.obs_window[1] == 14 && p.cfg.obs_window[2] == 14;
   if (d7 && id == K_STEP) {
-    hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, true>), grid, dim3(128), 0, s, p, cpl);
+    hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, true>), grid, dim3(192), 0, s, p, cpl);
     return hipGetLastError();
   }
   if (d7 && id == K_ROLLOUT) {

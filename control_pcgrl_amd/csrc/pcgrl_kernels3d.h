@@ -44,7 +44,9 @@ namespace pcgrl {
 // ([0] trips [1] queue entries [2] searches [3] search-loop cycles [4] regions [5] everything else [6] candidate walk incl.
 // the search loops) or, with -DPCGRL_M3_PHASES, the phases of the simulate wave ([0] loads until the barrier [1] columns +
 // move-table update [2] regions [3] candidate walk [4] overlay [5] outputs + write-back [6] fresh tables); [7] = wall clock.
-#if defined(PCGRL_M3_TRIPS)  // [0] chain trips [1] general trips [2] / [3] their cycles; the first four phases land in [6]
+#if defined(PCGRL_M3_SPEC)  // [0] pairs run [1] with a remembered farthest cell [2] of which the helper's search was used
+#define M3_MARK(coarse, fine) PHASE_MARK(6)
+#elif defined(PCGRL_M3_TRIPS)  // [0] chain trips [1] general trips [2] / [3] their cycles; the first four phases land in [6]
 #define M3_MARK(coarse, fine) PHASE_MARK((coarse) < 4 ? 6 : (coarse))
 #elif defined(PCGRL_M3_PHASES)
 #define M3_MARK(coarse, fine) PHASE_MARK(coarse)
@@ -57,7 +59,7 @@ template <int SC>
 struct M3C;
 template <>
 struct M3C<0> {
-  static constexpr int CELLS = 512, NW = 16, PW = 1, RING = 1024, COLS = 64, SLOTS = 6, ZMAX = 8;
+  static constexpr int CELLS = 512, NW = 16, PW = 1, RING = 512, COLS = 64, SLOTS = 6, ZMAX = 8;
   static constexpr int REC = 2 * NW + COLS / 2 + 2 + SLOTS * (4 + 2 * NW) + 2 * CELLS + 4;  // upper bound of m3_layout().rec_words
 };
 template <>
@@ -223,7 +225,7 @@ struct M3SlotHdr {
   uint16_t max_dist;
   uint16_t n_jump;
   uint32_t mk;      // z-planes marked visited by the first search (the fancy-index bug, :531)
-  uint32_t pad_;
+  uint32_t far1;    // farthest cell of the first search + 1 (0: unknown): where the second search started (see SPECULATION)
 };
 static_assert(sizeof(M3SlotHdr) == 4 * M3_SLOT_HDR, "slot header layout");
 
@@ -497,8 +499,10 @@ __device__ inline uint32_t m3_update_moves(const M3Ctx &c, int ex, int ey, int e
 // read instead of through the queue.  (A wave issues a DEPENDENT instruction every 8 cycles whatever its width and pipe --
 // tools/ubench/latency.hip -- so a trip costs its instruction count: ~60 here, ~100 in the 16-entry trip.)
 // `best` entries carry the search's epoch, so nothing is cleared between searches.
-template <int SC>
-__device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip, bool &overflow PHASE_ARG) {
+// `cancel` (helper wave, see SPECULATION): the search gives up as soon as *cancel is set; its result is then meaningless.
+template <int SC, bool CANCEL = false>
+__device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip, bool &overflow,
+                                const int *cancel PHASE_ARG) {
   constexpr int RING = M3C<SC>::RING, RM = RING - 1;
   const int16_t *mv = c.mv;
   uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch) + 1u;
@@ -541,6 +545,12 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
   bool in_hand = true;
   constexpr int WIDE_MIN = 2;  // queue lengths from which the 16-entry trip pays (measured: 5 is slower, a scalar trip costs ~700 cycles)
   for (;;) {
+    if (CANCEL) {
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0) {
+        overflow = true;  // (reported to the caller as "no result")
+        break;
+      }
+    }
     if (!in_hand) {
       head = __builtin_amdgcn_readfirstlane(head);
       tail = __builtin_amdgcn_readfirstlane(tail);
@@ -660,7 +670,7 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
   (void)_t_prev;
   (void)dbg_trips;
   (void)dbg_pushed;
-#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES)
+#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES) && !defined(PCGRL_M3_SPEC)
   (void)_t_prev;
   _ph[0] += (uint32_t)dbg_trips;
   _ph[1] += (uint32_t)dbg_pushed;
@@ -697,59 +707,163 @@ __device__ inline uint32_t m3_collect(M3Work<SC> &W, const M3Ctx &c, int n_order
   return wave_or(mkl);
 }
 
+// The tiles of paths[(mx,my,mz)] of the search just run in W, as a bit mask into slot s; returns n_jump of that path.
+// The accepted entries form a tree (an accepted entry's parent is the accepted entry of the parent cell: a strictly
+// shorter path to the parent would have produced a strictly shorter, hence accepted, entry for the child).  The chain of
+// parent cells is walked first -- one dependent LDS read per hop and nothing else, hop h parked in lane h -- then the
+// lanes mark their hop's cell and the intermediate tiles of its move in parallel: an entry knows its move code and
+// direction (helper_3D.py:214-319; +-YX = one plane up / down).  n_j of an entry = the jumps along its chain (:283-319).
+template <int SC>
+__device__ inline int m3_path_tiles(M3Work<SC> &W, const M3Ctx &c, int s, int far2) {
+  uint32_t *sp = c.spath(s);
+  for (int i = c.lane; i < c.L.nw; i += 64) sp[i] = 0;
+  int cell = far2, n_jump = 0;
+  bool more = true;
+  while (more) {
+    int mine = -1;
+    int h = 0;
+    for (; h < 64; h++) {  // up to 64 hops per batch
+      mine = c.lane == h ? cell : mine;
+      const int par = __builtin_amdgcn_readfirstlane((int)W.info[cell]) & 0x1FFF;
+      if (par == 0x1FFF) break;
+      cell = par;
+    }
+    more = h == 64;  // (the batch ended on a cell that is not the root: it continues there)
+    const uint32_t inf = mine >= 0 ? W.info[mine] : 0u;
+    const uint32_t m = (inf >> 13) & 31u;  // move code of the hop INTO this cell (0: the root)
+    n_jump += __popcll(M3_BALLOT((m & 4u) != 0u));
+    if (mine >= 0) {
+      const int d = (int)((inf >> 18) & 3u);
+      const int dq = m3_dy(d) * c.X + m3_dx(d), dz = (int)((m >> 3) & 3u) - 1;
+      auto mark = [&](int t) { atomicOr(&sp[t >> 5], 1u << (t & 31)); };
+      mark(mine);
+      if (m != 0u) {
+        if (m & 4u) {  // jumps: the jumped-over column at the landing's height, and at the take-off's height if they differ
+          mark(mine - dq);
+          if (dz != 0) mark(mine - dq - dz * c.YX);
+        } else {
+          if (dz < 0) mark(mine + c.YX);  // step down: the target column at the parent's height
+          if (dz > 0) mark(mine - dq);    // step up: above the parent
+        }
+      }
+    }
+  }
+  return n_jump;
+}
+
+// SPECULATION.  The second search of a pair starts at the farthest cell of the first, which is only known when the first
+// has ended -- but after a one-cell edit it is usually the cell it was the last time this plane was searched.  The step
+// kernel therefore carries a helper wavefront with a search workspace of its own: while the simulate wave runs the first
+// search, the helper runs the second one from the REMEMBERED farthest cell (kept in the slot header), including its
+// farthest-cell arg-max and path tiles.  If the first search ends at that cell the pair costs the longer of the two
+// searches instead of their sum; otherwise the helper is cancelled and the simulate wave runs the second search itself.
+// Results are those of the sequential pair either way.  Hand-over through an LDS mailbox.
+struct M3Mail {
+  int32_t seq;     // job number, bumped by the simulate wave once root / slot are in place
+  int32_t done;    // = seq when the helper has finished (or dropped) that job
+  int32_t cancel;  // the running job's result is not needed
+  int32_t exit;    // the simulate wave is done with the launch
+  int32_t root, slot;
+  int32_t ok, far2, max_dist, n_jump;  // results
+};
+__device__ inline int m3_ld(const int32_t *x) { return __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void m3_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// second search of a pair from `root` in workspace W: accepted cells -> W.racc (OR-ed in), path tiles -> slot s.
+template <int SC, bool CANCEL>
+__device__ inline bool m3_second_search(M3Work<SC> &W, const M3Ctx &c, int s, int root, uint32_t &epoch, uint32_t &trip, int &far2,
+                                        int &max_dist, int &n_jump, const int *cancel PHASE_ARG) {
+  bool overflow = false;
+  const int n_order = m3_search<SC, CANCEL>(W, c, root, epoch, trip, overflow, cancel PHASE_PASS);
+  if (overflow) return false;
+  (void)m3_collect(W, c, n_order, far2);
+  max_dist = (int)(__builtin_amdgcn_readfirstlane((int)W.best[far2].x) & 0xFFFF);
+  n_jump = m3_path_tiles(W, c, s, far2);
+  return true;
+}
+
+// body of the helper wave: serve the simulate wave's jobs until it leaves
+template <int SC>
+__device__ inline void m3_helper(M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
+  uint32_t epoch = 0, trip = 0;
+  for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
+  int seen = 0;
+  while (true) {
+    int sq;
+    while ((sq = __builtin_amdgcn_readfirstlane(m3_ld(&m.seq))) == seen) {
+      if (__builtin_amdgcn_readfirstlane(m3_ld(&m.exit)) != 0) return;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    seen = sq;
+    const int root = __builtin_amdgcn_readfirstlane(m3_ld(&m.root)), s = __builtin_amdgcn_readfirstlane(m3_ld(&m.slot));
+    for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
+    int far2 = 0, max_dist = 0, n_jump = 0;
+    const bool ok = m3_second_search<SC, true>(W, c, s, root, epoch, trip, far2, max_dist, n_jump, &m.cancel PHASE_PASS);
+    if (c.lane == 0) {
+      m.ok = ok ? 1 : 0;
+      m.far2 = far2;
+      m.max_dist = max_dist;
+      m.n_jump = n_jump;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      m3_st(&m.done, sq);
+    }
+  }
+}
+
 // The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s of the env (result + accepted cells).
+// W2 / mail: the helper wave's workspace and mailbox (null: no helper).
 template <int SC>
 __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch, uint32_t &trip,
-                                    bool &overflow PHASE_ARG) {
+                                    bool &overflow, M3Work<SC> *W2, M3Mail *mail PHASE_ARG) {
+  // the farthest cell of this plane's first search the last time it ran (+1; 0: none)
+  int guess = mail != nullptr ? (int)__builtin_amdgcn_readfirstlane((int)c.hdr(s)->far1) - 1 : -1;
+  if (guess >= c.n_cells) guess = -1;
+  int seq = 0;
+  if (guess >= 0) {
+    if (c.lane == 0) {
+      seq = m3_ld(&mail->seq) + 1;
+      mail->root = guess;
+      mail->slot = s;
+      m3_st(&mail->cancel, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      m3_st(&mail->seq, seq);
+    }
+    seq = __builtin_amdgcn_readfirstlane(seq);
+  }
   if (c.lane == 0) c.hdr(s)->valid = 0;
   for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
   const int root = sz * c.YX + start_bit;
-  int n_order = m3_search(W, c, root, epoch, trip, overflow PHASE_PASS);
+  int n_order = m3_search<SC>(W, c, root, epoch, trip, overflow, nullptr PHASE_PASS);
+  int far1 = 0, far2 = 0, n_jump = 0, max_dist = 0;
+  uint32_t mk = 0;
+  if (!overflow) mk = m3_collect(W, c, n_order, far1);
+  bool have2 = false;
+  if (guess >= 0) {  // the helper's job: used, or called off
+    const bool hit = !overflow && far1 == guess;
+    if (!hit && c.lane == 0) m3_st(&mail->cancel, 1);
+    while (__builtin_amdgcn_readfirstlane(m3_ld(&mail->done)) != seq) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (hit && __builtin_amdgcn_readfirstlane(m3_ld(&mail->ok)) != 0) {
+      far2 = __builtin_amdgcn_readfirstlane(m3_ld(&mail->far2));
+      max_dist = __builtin_amdgcn_readfirstlane(m3_ld(&mail->max_dist));
+      n_jump = __builtin_amdgcn_readfirstlane(m3_ld(&mail->n_jump));
+      for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] |= W2->racc[i];
+      have2 = true;
+    }
+#if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_SPEC)
+    _ph[1] += 1;
+    _ph[2] += have2 ? 1 : 0;
+#endif
+  }
+#if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_SPEC)
+  _ph[0] += 1;
+#endif
   if (overflow) return;
-  int far1 = 0, far2 = 0, n_jump = 0;
-  const uint32_t mk = m3_collect(W, c, n_order, far1);
-  n_order = m3_search(W, c, far1, epoch, trip, overflow PHASE_PASS);
-  if (overflow) return;
-  (void)m3_collect(W, c, n_order, far2);
-  // The tiles of paths[(mx,my,mz)] as a bit mask: the accepted entries form a tree (an accepted entry's parent is the
-  // accepted entry of the parent cell: a strictly shorter path to the parent would have produced a strictly shorter,
-  // hence accepted, entry for the child).  The chain of parent cells is walked first -- one dependent LDS read per hop and
-  // nothing else, hop h parked in lane h -- then the lanes mark their hop's cell and the intermediate tiles of its move in
-  // parallel: an entry knows its move byte and direction (helper_3D.py:214-319; +-YX = one plane up / down).
-  {
-    uint32_t *sp = c.spath(s);
-    for (int i = c.lane; i < c.L.nw; i += 64) sp[i] = 0;
-    int cell = far2;
-    bool more = true;
-    n_jump = 0;
-    while (more) {
-      int mine = -1;
-      int h = 0;
-      for (; h < 64; h++) {  // up to 64 hops per batch
-        mine = c.lane == h ? cell : mine;
-        const int par = __builtin_amdgcn_readfirstlane((int)W.info[cell]) & 0x1FFF;
-        if (par == 0x1FFF) break;
-        cell = par;
-      }
-      more = h == 64;  // (the batch ended on a cell that is not the root: it continues there)
-      const uint32_t inf = mine >= 0 ? W.info[mine] : 0u;
-      const uint32_t m = (inf >> 13) & 31u;  // move code of the hop INTO this cell (0: the root)
-      n_jump += __popcll(M3_BALLOT((m & 4u) != 0u));  // n_j of the accepted entry = jumps along its chain (:283-319)
-      if (mine >= 0) {
-        const int d = (int)((inf >> 18) & 3u);
-        const int dq = m3_dy(d) * c.X + m3_dx(d), dz = (int)((m >> 3) & 3u) - 1;
-        auto mark = [&](int t) { atomicOr(&sp[t >> 5], 1u << (t & 31)); };
-        mark(mine);
-        if (m != 0u) {
-          if (m & 4u) {  // jumps: the jumped-over column at the landing's height, and at the take-off's height if they differ
-            mark(mine - dq);
-            if (dz != 0) mark(mine - dq - dz * c.YX);
-          } else {
-            if (dz < 0) mark(mine + c.YX);  // step down: the target column at the parent's height
-            if (dz > 0) mark(mine - dq);    // step up: above the parent
-          }
-        }
-      }
+  if (!have2) {
+    if (!m3_second_search<SC, false>(W, c, s, far1, epoch, trip, far2, max_dist, n_jump, nullptr PHASE_PASS)) {
+      overflow = true;
+      return;
     }
   }
   uint32_t *ra = c.racc(s);
@@ -758,10 +872,10 @@ __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int st
     M3SlotHdr h;
     h.start = (uint16_t)start_bit;
     h.valid = 1;
-    h.max_dist = (uint16_t)(W.best[far2].x & 0xFFFFu);
+    h.max_dist = (uint16_t)max_dist;
     h.n_jump = (uint16_t)n_jump;
     h.mk = mk & ((1u << c.Z) - 1u);
-    h.pad_ = 0;
+    h.far1 = (uint32_t)(far1 + 1);
     *c.hdr(s) = h;
   }
 }
@@ -772,7 +886,7 @@ __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int st
 // Slots that are still valid (see SLOT CACHE) are reused; the caller invalidates them for fresh maps.
 template <int SC>
 __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<M3C<SC>::PW> air, int32_t *st, uint32_t &epoch,
-                                uint32_t &trip, uint32_t &filled, bool &overflow PHASE_ARG) {
+                                uint32_t &trip, uint32_t &filled, bool &overflow, M3Work<SC> *W2, M3Mail *mail PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
   const PM<PW> above = pm_down(air), below = pm_up(air);
@@ -789,7 +903,7 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
     {
       const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t *)c.hdr(s));  // start | valid << 16
       if (!((h0 >> 16) != 0u && (int)(h0 & 0xFFFFu) == bit)) {
-        m3_fill_slot(W, c, s, bit, sz, epoch, trip, overflow PHASE_PASS);
+        m3_fill_slot(W, c, s, bit, sz, epoch, trip, overflow, W2, mail PHASE_PASS);
         filled |= 1u << s;
         if (overflow) break;
       }
@@ -975,11 +1089,19 @@ __device__ inline void m3_advance_pos(const M3Ctx &c, int *pos, int &n_step) {
 
 // D7: the BASELINE map shape 7 x 7 x 7 and observation window 14 x 14 x 14 with compile-time dimensions (the search trip
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
+// HELP (pcgrl_step, size class 0): a third wavefront runs second searches speculatively, see SPECULATION.
 template <int MODE, int SC, bool D7 = false>
-__global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p, int cpl) {
+__global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void m3_kernel(Params p, int cpl) {
   constexpr int PW = M3C<SC>::PW;
+  constexpr bool HELP = MODE == M3_STEP && SC == 0;
   __shared__ M3Env<SC> E;
   __shared__ M3Work<SC> W;
+  __shared__ M3Mail mail;
+  M3Work<SC> *WH = nullptr;  // the helper wave's workspace
+  if constexpr (HELP) {
+    __shared__ M3Work<SC> wh_;
+    WH = &wh_;
+  }
   __shared__ M3ObsLds<SC> O;
   M3Ctx c;
   c.lane = (int)__lane_id();
@@ -1003,9 +1125,24 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
   uint32_t *grec = (uint32_t *)p.planes + (size_t)env * c.L.rec_words;
   EnvState *S = &p.st[env];
 
+  if constexpr (HELP) {
+    if (threadIdx.x == 0) {
+      mail.seq = 0;
+      mail.done = 0;
+      mail.cancel = 0;
+      mail.exit = 0;
+    }
+    __syncthreads();  // (the waves of a workgroup start together: nobody waits here)
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 2) {
+      // ---------------------------------------------------------------------------------------- helper wave
+      m3_helper<SC>(*WH, c, mail PHASE_PASS);
+      if (p.obs != nullptr) __syncthreads();  // (the closing barrier of the other two waves)
+      return;
+    }
+  }
   if constexpr (MODE == M3_STEP) {
     // ------------------------------------------------------------------------------------------ observe wave
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {  // (readfirstlane: a scalar branch)
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {  // (readfirstlane: a scalar branch)
       if (p.obs == nullptr) return;  // (the simulate wave skips the barrier in that case, too)
       // everything this wave needs of the old state is requested at once; an auto-reset replays the env's RNG streams in
       // both waves, so it takes its copy of them, too
@@ -1089,12 +1226,12 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     for (int i = c.lane; i < c.L.o_slots - c.L.o_col; i += 64) E.rec[c.L.o_col + i] = 0;
     m3_build_cols<PW>(c, air);
     m3_build_moves(c);
-    if (c.lane < n_slots) c.hdr(c.lane)->valid = 0;
+    if (c.lane < n_slots) *(uint4 *)c.hdr(c.lane) = make_uint4(0u, 0u, 0u, 0u);
     dirty_hdr = (1u << n_slots) - 1u;
     M3_MARK(6, 5);  // column masks + move table
     st[0] = m3_regions<PW>(c, air, notx0, notxl);
     M3_MARK(2, 4);  // regions
-    m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf PHASE_PASS);
+    m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, nullptr, nullptr PHASE_PASS);
   };
   auto store_record = [&]() {  // the whole record
     for (int i = c.lane; i < c.L.rec_words / 4; i += 64) ((uint4 *)grec)[i] = ((const uint4 *)E.rec)[i];
@@ -1276,7 +1413,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
         }
         flags &= ~ENV_STATS_DIRTY;
         M3_MARK(2, 4);  // regions
-        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf PHASE_PASS);
+        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP ? &mail : nullptr PHASE_PASS);
         over_dirty = true;
         if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
           for (int i = 0; i < NS; i++) st[i] = st_old[i];
@@ -1316,6 +1453,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? 128 : 64) void m3_kernel(Params p
     }
     if (ovf && c.lane == 0) atomicOr(p.err, 4);
     // ---- write back, once the observe wave has read the old state
+    if (HELP && c.lane == 0) m3_st(&mail.exit, 1);
     if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();
     if (whole_record) {
       store_record();

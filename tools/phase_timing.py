@@ -15,7 +15,7 @@ NAMES = ["loads+barrier", "action+state", "stats refresh (total)", "  flood", " 
          "loss/outputs/write-back"]
 
 if "--build" in sys.argv:
-    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",) + (("PCGRL_M3_PHASES",) if "--m3-phases" in sys.argv else ()) + (("PCGRL_M3_PHASES", "PCGRL_M3_TRIPS") if "--m3-trips" in sys.argv else ()))
+    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",) + (("PCGRL_M3_PHASES",) if "--m3-phases" in sys.argv else ()) + (("PCGRL_M3_PHASES", "PCGRL_M3_TRIPS") if "--m3-trips" in sys.argv else ()) + (("PCGRL_M3_SPEC",) if "--m3-spec" in sys.argv else ()))
     print("built", TIMING_LIB)
     sys.exit(0)
 
@@ -29,7 +29,9 @@ three_d = "--3d" in sys.argv
 soko = "--sokoban" in sys.argv  # sokoban-wide 16x16, 2048 envs (BASELINE C4)
 n, iters = (1024, 1000) if three_d else ((2048, 2000) if soko else (4096, 2000))
 if three_d:
-    if "--m3-trips" in sys.argv:
+    if "--m3-spec" in sys.argv:
+        NAMES = ["(count) search pairs", "(count) with a remembered farthest cell", "(count) helper result used", "-", "-", "-", "-"]
+    elif "--m3-trips" in sys.argv:
         NAMES = ["(count) chain trips", "(count) general trips", "chain-trip cycles", "general-trip cycles", "overlay", "outputs + write-back", "fresh tables"]
     elif "--m3-phases" in sys.argv:
         NAMES = ["loads until the barrier", "columns + move-table update", "regions", "candidate walk", "overlay", "outputs + write-back", "fresh tables (reset)"]
