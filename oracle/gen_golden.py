@@ -779,3 +779,167 @@ if __name__ == "__main__" and "shapes" in sys.argv[1:]:
         run_shape_episode(name, 60 + list(SHAPE_CONFIGS).index(name))
     if not only:
         gen_stats_shapes()
+
+
+# ------------------------------------------------------------------ 3-D maze off the 7x7x7 point
+# The reference's stock minecraft map is 15 x 15 x 15 (configs/config.py:153-157, inherited by MinecraftMazeConfig
+# :160-167 and MinecraftMazeControlConfig :195-205); 10 x 10 x 10 is a second cubic size whose planes need more than
+# one 64-bit word in the engine.  Non-cubic maps hit index errors in the reference (helper_3D.py:531 marks planes by
+# coordinate VALUE).  Episodes are kept short with cfg.change_percentage; compact format like the 2-D shape fixtures,
+# with the reference's obs dict (map incl. path overlay) as CRC per step and in full at a few steps.
+SHAPE3D_CONFIGS = {
+    # name: (map_shape, max_changes wanted)
+    "mc3dmaze_narrow_15": ((15, 15, 15), 140),
+    "mc3dmaze_narrow_10": ((10, 10, 10), 120),
+}
+
+
+def run_shape_episode_3d(name, seed, extra_steps=30):
+    shape, mc = SHAPE3D_CONFIGS[name]
+    problem, rep = "minecraft_3D_maze", "narrow"
+    n_cells = int(np.prod(shape))
+    cp = (mc + 0.5) / n_cells
+    cfg = ref_env.make_cfg(problem, rep, shape, change_percentage=cp)
+    env = ref_env.make_reference_env(cfg, seed=seed)
+    core = env.unwrapped
+    assert core._max_changes == mc, (core._max_changes, mc)
+    arng = np.random.default_rng(7000 + seed)
+    rec = {k: [] for k in ("grid_crc", "pos", "stats", "reward", "done", "changes", "iterations", "overlay_crc", "action")}
+    grids, overs = {}, {}
+    resets = {k: [] for k in ("step", "grid", "pos", "stats", "overlay")}
+
+    def cur_pos():
+        return np.array(core._rep.unwrapped._pos, dtype=np.int64).copy()
+
+    def do_reset(step_idx):
+        obs, _ = env.reset()
+        resets["step"].append(step_idx)
+        resets["grid"].append(core._rep.unwrapped._map.astype(np.uint8).ravel().copy())
+        resets["pos"].append(cur_pos())
+        resets["stats"].append(stats_vec(problem, core._rep_stats))
+        resets["overlay"].append(np.asarray(obs["map"]).astype(np.uint8).ravel().copy())
+
+    t, ep_len = 0, None
+    do_reset(0)
+    while True:
+        a = int(arng.integers(2))
+        obs, r, d, tr, info = env.step(a)
+        g = core._rep.unwrapped._map.astype(np.uint8).ravel().copy()
+        m = np.asarray(obs["map"]).astype(np.uint8).ravel().copy()
+        rec["action"].append(a); rec["grid_crc"].append(zlib.crc32(g.tobytes())); rec["pos"].append(cur_pos())
+        rec["stats"].append(stats_vec(problem, core._rep_stats)); rec["reward"].append(float(r)); rec["done"].append(bool(d))
+        rec["changes"].append(int(info["changes"])); rec["iterations"].append(int(info["iterations"]))
+        rec["overlay_crc"].append(zlib.crc32(m.tobytes()))
+        grids[t], overs[t] = g, m
+        t += 1
+        if d:
+            if ep_len is None:
+                ep_len = t
+                do_reset(t)
+            else:
+                break
+        if ep_len is not None and t >= ep_len + extra_steps:
+            break
+    keep = sorted(set([0, 1, ep_len // 3, ep_len // 2, ep_len - 1, ep_len, t - 1]))
+    out = dict(
+        problem=problem, representation=rep, map_shape=np.array(shape), seed=seed, change_percentage=cp, max_changes=mc,
+        stat_keys=np.array(STAT_KEYS[problem]), episode_len=ep_len,
+        action=np.array(rec["action"], np.int32), grid_crc=np.array(rec["grid_crc"], np.uint32),
+        pos=np.array(rec["pos"], np.int16), stats=np.array(rec["stats"], np.int32), reward=np.array(rec["reward"], np.float64),
+        done=np.array(rec["done"], np.bool_), changes=np.array(rec["changes"], np.int32),
+        iterations=np.array(rec["iterations"], np.int32), overlay_crc=np.array(rec["overlay_crc"], np.uint32),
+        full_steps=np.array(keep, np.int32), grid_full=np.array([grids[k] for k in keep], np.uint8),
+        overlay_full=np.array([overs[k] for k in keep], np.uint8),
+        reset_step=np.array(resets["step"], np.int32), reset_grid=np.array(resets["grid"], np.uint8),
+        reset_pos=np.array(resets["pos"], np.int16), reset_stats=np.array(resets["stats"], np.int32),
+        reset_overlay=np.array(resets["overlay"], np.uint8))
+    path = os.path.join(OUT, f"shape3d_{name}_s{seed}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "T=", t, "ep_len=", ep_len, "max stats", np.array(rec["stats"]).max(0), os.path.getsize(path), "bytes", flush=True)
+
+
+def gen_stats_mc3d_big():
+    """Minecraft3DmazeProblem.get_stats known answers at 15^3 and 10^3: random densities, degenerate maps, a staircase."""
+    rng = np.random.default_rng(77)
+    out = {}
+    for shape, n in (((15, 15, 15), 36), ((10, 10, 10), 40)):
+        core = _problem("minecraft_3D_maze", shape)
+        grids = [np.zeros(shape, np.uint8), np.ones(shape, np.uint8)]
+        g = np.ones(shape, np.uint8)  # a staircase corridor along x climbing in z, two tiles of head-room
+        for x in range(shape[2]):
+            z0 = min(1 + x // 2, shape[0] - 3)
+            g[z0:z0 + 3, shape[1] // 2, x] = 0
+        grids.append(g)
+        g = np.ones(shape, np.uint8)  # a floor with a one-tile gap every third column (jumps)
+        g[2:5, :, :] = 0
+        g[1, :, 2::3] = 0
+        g[0, :, 2::3] = 0
+        grids.append(g)
+        for i in range(n):
+            grids.append((rng.random(shape) < rng.uniform(0.08, 0.75)).astype(np.uint8))
+        grids = np.array(grids, np.uint8)
+        stats = np.array([_get_stats(core, "minecraft_3D_maze", g) for g in grids], np.int32)
+        key = "x".join(str(s) for s in shape)
+        out["grids_" + key], out["stats_" + key] = grids, stats
+        print("stats_mc3d_big", key, grids.shape, "max", stats.max(0), "jumps>0", int((stats[:, 2] > 0).sum()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "stats_mc3dmaze_big.npz"), stat_keys=np.array(STAT_KEYS["minecraft_3D_maze"]), **out)
+
+
+def run_control_episode_3d(seed, shape=(7, 7, 7), controls=("n_jump", "path-length"), n_steps=150):
+    """Controllable 3-D maze (configs/config.py:195-205: controls n_jump, path-length).  The reference's
+    ControlWrapper cannot be built with ctrl_metrics on this problem -- its __init__ reads observation_space.shape of a
+    Dict space (control_wrappers.py:97-100) -- so the targets are set through the same wrapper built without them
+    (set_trgs -> do_set_trgs -> metric_trgs, :168-178; the loss then uses them like any static target, :318-345).
+    What the control observation WOULD show follows observe_metric_trgs (:189-214) from values the reference holds:
+    (target, metric) / |cond_bounds[k][1] - cond_bounds[k][0]| per control metric."""
+    problem, rep = "minecraft_3D_maze", "narrow"
+    cfg = ref_env.make_cfg(problem, rep, shape)
+    env = ref_env.make_reference_env(cfg, seed=seed)
+    core = env.unwrapped
+    arng = np.random.default_rng(2000 + seed)
+    trng = np.random.default_rng(3000 + seed)
+    ranges = {k: abs(env.cond_bounds[k][1] - env.cond_bounds[k][0]) for k in controls}
+    rec = dict(action=[], reward=[], done=[], stats=[], ctrl=[], overlay_crc=[], reset_at=[])
+    resets = dict(ctrl=[], stats=[], trg=[])
+    t = 0
+
+    def ctrl_now(trg):
+        out = []
+        for k, v in zip(controls, trg):
+            out += [v / ranges[k], float(core._rep_stats[k]) / ranges[k]]
+        return np.array(out, np.float64)
+
+    for ep in range(2):
+        trg = []
+        for k in controls:
+            lb, ub = env.cond_bounds[k]
+            trg.append(float(trng.random() * (ub - lb) + lb))
+        env.set_trgs(dict(zip(controls, trg)))
+        obs, _ = env.reset()
+        resets["ctrl"].append(ctrl_now(trg)); resets["stats"].append(stats_vec(problem, core._rep_stats)); resets["trg"].append(trg)
+        rec["reset_at"].append(t)
+        for _ in range(n_steps):
+            a = int(arng.integers(2))
+            obs, r, d, tr_, info = env.step(a)
+            rec["action"].append(a); rec["reward"].append(float(r)); rec["done"].append(bool(d))
+            rec["stats"].append(stats_vec(problem, core._rep_stats)); rec["ctrl"].append(ctrl_now(trg))
+            rec["overlay_crc"].append(zlib.crc32(np.asarray(obs["map"]).astype(np.uint8).tobytes()))
+            t += 1
+    out = dict(problem=problem, representation=rep, map_shape=np.array(shape), seed=seed, controls=np.array(controls),
+               stat_keys=np.array(STAT_KEYS[problem]), steps_per_episode=n_steps,
+               cond_bounds=np.array([env.cond_bounds[k] for k in controls], np.float64),
+               action=np.array(rec["action"], np.int32), reward=np.array(rec["reward"], np.float64), done=np.array(rec["done"]),
+               stats=np.array(rec["stats"], np.int32), ctrl=np.array(rec["ctrl"], np.float64),
+               overlay_crc=np.array(rec["overlay_crc"], np.uint32), reset_at=np.array(rec["reset_at"], np.int32),
+               reset_ctrl=np.array(resets["ctrl"], np.float64), reset_stats=np.array(resets["stats"], np.int32),
+               reset_trg=np.array(resets["trg"], np.float64))
+    path = os.path.join(OUT, f"control3d_mc3dmaze_narrow_s{seed}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "ret", sum(rec["reward"]), "ctrl[0]", rec["ctrl"][0], "bounds", out["cond_bounds"].tolist())
+
+
+if __name__ == "__main__" and "shapes3d" in sys.argv[1:]:
+    run_shape_episode_3d("mc3dmaze_narrow_15", 81)
+    run_shape_episode_3d("mc3dmaze_narrow_10", 82)
+    gen_stats_mc3d_big()
+    run_control_episode_3d(11)

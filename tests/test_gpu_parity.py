@@ -181,6 +181,99 @@ def test_mc3dmaze_other_shapes_vs_oracle():
     _rollout_vs_oracle("minecraft_3D_maze", "narrow", (8, 7, 9), 17, 300, full_every=41)
 
 
+SHAPES3D = sorted(glob.glob(os.path.join(GOLDEN, "shape3d_*.npz")))
+
+
+def _expected_obs_3d(shape, overlay_map, pos):
+    m = overlay_map.reshape(shape).astype(np.int64) + 1
+    ow = tuple(2 * s for s in shape)
+    padded = np.pad(m, [(w // 2, w // 2) for w in ow], constant_values=0)
+    sl = tuple(slice(int(p), int(p) + w) for p, w in zip(pos, ow))
+    return np.eye(4, dtype=np.uint8)[padded[sl]]
+
+
+@pytest.mark.parametrize("path", SHAPES3D, ids=[os.path.basename(p)[8:-4] for p in SHAPES3D])
+def test_golden_shape3d_episode_replay(path):
+    """minecraft_3D_maze at the reference's stock map size 15 x 15 x 15 (configs/config.py:153-157) and at 10 x 10 x 10
+    against reference episodes: reset from the seed alone, every step's grid, position, stats, reward, done, counters;
+    the observation (incl. the path overlay) where the fixture holds the reference's obs dict in full."""
+    z = np.load(path)
+    shape = tuple(int(s) for s in z["map_shape"])
+    env = _vec("minecraft_3D_maze", "narrow", shape, 1, seeds=[int(z["seed"])], auto_reset=False,
+               change_percentage=float(z["change_percentage"]))
+    T, ep_len = len(z["action"]), int(z["episode_len"])
+    full = {int(s): i for i, s in enumerate(z["full_steps"])}
+
+    def check_reset(k):
+        obs, _ = env.reset()
+        st = env.get_state()
+        assert np.array_equal(st.grids[0].cpu().numpy().ravel(), z["reset_grid"][k]), "reset grid (RNG stream)"
+        assert np.array_equal(st.pos[0].cpu().numpy(), z["reset_pos"][k])
+        assert np.array_equal(st.stats[0].cpu().numpy(), z["reset_stats"][k])
+        assert np.array_equal(obs[0].cpu().numpy(), _expected_obs_3d(shape, z["reset_overlay"][k], z["reset_pos"][k]))
+
+    check_reset(0)
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    for t in range(T):
+        obs, rew, done, _, info = env.step(acts[t:t + 1])
+        st = env.get_state()
+        assert zlib.crc32(st.grids[0].cpu().numpy().astype(np.uint8).tobytes()) == int(z["grid_crc"][t]), f"grid @ {t}"
+        assert np.array_equal(st.pos[0].cpu().numpy(), z["pos"][t]), f"pos @ {t}"
+        got = info["stats"][0].cpu().numpy()
+        assert np.array_equal(got, z["stats"][t]), f"stats @ {t}: {got} vs {z['stats'][t]}"
+        assert abs(float(rew[0]) - z["reward"][t]) <= REW_TOL, f"reward @ {t}"
+        assert bool(done[0]) == bool(z["done"][t]), f"done @ {t}"
+        assert int(st.changes[0]) == z["changes"][t] and int(st.iteration[0]) == z["iterations"][t]
+        if t in full:
+            assert np.array_equal(obs[0].cpu().numpy(), _expected_obs_3d(shape, z["overlay_full"][full[t]], z["pos"][t])), f"obs/overlay @ {t}"
+        if t == ep_len - 1:
+            check_reset(1)
+    env.check_errors()
+
+
+def test_golden_mc3dmaze_big_stats_known_answers():
+    z = np.load(os.path.join(GOLDEN, "stats_mc3dmaze_big.npz"))
+    for key in ("15x15x15", "10x10x10"):
+        grids = z["grids_" + key]
+        env = _vec("minecraft_3D_maze", "narrow", grids.shape[1:], 1, auto_reset=False)
+        got = env.stats_for_grids(torch.as_tensor(grids)).cpu().numpy()
+        bad = np.nonzero((got != z["stats_" + key]).any(axis=1))[0]
+        assert len(bad) == 0, f"{key}: {len(bad)} grids differ, first {bad[:5]}: got {got[bad[:3]]} want {z['stats_' + key][bad[:3]]}"
+        env.check_errors()
+
+
+def test_golden_controllable_3d_episode_replay():
+    """controls n_jump / path-length on the 3-D maze (configs/config.py:195-205) against the reference's rewards for
+    float targets set through ControlWrapper.set_trgs, and the control observation by the reference's formula."""
+    z = np.load(os.path.join(GOLDEN, "control3d_mc3dmaze_narrow_s11.npz"))
+    shape = tuple(int(s) for s in z["map_shape"])
+    controls = [str(c) for c in z["controls"]]
+    env = _vec("minecraft_3D_maze", "narrow", shape, 1, seeds=[int(z["seed"])], auto_reset=False, controls=controls,
+               reward_dtype=torch.float64)
+    n, t = int(z["steps_per_episode"]), 0
+    acts = torch.as_tensor(z["action"], dtype=torch.int32, device=env.device)
+    for ep in range(len(z["reset_at"])):
+        env.queue_targets({k: float(v) for k, v in zip(controls, z["reset_trg"][ep])})
+        obs, info = env.reset()
+        assert np.array_equal(env.get_state().stats[0].cpu().numpy(), z["reset_stats"][ep])
+        assert np.allclose(info["ctrl_obs"][0].cpu().numpy(), z["reset_ctrl"][ep], rtol=1e-6, atol=1e-7)
+        for _ in range(n):
+            obs, rew, done, _, info = env.step(acts[t:t + 1])
+            assert np.array_equal(info["stats"][0].cpu().numpy(), z["stats"][t]), f"stats @ {t}"
+            assert abs(float(rew[0]) - z["reward"][t]) <= 1e-9, f"reward @ {t}"
+            assert np.allclose(info["ctrl_obs"][0].cpu().numpy(), z["ctrl"][t], rtol=1e-6, atol=1e-7), f"ctrl @ {t}"
+            t += 1
+    env.check_errors()
+
+
+def test_mc3dmaze_stock_size_batch_vs_oracle():
+    """15 x 15 x 15 and 10 x 10 x 10 (planes of more than 64 cells: the multi-word kernels) in batches across
+    auto-resets, against the oracle: every step's stats / reward / done, full state and observations now and then."""
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (15, 15, 15), 48, 420, full_every=59, change_percentage=0.03)
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (10, 10, 10), 65, 500, full_every=71, change_percentage=0.1)
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (16, 16, 16), 9, 150, full_every=37, change_percentage=0.01)
+
+
 def test_binary_narrow_4096_envs_vs_oracle():
     """BASELINE configs[1]: binary-narrow 16x16, 4096 envs on one MI355X, bit-exact state check vs CPU,
     across an auto-reset boundary (episode = 770 steps)."""
@@ -823,7 +916,8 @@ def test_auto_reset_every_few_steps_4096_envs_vs_oracle(problem, rep):
 
 @pytest.mark.parametrize("problem,rep,shape", [("binary", "narrow", (16, 16)), ("binary", "turtle", (20, 24)),
                                                ("zelda", "narrow", (16, 16)), ("sokoban", "turtle", (16, 16)),
-                                               ("binary", "narrow", (40, 48))])
+                                               ("binary", "narrow", (40, 48)), ("minecraft_3D_maze", "narrow", (7, 7, 7)),
+                                               ("minecraft_3D_maze", "narrow", (10, 10, 10))])
 def test_update_then_step_without_refresh_vs_oracle(problem, rep, shape):
     """pcgrl_update leaves the statistics stale; the next CHANGING pcgrl_step must recompute them from scratch (the
     reference's get_stats, pcgrl_env.py:314-323) -- not incrementally from the stale masks -- and non-changing steps in
