@@ -17,7 +17,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "pcgrl_amd.h")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-falign-loops=32", "-fPIC"]
 
 PCGRL_MAX_STATS = 8
-ERRORS = {1: "EINVAL", 2: "EUNSUPPORTED", 3: "EHIP", 4: "EACTION"}
+ERRORS = {1: "EINVAL", 2: "EUNSUPPORTED", 3: "EHIP", 4: "EACTION", 5: "ESTALE"}
 
 
 class PcgrlConfig(C.Structure):

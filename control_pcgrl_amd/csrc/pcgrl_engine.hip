@@ -921,6 +921,9 @@ int pcgrl_poll_error(pcgrl_handle h) {
     if (flags[0] & 1) return fail(PCGRL_EACTION, "an action was outside the action space (the reference raises IndexError)");
     if (flags[0] & 2) return fail(PCGRL_EUNSUPPORTED, "sokoban solver: level exceeds the device solver's limits");
     if (flags[0] & 4) return fail(PCGRL_EUNSUPPORTED, "3-D maze path search: more live queue entries than the search ring holds (1024 for planes of <= 64 cells, else 4096); the statistics of that step were kept at their previous values");
+    if (flags[0] & 8)
+      return fail(PCGRL_ESTALE, "a step launch issued before pcgrl_update (a replayed HIP graph?) met statistics that pcgrl_update "
+                                "left stale: re-capture after pcgrl_update or call pcgrl_refresh_stats first (include/pcgrl_amd.h, HIP graphs)");
     return fail(PCGRL_EINVAL, "device error flag set");
   }
   return PCGRL_OK;

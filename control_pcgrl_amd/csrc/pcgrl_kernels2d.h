@@ -591,7 +591,7 @@ __device__ inline void sokoban_helpers_init();
 __device__ inline void sokoban_helpers_release();
 struct SokoHelpersGuard {  // the simulate wave lets its helpers go when it leaves the kernel, whichever way
   bool on;
-  __device__ ~SokoHelpersGuard() {
+  __device__ __attribute__((always_inline)) ~SokoHelpersGuard() {  // (out of line it costs every lane a 64-byte stack frame)
     if (on) sokoban_helpers_release();
   }
 };
@@ -1125,9 +1125,16 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
                          [&](int i) -> const uint8_t * { return lds + (gb + i) * stride; });
       return;
     }
-    if (active && g.row < H) {
-      uint8_t *dst = obs_base + ((size_t)env * H + g.row) * row_bytes;
-      for (int q = 0; q < chunks; q++) store_obs16(dst + q * 16, *(uint4 *)(row + q * 16));
+    if (active) {
+      // the env's observation as consecutive 16-byte chunks, lane r of the group taking chunks r, r + LPE, ...: every
+      // store instruction covers LPE * 16 contiguous bytes (whole cache lines; lane-per-row stores left every line to be
+      // written piecewise by several instructions, which write-through stores turn into 2 x the HBM write traffic)
+      uint8_t *base = obs_base + (size_t)env * H * row_bytes;
+      const int stride = lds_row_stride(row_bytes), total = H * chunks;
+      for (int k = g.row; k < total; k += LPE) {
+        const int i = k / chunks, q = k - i * chunks;
+        store_obs16(base + (size_t)k * 16, *(const uint4 *)(lds + (g.gbase + i) * stride + q * 16));
+      }
     }
     return;
   }
@@ -1703,6 +1710,12 @@ void step_kernel(Params p) {
   // no code for it (it costs them 4 % at large batches): while stale envs may exist the host launches the general kernel
   // (Params::no_fast), which also drops the PREFLOOD plane it does not maintain.
   const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change && map_changed;
+  if constexpr (FAST) {
+    // Which kernel runs is a HOST decision (Params::no_fast) that a captured HIP graph freezes: a graph captured before
+    // pcgrl_update and replayed after it lands here with stale statistics.  Never silently: the launch raises error
+    // bit 8 (pcgrl_poll_error -> PCGRL_ESTALE) instead of updating incrementally from stale masks.
+    if ((flags & ENV_STATS_DIRTY) != 0 && change && map_changed && active && g.row == 0) atomicOr(p.err, 8);
+  }
   if constexpr (PROB == PCGRL_PROB_BINARY && !FAST) {
     if (p.no_fast && rowok) *pre_word = M(0);
   }
@@ -1884,6 +1897,9 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
     } else {
       const bool restat = change && map_changed;
       const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && restat;  // first changing step after pcgrl_update
+      if constexpr (FAST) {  // (see step_kernel: a captured launch replayed after pcgrl_update)
+        if ((flags & ENV_STATS_DIRTY) != 0 && restat && active && g.row == 0) atomicOr(p.err, 8);
+      }
       if (!FAST && __ballot(stale) != 0) {
         int32_t ns[NS];
         compute_stats<PROB, LPE, M>(g, p, e, stale && active, b, colmask, ns);

@@ -33,6 +33,20 @@
  *     destroy / seed / poll_error are asynchronous on that stream.
  *   - return value 0 = success, otherwise a PCGRL_E* code; pcgrl_last_error() gives the message.
  *   - one handle per (process, GPU); a handle is not re-entrant; several handles may coexist.
+ *
+ * HIP graphs.  Every asynchronous entry point may be captured into a HIP graph (it only enqueues kernels on `stream`)
+ * and replayed with new contents in the same buffers.  Three host-side decisions are taken when a launch is ISSUED and are
+ * therefore frozen into a captured launch:
+ *   - which step / rollout kernel runs: the compile-time 16x16 kernels carry no code for statistics left stale by
+ *     pcgrl_update (the reference recomputes them from scratch at the next changing step, pcgrl_env.py:314-323), so after
+ *     pcgrl_update the engine issues the general kernels until pcgrl_refresh_stats or a full reset.  A graph captured
+ *     BEFORE pcgrl_update and replayed AFTER it would update stale statistics incrementally: such a launch raises a
+ *     device error bit instead (pcgrl_poll_error returns PCGRL_ESTALE; the statistics of the affected envs are
+ *     undefined until pcgrl_refresh_stats or a reset).  Re-capture after pcgrl_update, or call pcgrl_refresh_stats
+ *     before replaying.
+ *   - sokoban: whether a step launch gives every env a workgroup of its own and carries the solver's helper wavefronts
+ *     (chosen from how recently the device solver ran).  Performance only; results do not depend on it.
+ *   - pcgrl_set_static: the static-tile parameters in force when the launch was issued.
  */
 #ifndef PCGRL_AMD_H
 #define PCGRL_AMD_H
@@ -51,7 +65,8 @@ enum {
   PCGRL_EINVAL = 1,       /* bad argument / config */
   PCGRL_EUNSUPPORTED = 2, /* problem x representation x shape not supported by the kernels */
   PCGRL_EHIP = 3,         /* HIP runtime error */
-  PCGRL_EACTION = 4       /* an out-of-range action was seen on the device (pcgrl_poll_error) */
+  PCGRL_EACTION = 4,      /* an out-of-range action was seen on the device (pcgrl_poll_error) */
+  PCGRL_ESTALE = 5        /* a captured launch met stale statistics (see "HIP graphs" below; pcgrl_poll_error) */
 };
 
 /* Stat order per problem (columns of every `stats` array):
@@ -216,7 +231,9 @@ int pcgrl_get_rng_state(pcgrl_handle h, uint64_t *d_out, void *stream);
 int pcgrl_set_rng_state(pcgrl_handle h, const uint8_t *d_mask, const uint64_t *d_in, void *stream);
 
 /* Synchronises the device and returns PCGRL_EACTION if any kernel saw an out-of-range action since the
- * last poll (the reference raises IndexError there), PCGRL_EHIP on a pending HIP error, else 0. */
+ * last poll (the reference raises IndexError there), PCGRL_EUNSUPPORTED if a level / search exceeded the device
+ * solver's or the 3-D path search's limits, PCGRL_ESTALE if a captured launch met stale statistics (see "HIP graphs"),
+ * PCGRL_EHIP on a pending HIP error, else 0. */
 int pcgrl_poll_error(pcgrl_handle h);
 /* Development aid: copies n 64-bit device counters to `out` (HOST pointer) and zeroes them.  They are only written by
  * a library built with -DPCGRL_PHASE_TIMING (tools/phase_timing.py); otherwise all zero. */

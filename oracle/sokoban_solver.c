@@ -266,6 +266,8 @@ static int make_root(pool_t *p, int px, int py, const uint8_t *crates) {
   return r;
 }
 
+static __thread int dbg_iters, dbg_exhausted;
+
 #define BETTER(p, cur, best) \
   ((best) < 0 || (p)->nodes[cur].h < (p)->nodes[best].h || ((p)->nodes[cur].h == (p)->nodes[best].h && (p)->nodes[cur].depth < (p)->nodes[best].depth))
 
@@ -304,6 +306,8 @@ static int solve_bfs(const level_t *lv, int px, int py, const uint8_t *crates, i
   *res_h = p.nodes[best].h;
   *res_depth = p.nodes[best].depth;
 done:
+  dbg_iters = iters;
+  dbg_exhausted = !won && head >= tail;
   free(q);
   free(key);
   vset_free(&vs);
@@ -388,6 +392,8 @@ static int solve_astar(const level_t *lv, int px, int py, const uint8_t *crates,
   *res_h = p.nodes[best].h;
   *res_depth = p.nodes[best].depth;
 done:
+  dbg_iters = iters;
+  dbg_exhausted = !won && hn == 0;
   free(heap);
   free(key);
   vset_free(&vs);
@@ -395,6 +401,14 @@ done:
   return won;
 #undef SIFTDOWN
 #undef HEAPPUSH
+}
+
+/* development counters (tools/solver_hist.py): calls, BFS pops, BFS wins, BFS exhausted, A* stages run, A* pops, A* wins,
+ * A* exhausted; [8 + b]: calls whose total pops fall into [2^b, 2^(b+1)) */
+long long orc_solver_hist[40];
+static void hist_add(int i, long long v) {
+#pragma omp atomic
+  orc_solver_hist[i] += v;
 }
 
 /* sokoban_prob.py:99-148 _run_game.  grid tiles: 0 empty 1 solid 2 player 3 crate 4 target.
@@ -419,8 +433,28 @@ void orc_sokoban_solve(const uint8_t *grid, int H, int W, int power, int *dist_w
   init_deadlocks(&lv);
   int h = 0, depth = 0;
   *sol_len = 0;
-  if (solve_bfs(&lv, px, py, crates, power, &h, &depth) || solve_astar(&lv, px, py, crates, 1.0, power, &h, &depth) ||
-      solve_astar(&lv, px, py, crates, 0.5, power, &h, &depth) || solve_astar(&lv, px, py, crates, 0.0, power, &h, &depth)) {
+  long long total = 0;
+  int won = solve_bfs(&lv, px, py, crates, power, &h, &depth);
+  hist_add(0, 1);
+  hist_add(1, dbg_iters);
+  hist_add(2, won);
+  hist_add(3, dbg_exhausted);
+  total += dbg_iters;
+  static const double BAL[3] = {1.0, 0.5, 0.0};
+  for (int k = 0; k < 3 && !won; k++) {
+    won = solve_astar(&lv, px, py, crates, BAL[k], power, &h, &depth);
+    hist_add(4, 1);
+    hist_add(5, dbg_iters);
+    hist_add(6, won);
+    hist_add(7, dbg_exhausted);
+    total += dbg_iters;
+  }
+  {
+    int b = 0;
+    while ((1ll << (b + 1)) <= total && b < 30) b++;
+    hist_add(8 + b, 1);
+  }
+  if (won) {
     *dist_win = 0;
     *sol_len = depth;
   } else {

@@ -1308,3 +1308,65 @@ def test_sokoban_wide_2048_envs_solver_inside_episodes_vs_oracle():
         solved += int((got[:, 5] > 0).sum())
     assert active > 0.12 * 24 * n and solved > 0.03 * 24 * n, (active, solved)  # thousands of searches inside step launches
     env.check_errors()
+
+
+@pytest.mark.parametrize("problem,rep", [("binary", "narrow"), ("zelda", "turtle")])
+def test_step_graph_replay_vs_oracle(problem, rep):
+    """VecPcgrlEnv.step captured once in a HIP graph (static action buffer) and replayed with fresh actions across
+    auto-resets equals the oracle step for step; a replay AFTER pcgrl_update -- the captured launch is the compile-time
+    16x16 kernel, which has no code for the statistics pcgrl_update leaves stale -- is reported (PCGRL_ESTALE), never a
+    silent divergence; after a reset the same graph is good again.  (include/pcgrl_amd.h, "HIP graphs")"""
+    n, shape = 192, (16, 16)
+    seeds = 40 + np.arange(n)
+    env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=True)
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8)
+    env.reset(); orc.reset()
+    gen = torch.Generator().manual_seed(3)
+    static_a = torch.zeros(n, dtype=torch.int32, device=env.device)
+
+    def draw():
+        return torch.randint(0, env.num_actions, (n,), generator=gen, dtype=torch.int32)
+
+    for _ in range(3):  # (eager warm-up before the capture)
+        a = draw()
+        env.step(a.to(env.device)); orc.step(a.numpy(), auto_reset=True, want_obs=False)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            obs, rew, done, _, info = env.step(static_a)
+    torch.cuda.current_stream().wait_stream(side)
+    T = 1000  # episode length 770: the replays cross the auto-reset
+    for t in range(T):
+        a = draw()
+        static_a.copy_(a)
+        graph.replay()
+        want_obs = t % 97 == 0 or t == T - 1
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want_obs)
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL, f"reward @ {t}"
+        assert np.array_equal(done.cpu().numpy(), odone), f"done @ {t}"
+        if want_obs:
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+    env.check_errors()
+    # pcgrl_update leaves statistics stale; the captured launch cannot handle that and must say so
+    for _ in range(6):
+        a = draw()
+        env.update(a.to(env.device), want_obs=False); orc.update(a.numpy())
+    for t in range(40):
+        static_a.copy_(draw())
+        graph.replay()
+    with pytest.raises(RuntimeError, match="ESTALE"):
+        env.check_errors()
+    # ... and a full reset makes the same graph valid again
+    env.reset(); orc.reset()
+    for t in range(60):
+        a = draw()
+        static_a.copy_(a)
+        graph.replay()
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=(t == 59))
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats after reset @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    env.check_errors()
