@@ -68,6 +68,9 @@ SYMBOLS = {
     "pcgrl_stats_cache_clear": (None, []),
     "pcgrl_reduce_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pcgrl_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "pcgrl_state_bytes": (C.c_int64, [C.c_void_p]),
+    "pcgrl_export_state": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "pcgrl_import_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pcgrl_get_rng_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_set_rng_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_poll_error": (C.c_int, [C.c_void_p]),
@@ -130,7 +133,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or control_pcgrl_amd._lib.build()).  There is no CPU fallback.")
-        override = os.environ.get("PCGRL_LIB")  # development: load another build of the same ABI (A/B timing)
+        # development: another build of the same ABI for A/B timing -- only a file of this package's csrc directory
+        override = os.environ.get("PCGRL_LIB")
+        if override and os.path.dirname(os.path.realpath(override)) != os.path.realpath(CSRC):
+            raise RuntimeError(f"PCGRL_LIB={override}: only libraries inside {CSRC} are loaded")
         L = C.CDLL(override or LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             if override and not hasattr(L, name):

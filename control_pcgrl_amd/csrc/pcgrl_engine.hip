@@ -51,6 +51,8 @@ struct pcgrl_engine {
   int32_t obs_shape[4] = {0, 0, 0, 0};
   RedScratch *red = nullptr;  // pcgrl_reduce_episodes block partials
   std::vector<void *> allocs;
+  // the persistent per-env arrays (pointer, bytes per env): what pcgrl_export_state / pcgrl_import_state carry
+  std::vector<std::pair<void *, size_t>> state_arrays;
 };
 
 // ---------------------------------------------------------------------------------------------- RNG seeding (host)
@@ -397,6 +399,14 @@ __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, 
   }
 }
 
+// pcgrl_import_state with a mask: rows (envs) of one state array, 4 bytes per thread
+__global__ __launch_bounds__(256) void masked_rows_copy_kernel(uint32_t *dst, const uint32_t *src, int64_t words_per_env, int32_t n_envs,
+                                                              const uint8_t *mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= words_per_env * n_envs) return;
+  if (mask[i / words_per_env]) dst[i] = src[i];
+}
+
 }  // namespace pcgrl
 
 // sokoban: while the device solver has been running in recent launches, step with one env per wavefront (every search gets
@@ -543,6 +553,23 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     CREATE_CHK(hipMemcpy(p.trg, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
   }
 #undef CREATE_CHK
+  {
+    const size_t plane_bytes = is3d ? (size_t)m3_layout(cfg->dims[0], cfg->dims[1], cfg->dims[2]).rec_words * sizeof(uint32_t)
+                                    : (size_t)ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t));
+    e->state_arrays.push_back({p.planes, plane_bytes});
+    e->state_arrays.push_back({p.st, sizeof(EnvState)});
+    e->state_arrays.push_back({p.rng, sizeof(RngState)});
+    if (p.xplanes) {
+      const size_t mbytes = W > 32 ? sizeof(uint64_t) : sizeof(uint32_t);
+      e->state_arrays.push_back({p.xplanes, (size_t)(1 + (p.n_tiles <= 2 ? 1 : 3)) * H * mbytes});
+      e->state_arrays.push_back({p.xstate, 4 * sizeof(uint32_t)});
+    }
+    if (p.trg) {
+      e->state_arrays.push_back({p.trg, PCGRL_MAX_STATS * 2 * sizeof(double)});
+      e->state_arrays.push_back({p.trg_pending, PCGRL_MAX_STATS * 2 * sizeof(double)});
+      e->state_arrays.push_back({p.trg_flag, sizeof(int32_t)});
+    }
+  }
   *out = e;
   // default seeding: env i gets seed i (callers normally call pcgrl_seed)
   std::vector<uint64_t> seeds(n_envs);
@@ -809,7 +836,7 @@ static int stats_engine_for(const pcgrl_config &cfg, int device, pcgrl_handle *o
   auto it = g_stats_engines.find(key);
   if (it == g_stats_engines.end()) {
     pcgrl_handle h = nullptr;
-    int rc = pcgrl_create(&c, 64, device, &h);  // 64 "envs": sizes the sokoban solver's workspace pool
+    int rc = pcgrl_create(&c, 256, device, &h);  // 256 "envs": sizes the sokoban solver's workspace pool (64 slots)
     if (rc) return rc;
     it = g_stats_engines.emplace(key, h).first;
   }
@@ -880,6 +907,49 @@ int pcgrl_set_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_grid
   p.set_state = 1;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   if (d_mask == nullptr) h->maybe_stale = false;
+  return PCGRL_OK;
+}
+
+static size_t state_section(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+int64_t pcgrl_state_bytes(pcgrl_handle h) {
+  if (!h) return -1;
+  size_t total = 0;
+  for (auto &a : h->state_arrays) total += state_section(a.second * (size_t)h->p.n_envs);
+  return (int64_t)total;
+}
+
+int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out, void *stream) {
+  if (!h || !d_buf) return fail(PCGRL_EINVAL, "pcgrl_export_state: bad arguments");
+  ON_DEVICE(h->device);
+  size_t off = 0;
+  for (auto &a : h->state_arrays) {
+    const size_t bytes = a.second * (size_t)h->p.n_envs;
+    HIPCHK(hipMemcpyAsync(d_buf + off, a.first, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    off += state_section(bytes);
+  }
+  if (maybe_stale_out) *maybe_stale_out = h->maybe_stale ? 1 : 0;
+  return PCGRL_OK;
+}
+
+int pcgrl_import_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_buf, int32_t maybe_stale, void *stream) {
+  if (!h || !d_buf) return fail(PCGRL_EINVAL, "pcgrl_import_state: bad arguments");
+  ON_DEVICE(h->device);
+  size_t off = 0;
+  for (auto &a : h->state_arrays) {
+    const size_t bytes = a.second * (size_t)h->p.n_envs;
+    if (d_mask == nullptr) {
+      HIPCHK(hipMemcpyAsync(a.first, d_buf + off, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    } else {
+      const int64_t wpe = (int64_t)(a.second / 4), total = wpe * h->p.n_envs;  // (every array's row is a multiple of 4 bytes)
+      hipLaunchKernelGGL(masked_rows_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (uint32_t *)a.first, (const uint32_t *)(d_buf + off), wpe, h->p.n_envs, d_mask);
+      HIPCHK(hipGetLastError());
+    }
+    off += state_section(bytes);
+  }
+  // the imported envs may carry statistics left stale by pcgrl_update: the host-side kernel choice follows the exporter's
+  h->maybe_stale = d_mask == nullptr ? (maybe_stale != 0) : (h->maybe_stale || maybe_stale != 0);
   return PCGRL_OK;
 }
 

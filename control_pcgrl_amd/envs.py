@@ -20,6 +20,8 @@ except Exception:  # pragma: no cover - gymnasium is not in the build image
 
     class Box:
         def __init__(self, low, high, shape=None, dtype=np.float32):
+            if shape is None:  # array bounds, like gymnasium
+                shape = np.shape(low)
             self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
 
         def __repr__(self):
@@ -63,7 +65,10 @@ class PcgrlGymEnv:
         shape = v.obs_shape[:-1] + (v.obs_shape[-1] + self._n_ctrl_planes,)
         # ToImage takes high = max over the stacked spaces (wrappers.py:113-123); the control planes are declared
         # Box(0, 1) by the reference (control_wrappers.py:96-104) although target / range can leave that interval
-        self.observation_space = Box(low=0, high=1, shape=shape, dtype=np.float32)
+        if self._n_ctrl_planes:  # control_wrappers.py:96-104: low / high arrays, zeros / ones for the control planes
+            self.observation_space = Box(low=np.zeros(shape, np.float32), high=np.ones(shape, np.float32), dtype=np.float32)
+        else:
+            self.observation_space = Box(low=0, high=1, shape=shape, dtype=np.float32)
         if v.act_window:  # envs/reps/wrappers.py:434-439: one tile id per cell of the action patch
             self.action_space = MultiDiscrete([v.spec.n_tiles] * v.action_entries)
         else:

@@ -400,18 +400,32 @@ class VecPcgrlEnv:
                                                self._stream()), "pcgrl_set_rng_state")
 
     def state_dict(self):
-        """Everything needed to continue bit-exactly later: maps, positions, counters, running returns, RNG streams."""
+        """Everything needed to continue bit-exactly later.  `blob` is the engine's complete per-env state
+        (pcgrl_export_state: maps, incremental-statistics masks, counters, statistics, returns and episode totals, RNG
+        streams, static-tile masks / lagging bordered planes / spare RNG half, active and queued control targets, the 3-D
+        move table and cached searches) -- what pickling the reference's env keeps (pcgrl_env.py:102-112,
+        reps/wrappers.py:80-87); the portable fields (maps, positions, counters, returns, RNG streams) ride along."""
         st = self.get_state()
+        blob = torch.empty(int(self._L.pcgrl_state_bytes(self._h)), dtype=torch.uint8, device=self.device)
+        stale = C.c_int32(0)
+        _lib.check(self._L.pcgrl_export_state(self._h, blob.data_ptr(), C.byref(stale), self._stream()), "pcgrl_export_state")
         return {"grids": st.grids.clone(), "pos": st.pos.clone(), "counters": st.counters.clone(),
-                "ep_return": st.ep_return.clone(), "rng": self.get_rng_state()}
+                "ep_return": st.ep_return.clone(), "rng": self.get_rng_state(), "blob": blob, "maybe_stale": int(stale.value)}
 
     def load_state_dict(self, sd, mask=None):
         def dev(t, dtype):
             return torch.as_tensor(t, device=self.device).to(dtype).contiguous()
 
+        m = None if mask is None else dev(mask, torch.uint8)
+        if "blob" in sd:
+            b = dev(sd["blob"], torch.uint8)
+            if b.numel() != int(self._L.pcgrl_state_bytes(self._h)):
+                raise ValueError("state_dict from an engine with another config or batch size")
+            _lib.check(self._L.pcgrl_import_state(self._h, m.data_ptr() if m is not None else None, b.data_ptr(),
+                                                  int(sd.get("maybe_stale", 1)), self._stream()), "pcgrl_import_state")
+            return
         g, p, c = dev(sd["grids"], torch.uint8), dev(sd["pos"], torch.int32), dev(sd["counters"], torch.int32)
         r = dev(sd["ep_return"], torch.float64)
-        m = None if mask is None else dev(mask, torch.uint8)
         assert g.numel() == self.num_envs * self.n_cells and p.shape == (self.num_envs, 3) and c.shape == (self.num_envs, 4)
         _lib.check(self._L.pcgrl_set_state(self._h, m.data_ptr() if m is not None else None, g.data_ptr(), p.data_ptr(),
                                            c.data_ptr(), r.data_ptr(), self._stream()), "pcgrl_set_state")

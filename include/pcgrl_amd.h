@@ -25,6 +25,7 @@
  *                                  evo/evolve.py:1083-1120
  *   pcgrl_reduce_episodes          rl/callbacks.py:91-117 on_episode_end metrics, summed over the batch
  *   pcgrl_set_state / _rng_state   envs/pcgrl_env.py:102-112 get_task / set_task (env pickling = checkpoint / restore)
+ *   pcgrl_export_state / _import   the same, complete: wrapped representation (reps/wrappers.py:80-87), control targets
  *
  * Conventions
  *   - every `d_` pointer is a DEVICE pointer on the engine's GPU; the caller owns all I/O buffers,
@@ -235,6 +236,21 @@ int pcgrl_set_rng_state(pcgrl_handle h, const uint8_t *d_mask, const uint64_t *d
  * solver's or the 3-D path search's limits, PCGRL_ESTALE if a captured launch met stale statistics (see "HIP graphs"),
  * PCGRL_EHIP on a pending HIP error, else 0. */
 int pcgrl_poll_error(pcgrl_handle h);
+
+/* Checkpoint / restore of EVERYTHING the engine keeps per env (envs/pcgrl_env.py:102-112 get_task / set_task: RLlib
+ * pickles the whole env, wrapped representation included -- reps/wrappers.py:80-87): tile planes and incremental-
+ * statistics masks, counters, statistics, losses, running / last-episode returns and totals, both RNG streams, and where
+ * configured the static-tile mask with its lagging bordered-map planes and the spare half of the representation RNG's last
+ * draw, the active and queued control targets, the 3-D maze's move table and cached searches.
+ *   pcgrl_state_bytes   size of the buffer
+ *   pcgrl_export_state  d_buf uint8 [pcgrl_state_bytes]; *maybe_stale_out (host, may be NULL) = 1 when statistics left
+ *                       stale by pcgrl_update may be among them -- hand it back to pcgrl_import_state
+ *   pcgrl_import_state  into an engine created with the same config and batch size; d_mask uint8 [N] (NULL = all envs)
+ * The buffer is an opaque image for this library version and config; pcgrl_get_state / pcgrl_set_state remain the
+ * portable (maps, positions, counters) form. */
+int64_t pcgrl_state_bytes(pcgrl_handle h);
+int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out, void *stream);
+int pcgrl_import_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_buf, int32_t maybe_stale, void *stream);
 /* Development aid: copies n 64-bit device counters to `out` (HOST pointer) and zeroes them.  They are only written by
  * a library built with -DPCGRL_PHASE_TIMING (tools/phase_timing.py); otherwise all zero. */
 int pcgrl_debug_counters(pcgrl_handle h, uint64_t *out, int32_t n);

@@ -983,18 +983,31 @@ def test_reduce_episodes_equals_per_env_totals(problem, rep, shape, n):
     env.check_errors()
 
 
-@pytest.mark.parametrize("problem,rep,shape", [("binary", "narrow", (16, 16)), ("zelda", "turtle", (16, 16)),
-                                               ("sokoban", "wide", (16, 16)), ("minecraft_3D_maze", "narrow", (7, 7, 7)),
-                                               ("binary", "turtle", (40, 48))])
-def test_state_dict_round_trip_continues_bit_exactly(problem, rep, shape):
-    """checkpoint / restore (pcgrl_get_state + pcgrl_get_rng_state -> pcgrl_set_state + pcgrl_set_rng_state): a run
-    restored into ANOTHER engine continues with identical outputs, including auto-resets drawn from the restored RNG."""
+@pytest.mark.parametrize("problem,rep,shape,xkw", [
+    ("binary", "narrow", (16, 16), {}), ("zelda", "turtle", (16, 16), {}), ("sokoban", "wide", (16, 16), {}),
+    ("minecraft_3D_maze", "narrow", (7, 7, 7), {}), ("binary", "turtle", (40, 48), {}),
+    ("minecraft_3D_maze", "narrow", (10, 10, 10), {}),
+    ("binary", "narrow", (16, 16), dict(static_prob=0.3, n_static_walls=3)),
+    ("zelda", "narrow", (16, 16), dict(static_prob=0.1, n_static_walls=3, act_window=[2, 2])),
+    ("binary", "narrow", (16, 16), dict(controls=["regions", "path-length"])),
+    ("minecraft_3D_maze", "narrow", (7, 7, 7), dict(controls=["n_jump", "path-length"]))])
+def test_state_dict_round_trip_continues_bit_exactly(problem, rep, shape, xkw):
+    """checkpoint / restore (pcgrl_export_state -> pcgrl_import_state): a run restored into ANOTHER engine continues with
+    identical outputs, including auto-resets drawn from the restored RNG -- with static tiles / action patches (static
+    mask, lagging bordered planes, spare RNG half) and in controllable mode (active and queued targets) too."""
     n = 96
-    kw = dict(seeds=40 + np.arange(n), auto_reset=True, change_percentage=0.05)
+    kw = dict(seeds=40 + np.arange(n), auto_reset=True, change_percentage=0.05, **xkw)
+    if "controls" in xkw:
+        kw["reward_dtype"] = torch.float64
     env = _vec(problem, rep, shape, n, **kw)
+    if "controls" in xkw:
+        env.sample_uniform_targets(generator=torch.Generator(device=env.device).manual_seed(1))
     env.reset()
+    if "controls" in xkw:  # targets queued but not yet applied when the checkpoint is taken
+        env.sample_uniform_targets(generator=torch.Generator(device=env.device).manual_seed(2))
     g = torch.Generator().manual_seed(8)
-    acts = torch.randint(0, env.num_actions, (140, n), generator=g, dtype=torch.int32).to(env.device)
+    ashape = (140, n, env.action_entries) if env.action_entries > 1 else (140, n)
+    acts = torch.randint(0, env.spec.n_tiles if env.act_window else env.num_actions, ashape, generator=g, dtype=torch.int32).to(env.device)
     for t in range(60):
         env.step(acts[t])
     sd = env.state_dict()
@@ -1002,7 +1015,8 @@ def test_state_dict_round_trip_continues_bit_exactly(problem, rep, shape):
     for t in range(60, 140):
         obs, rew, done, _, info = env.step(acts[t])
         want.append((obs.clone(), rew.clone(), done.clone(), info["stats"].clone()))
-    other = _vec(problem, rep, shape, n, seeds=np.zeros(n, np.int64), auto_reset=True, change_percentage=0.05)
+    kw["seeds"] = np.zeros(n, np.int64)
+    other = _vec(problem, rep, shape, n, **kw)
     other.reset()
     other.load_state_dict(sd)
     st = other.get_state()
@@ -1166,6 +1180,78 @@ def test_rllib_vector_env_adapter_matches_golden(name):
                 assert info == {} and np.array_equal(o.astype(np.uint8).ravel(), zs[k]["reset_obs"][1])
     with pytest.raises(IndexError):
         env.vector_step([0, 10 ** 6, 0])
+    env.close()
+
+
+def test_rllib_vector_env_adapter_never_rewrites_what_it_returned():
+    """RLlib's collectors keep references to the observations / infos a call returned and stack them later: neither the
+    next vector_step nor a reset_at (which RLlib calls inside its per-env loop, before it has consumed the other envs'
+    last observations) may change them."""
+    from control_pcgrl_amd import PcgrlVectorEnv
+    cfg = {"task": {"problem": "binary", "map_shape": [16, 16], "obs_window": [32, 32], "weights": None},
+           "representation": "narrow", "change_percentage": 0.02}
+    n = 5
+    env = PcgrlVectorEnv(cfg, num_envs=n, seeds=list(range(n)))
+    obs0, _ = env.vector_reset()
+    keep0 = [o.copy() for o in obs0]
+    rng = np.random.default_rng(0)
+    kept = []
+    for t in range(60):
+        obs, rew, term, trunc, infos = env.vector_step(rng.integers(0, 2, n).tolist())
+        kept.append((obs, [o.copy() for o in obs], infos, [dict(infos[i]) for i in range(n)]))
+        if any(term):
+            for i in np.nonzero(term)[0]:
+                o, _ = env.reset_at(int(i))
+                # the reset of env i left every array of the last step as it was -- also those of the other finished envs
+                assert all(np.array_equal(a, b) for a, b in zip(kept[-1][0], kept[-1][1]))
+                assert not np.shares_memory(o, kept[-1][0][int(i)])
+    assert all(np.array_equal(a, b) for a, b in zip(obs0, keep0)), "vector_reset observations were overwritten"
+    for live, copy, infos, info_copy in kept:
+        assert all(np.array_equal(a, b) for a, b in zip(live, copy)), "a later call rewrote a returned observation"
+        assert [dict(infos[i]) for i in range(n)] == info_copy, "a later call changed a returned info"
+    env.close()
+
+
+def test_rllib_vector_env_adapter_controllable_and_rep_wrappers():
+    """cfg.controls through PcgrlVectorEnv: the 2 * n_ctrl constant planes in front of the one-hot channels, targets set
+    per sub-env (control_wrappers.py:168-178, :189-214), against the reference's controllable episode; and static tiles +
+    an action patch through the adapter against the reference's representation-wrapper episode."""
+    from control_pcgrl_amd import PcgrlVectorEnv
+    z = np.load(os.path.join(GOLDEN, "control_binary_narrow_s7.npz"))
+    controls = [str(c) for c in z["controls"]]
+    cfg = {"task": {"problem": "binary", "map_shape": [16, 16], "obs_window": [32, 32], "weights": {"path-length": 1, "regions": 1}},
+           "representation": "narrow", "controls": controls}
+    env = PcgrlVectorEnv(cfg, num_envs=2, seeds=[int(z["seed"]), 12345])
+    K2 = 2 * len(controls)
+    assert env.observation_space.shape == (32, 32, 3 + K2) and float(np.max(env.observation_space.high)) == 1.0
+    n, t = int(z["steps_per_episode"]), 0
+    for ep in range(len(z["reset_at"])):
+        env.get_sub_environments()[0].set_trgs({k: float(v) for k, v in zip(controls, z["reset_trg"][ep])})
+        obs = env.vector_reset()[0] if ep == 0 else [env.reset_at(0)[0], env.reset_at(1)[0]]
+        assert obs[0].shape == (32, 32, 3 + K2) and np.all(obs[0][..., :K2] == obs[0][0, 0, :K2])
+        assert np.allclose(obs[0][3, 4, :K2], z["reset_ctrl"][ep], rtol=1e-6, atol=1e-7)
+        assert zlib.crc32(obs[0][..., K2:].astype(np.uint8).tobytes()) == int(z["reset_obs_crc"][ep])
+        for _ in range(n):
+            obs, rew, term, trunc, infos = env.vector_step([int(z["action"][t]), 0])
+            assert abs(rew[0] - z["reward"][t]) <= 1e-5, f"reward @ {t}"  # (the adapter hands out float32 rewards)
+            assert np.allclose(obs[0][0, 0, :K2], z["ctrl"][t], rtol=1e-6, atol=1e-7), f"ctrl planes @ {t}"
+            assert zlib.crc32(obs[0][..., K2:].astype(np.uint8).tobytes()) == int(z["obs_crc"][t]), f"obs @ {t}"
+            assert {k: infos[0][k] for k in ("regions", "path-length")} == dict(zip(("regions", "path-length"), z["stats"][t].tolist()))
+            t += 1
+    env.close()
+
+    z = np.load(os.path.join(GOLDEN, "ext_zelda_narrow_aw2x2_sp10_sw3_s30.npz"))
+    cfg = {"task": {"problem": "zelda", "map_shape": [16, 16], "obs_window": [32, 32], "weights": None}, "representation": "narrow",
+           "static_prob": float(z["static_prob"]), "n_static_walls": int(z["n_static_walls"]), "act_window": [int(a) for a in z["act_window"]]}
+    env = PcgrlVectorEnv(cfg, num_envs=1, seeds=[int(z["seed"])])
+    n = int(z["steps_per_episode"])
+    for ep, t0 in enumerate(z["reset_at"][:2]):
+        obs = env.vector_reset()[0] if ep == 0 else [env.reset_at(0)[0]]
+        assert np.array_equal(obs[0].astype(np.uint8).ravel(), z["reset_obs"][ep])
+        for t in range(int(t0), int(t0) + n):
+            obs, rew, term, trunc, infos = env.vector_step([z["action"][t]])
+            assert zlib.crc32(obs[0].astype(np.uint8).tobytes()) == int(z["obs_crc"][t]), f"ext obs @ {t}"
+            assert abs(rew[0] - z["reward"][t]) <= REW_TOL
     env.close()
 
 
