@@ -943,3 +943,75 @@ if __name__ == "__main__" and "shapes3d" in sys.argv[1:]:
     run_shape_episode_3d("mc3dmaze_narrow_10", 82)
     gen_stats_mc3d_big()
     run_control_episode_3d(11)
+
+
+# ------------------------------------------------------------------ the last oracle-only corners, off 16 x 16
+# (a) representation wrappers on the reference's zelda_small (7 x 11, obs 22 x 22: 198-byte observation rows) and
+#     binary_big (32 x 32, obs 64 x 64) task configs;  (b) solver-firing sokoban levels on other map shapes.
+EXT_SHAPE_CONFIGS = {
+    # name: (problem, representation, map_shape, obs_window, static_prob, n_static_walls, act_window)
+    "zelda_small_narrow_sp20_sw2": ("zelda", "narrow", (7, 11), (22, 22), 0.2, 2, None),
+    "binary_big_narrow_aw3x3": ("binary", "narrow", (32, 32), (64, 64), None, None, [3, 3]),
+    "binary_big_turtle_sp10_sw4": ("binary", "turtle", (32, 32), (64, 64), 0.1, 4, None),
+}
+
+
+def run_ext_shape_episode(name, seed, n_eps=3, n_steps=120):
+    problem, rep, shape, ow, sp, sw, aw = EXT_SHAPE_CONFIGS[name]
+    CONFIGS["_tmp_" + name] = (problem, rep, shape)
+    EXT_CONFIGS[name] = ("_tmp_" + name, sp, sw, aw)
+    make = ref_env.make_cfg
+
+    def make_with_window(problem_, rep_, shape_, **kw):
+        return make(problem_, rep_, shape_, obs_window=ow, **kw)
+
+    ref_env.make_cfg = make_with_window
+    try:
+        run_ext_episode(name, seed, n_eps=n_eps, n_steps=n_steps)
+    finally:
+        ref_env.make_cfg = make
+        del CONFIGS["_tmp_" + name], EXT_CONFIGS[name]
+    # the fixture's obs_window rides along for the replay
+    path = os.path.join(OUT, f"ext_{name}_s{seed}.npz")
+    z = dict(np.load(path))
+    z["obs_window"] = np.array(ow)
+    np.savez_compressed(path, **z)
+
+
+def gen_stats_sokoban_solver_shapes():
+    """solver-firing levels (one player, k crates / targets, one room; BFS wins, A* wins, failures) on 8 x 8, 20 x 20 and
+    30 x 30 maps: SokobanCtrlProblem.get_stats answers of the reference"""
+    rng = np.random.default_rng(33)
+    E, S, P, C, T = range(5)
+    out = {}
+    for shape, n in (((8, 8), 9), ((20, 20), 8), ((30, 30), 7)):
+        core = _problem("sokoban", shape)
+        grids = []
+        while len(grids) < n:
+            g = np.full(shape, S, np.uint8)
+            h, w = int(rng.integers(3, 7)), int(rng.integers(3, 7))
+            y0, x0 = int(rng.integers(0, shape[0] - h + 1)), int(rng.integers(0, shape[1] - w + 1))
+            g[y0:y0 + h, x0:x0 + w] = E
+            for _ in range(int(rng.integers(0, 3))):
+                g[y0 + int(rng.integers(h)), x0 + int(rng.integers(w))] = S
+            free = np.argwhere(g == E)
+            k = int(rng.integers(1, 4))
+            if len(free) < 1 + 2 * k:
+                continue
+            sel = free[rng.permutation(len(free))[: 1 + 2 * k]]
+            for (y, x), t in zip(sel, [P] + [C] * k + [T] * k):
+                g[y, x] = t
+            grids.append(g)
+        grids = np.array(grids, np.uint8)
+        stats = np.array([_get_stats(core, "sokoban", g) for g in grids], np.int32)
+        key = f"{shape[0]}x{shape[1]}"
+        out["grids_" + key], out["stats_" + key] = grids, stats
+        print("stats_sokoban_solver_shapes", key, grids.shape, "one-region", int((stats[:, 3] == 1).sum()), "solved",
+              int((stats[:, 5] > 0).sum()), "failed with dist", int(((stats[:, 4] > 0) & (stats[:, 4] != shape[0] * shape[1] * (shape[0] + shape[1]))).sum()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver_shapes.npz"), stat_keys=np.array(STAT_KEYS["sokoban"]), **out)
+
+
+if __name__ == "__main__" and "corners" in sys.argv[1:]:
+    for i, name in enumerate(EXT_SHAPE_CONFIGS):
+        run_ext_shape_episode(name, 41 + i)
+    gen_stats_sokoban_solver_shapes()

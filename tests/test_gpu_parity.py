@@ -552,6 +552,8 @@ def _ext_kwargs(z):
         kw["n_static_walls"] = int(z["n_static_walls"])
     if int(z["act_window"][0]) > 0:
         kw["act_window"] = [int(a) for a in z["act_window"]]
+    if "obs_window" in z.files:  # (fixtures off the 16 x 16 point carry the task config's window)
+        kw["obs_window"] = tuple(int(a) for a in z["obs_window"])
     return kw
 
 
@@ -1284,6 +1286,17 @@ def test_sokoban_solver_other_map_shapes_vs_oracle(shape):
     got = env.stats_for_grids(torch.as_tensor(g).to(env.device)).cpu().numpy()
     assert np.array_equal(got, want)
     env.check_errors()
+
+
+def test_golden_sokoban_solver_other_shapes_known_answers():
+    """solver-firing levels on 8 x 8, 20 x 20 and 30 x 30 maps: the reference's SokobanCtrlProblem.get_stats answers"""
+    z = np.load(os.path.join(GOLDEN, "stats_sokoban_solver_shapes.npz"))
+    for key in ("8x8", "20x20", "30x30"):
+        grids = z["grids_" + key]
+        env = _vec("sokoban", "narrow", grids.shape[1:], 1, auto_reset=False)
+        got = env.stats_for_grids(torch.as_tensor(grids)).cpu().numpy()
+        assert np.array_equal(got, z["stats_" + key]), f"{key}: got {got.tolist()} want {z['stats_' + key].tolist()}"
+        env.check_errors()
 
 
 def test_loss_integer_and_float64_forms_agree():
