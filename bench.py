@@ -129,8 +129,14 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
-        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU (no
-        # torch import yet), and the ranks are ordinary child processes -- never an exec of a process that holds a GPU.
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU
+        # (counting devices does not initialise them), and the ranks are ordinary child processes -- never an exec of a
+        # process that holds a GPU.
+        if not args.dry_run and not os.environ.get("PCGRL_BENCH_SINGLE_DEVICE"):
+            import torch
+            have = torch.cuda.device_count()
+            if args.gpus > have:
+                sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s): one rank per GPU, nothing was started")
         sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (it launches its own ranks) "
@@ -167,6 +173,8 @@ def main():
     if os.environ.get("PCGRL_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     backend = os.environ.get("PCGRL_BENCH_BACKEND", "nccl")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
@@ -325,7 +333,7 @@ def main():
     ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
     done_ev = torch.cuda.Event()
 
-    def reduce_episodes():
+    def reduce_episodes(after=None):
         """the path's only exchange: one pcgrl_reduce_episodes launch; world == 1: the kernel writes its 3 + n_stats
         doubles straight into pinned host memory (no copy); world > 1: one small all-reduce over RCCL, then one
         device -> host copy.  Ends with the device synchronised."""
@@ -334,6 +342,8 @@ def main():
             if rc:
                 raise RuntimeError(f"pcgrl_reduce_episodes rc={rc}")
             # (waiting on an event returns ~15 us sooner than the device-wide wait; the synchronise then finds an idle device)
+            if after is not None:
+                after.record(stream)
             done_ev.record(stream)
             done_ev.synchronize()
             torch.cuda.synchronize(dev)
@@ -344,8 +354,13 @@ def main():
             t = ep_dev.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             ep_host.copy_(t)
+            if after is not None:
+                after.record(stream)
+                torch.cuda.synchronize(dev)
             return
         dist.all_reduce(ep_dev, op=dist.ReduceOp.SUM)
+        if after is not None:
+            after.record(stream)
         ep_host.copy_(ep_dev, non_blocking=True)
         torch.cuda.synchronize(dev)
 
@@ -392,15 +407,20 @@ def main():
     ev0.record(stream)
     run(K)
     ev1.record(stream)
+    ev2 = torch.cuda.Event(enable_timing=True)
     # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-reduce of the episode sums
     # cannot complete on any rank before every rank has contributed, i.e. finished its K launches; one collective instead
     # of an all-reduce followed by a barrier.  Ends with the device synchronised.
-    reduce_episodes()
+    reduce_episodes(ev2)
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
+    # the exchange on this rank's stream: reduction launch + (N > 1) the all-reduce, which also waits for the slowest rank
+    exchange_ms = ev1.elapsed_time(ev2) if ev2.query() else float("nan")
     env.check_errors()
     elapsed, per_rank_elapsed = max_over_ranks(elapsed)
     _, per_rank_eps = max_over_ranks(float(local_eps.item()))
+    _, per_rank_kernel_ms = max_over_ranks(kernel_ms)
+    _, per_rank_exchange_ms = max_over_ranks(exchange_ms)
     h = ep_host.tolist()
     n_ep = max(h[2], 1.0)
     ep = {"episodes": h[2], "mean_return": h[0] / n_ep, "mean_length": h[1] / n_ep,
@@ -424,6 +444,9 @@ def main():
                                       "placements, no auto-reset, " if bfs_active else "uniform random actions, auto-reset, ")
                                    + "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
+                       # (SURVEY 8(d) says torch.randint per step; the action source is not the hot path, so the rows are drawn
+                       # once, on the device, before the timed region, and step k reads row k mod POOL)
+                       "actions": f"pool of {POOL} pre-drawn rows of uniform random actions resident in HBM, row k mod {POOL} at step k",
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)",
                        "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
                        "seed_ranges": [[0x5EED + lo, 0x5EED + hi - 1] for lo, hi in
@@ -439,8 +462,12 @@ def main():
                          "fill_same_bytes": (dict(fill, step_over_fill=(elapsed / K * 1e6) / fill["us"]) if fill else None)},
             "episodes": ep,
         }
-        if world > 1:
-            out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "episodes": per_rank_eps}
+        # per rank: its own clock of the timed region, the HIP-event time of its K launches alone, and the closing exchange
+        # (reduction launch + all-reduce, which waits for the slowest rank): weak-scaling efficiency can be read off this
+        # one line as  min(launch_ms_per_step at N = 1) / max(launch_ms_per_step)  and the exchange's share
+        out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "ms_per_step": [t / K * 1e3 for t in per_rank_elapsed],
+                           "launch_ms_per_step": per_rank_kernel_ms, "exchange_ms": per_rank_exchange_ms,
+                           "episodes": per_rank_eps, "collective": "none" if world == 1 else f"{backend} all-reduce of {3 + env.n_stats} doubles"}
         if solver_active:
             st = env.get_state().stats
             out["solver_active"] = {"reinject_every": REINJECT, "solver_power": int(env.cfg.solver_power),
@@ -453,7 +480,7 @@ def main():
                                  "envs_with_one_player_at_end": (st[:, 0] == 1).float().mean().item()}
         if rollout is not None:
             out["open_loop_rollout"] = rollout
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # rank 0 only, also with N > 1 ranks (the others wait at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -473,10 +500,30 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
+    # rank 0's output is read on a thread so that this loop can watch every rank: one that dies before the rendezvous
+    # would otherwise leave the others (and this launcher) waiting for it for ever
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("PCGRL_BENCH_TIMEOUT", "3600"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = f"rank {bad[0]} exited with code {procs[bad[0]].returncode}" if bad else "timeout"
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
+    if failed:
+        sys.stderr.write(f"bench.py launcher: {failed}; the remaining ranks were stopped\n")
+        return 1
     return max(abs(rc) for rc in rcs)
 
 
