@@ -350,12 +350,17 @@ __device__ __attribute__((always_inline)) inline SkKey sk_key(const SokoCtx &c, 
 
 // returns true if the state (key; crates cr) was already in the visited set; inserts node n otherwise.  A probe reads one
 // group of 8 entries with one load; a full group overflows into the next.
+// `pre` / `have_pre`: the first group of the probe, already requested by the caller (the A* stage asks for it before its
+// heap pop, so the memory round trip runs under the pop instead of after it).
 template <bool BIG>
-__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, const SkKey &key, const SkCrates<BIG> &cr) {
+__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, const SkKey &key, const SkCrates<BIG> &cr,
+                                                                               sk_u32x4 pre = sk_u32x4{0u, 0u, 0u, 0u}, bool have_pre = false) {
   int grp = key.group();
   while (true) {
     sk_u32x4 e = {0u, 0u, 0u, 0u};
-    if (c.lane < 8) e = c.vis[grp * 8 + c.lane];
+    if (have_pre) e = pre;
+    else if (c.lane < 8) e = c.vis[grp * 8 + c.lane];
+    have_pre = false;
     const bool valid = c.lane < 8 && (e.x >> 17) == c.epoch && (e.x & 0x1FFFFu) != 0;
     const uint32_t empties = (uint32_t)__ballot(c.lane < 8 && !valid);
     const uint32_t matches = (uint32_t)__ballot(valid && e.y == key.k0 && e.z == key.k1 && e.w == key.k2);
@@ -557,12 +562,23 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
     int cur;
     bool had_pre = pre_valid;
     uint32_t new_top = 0;
+    SkKey pkey;
+    sk_u32x4 pgrp = {0u, 0u, 0u, 0u};
+    bool have_pgrp = false;
+    pkey.k0 = pkey.k1 = pkey.k2 = 0u;
+    pkey.exact = true;
     if (b2 < 0) {
       cur = had_pre ? pre_cur : bfs_entry(head);  // queue.pop(0)
       head++;
     } else {  // heapq.heappop
+      if (had_pre) {  // the next node is (almost always) the root the previous pop left behind: its visited-set line is
+        pkey = sk_key(c, sk_u(pre_nd.px), sk_u(pre_nd.py), pre_cr);  // requested now and arrives while the heap is sifted
+        if (c.lane < 8) pgrp = c.vis[pkey.group() * 8 + c.lane];
+        have_pgrp = true;
+      }
       cur = (int)(sk_heappop(c, tail, &new_top) & 0xFFFFu);
       had_pre = had_pre && cur == pre_cur;  // (the record requested ahead of time: the root the previous pop left behind)
+      have_pgrp = have_pgrp && had_pre;
     }
     SK_T_MARK(0);  // pop
     SokoNode nd;
@@ -592,8 +608,8 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
       return true;
     }
     SK_T_MARK(1);  // record loads + win test
-    const SkKey key = sk_key(c, px, py, cr);
-    const bool seen = sk_visited_test_and_set(c, cur, key, cr);
+    const SkKey key = have_pgrp ? pkey : sk_key(c, px, py, cr);
+    const bool seen = sk_visited_test_and_set(c, cur, key, cr, pgrp, have_pgrp);
     SK_T_MARK(2);  // visited set
     if (!seen) {
       if (best < 0 || nd.h < best_h || (nd.h == best_h && nd.depth < best_depth)) {  // engine.py:66-69
