@@ -1,7 +1,7 @@
 #!/bin/bash
 # every bench line behind profiles/<tag>_bench_lines.json (collected by tools/finish_round.py).  On the GPU box, from the
 # repo root:  bash tools/bench_all.sh r2
-T=${1:-r2}
+T=${1:-r3}
 O=gpurun_out
 python bench.py > $O/bench_${T}_binary-narrow.log 2>&1
 for W in zelda-turtle sokoban-wide minecraft_3D_maze-narrow zelda-turtle-bfs binary-narrow-static binary-narrow-patch3x3; do

@@ -71,7 +71,7 @@ NOTES = {
     "zelda-turtle": "store-bound: 37.7 MB of observations per launch",
     "zelda-turtle-bfs": "SURVEY §8 d \"BFS-active\": maps with exactly one player / key / door re-injected every 128 steps, actions = moves and empty / solid / enemy placements (both single-source searches run); incl. the injection launches",
     "sokoban-wide": "compile-time 16×16 wide kernel; rare solver calls after resets (dense random levels) are in the mean",
-    "minecraft_3D_maze-narrow": "the launch waits for the env with the most open map (§4.2)",
+    "minecraft_3D_maze-narrow": "the launch waits for the env whose pair of searches has the largest hop depth (§4.2); round 2: 34.6 µs",
     "binary-narrow-static": "static tiles (p ≤ 0.3, 3 walls), general kernel",
     "binary-narrow-patch3x3": "3×3 action patch, general kernel",
     "sokoban-wide-solver": "solver-active, see below",

@@ -2,7 +2,7 @@
 # rocprofv3 passes behind profiles/<tag>_*: for every BASELINE workload a kernel trace (+stats) and three separate PMC
 # passes (never combined with a trace domain).  Run on the GPU box from the repo root:  bash tools/profile_all.sh r02
 # Raw output goes to gpurun_out/prof_* and is condensed by tools/summarize_profiles.py into gpurun_out/summary/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 WORKLOADS=${2:-"binary-narrow zelda-turtle sokoban-wide minecraft_3D_maze-narrow"}
 R=$(pwd)
 export TMPDIR=/tmp

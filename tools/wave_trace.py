@@ -23,14 +23,19 @@ _lib.LIB_PATH = TRACE_LIB
 from control_pcgrl_amd import VecPcgrlEnv
 
 three_d = "--3d" in sys.argv
-n = 1024 if three_d else 4096
-if three_d:
+soko, zelda = "--sokoban" in sys.argv, "--zelda" in sys.argv
+n = 1024 if three_d else (2048 if soko else 4096)
+if soko:
+    env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+elif zelda:
+    env = VecPcgrlEnv("zelda", "turtle", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+elif three_d:
     env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
 else:
     env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset="--no-reset" not in sys.argv)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
-pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
+pool = torch.randint(0, env.num_actions, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
 for k in range(500):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
