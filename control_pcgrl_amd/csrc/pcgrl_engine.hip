@@ -175,12 +175,12 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
     return fail(PCGRL_EINVAL, "static_prob / n_static_walls need static_tiles = 1");
   }
   if (H < 1 || W < 1 || H > 64 || W > 64) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 64");
-  if (W > 32 && H <= 16) return fail(PCGRL_EUNSUPPORTED, "maps wider than 32 need more than 16 rows (64-bit row-mask kernels)");
   if (W > 32 && c.problem == PCGRL_PROB_SOKOBAN) return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32");
   if (c.problem == PCGRL_PROB_SOKOBAN && (c.solver_power < 1 || c.solver_power > SK_MAX_POWER))
     return fail(PCGRL_EUNSUPPORTED, "sokoban: solver_power must be in [1, " + std::to_string(SK_MAX_POWER) +
                                         "] (the device solver's visited table and node ids are sized for that)");
   lpe = H <= 8 ? 8 : (H <= 16 ? 16 : (H <= 32 ? 32 : 64));
+  if (W > 32 && lpe < 32) lpe = 32;  // the 64-bit row-mask kernels are built for 32 and 64 lanes per env: short maps leave rows idle
   if (c.representation == PCGRL_REP_WIDE) {
     if (c.obs_window[0] != H || c.obs_window[1] != W)
       return fail(PCGRL_EINVAL, "wide representation needs obs_window == map_shape (reference wrappers.py:140-150 reshape)");

@@ -274,6 +274,17 @@ def test_mc3dmaze_stock_size_batch_vs_oracle():
     _rollout_vs_oracle("minecraft_3D_maze", "narrow", (16, 16, 16), 9, 150, full_every=37, change_percentage=0.01)
 
 
+def test_mc3dmaze_odd_observation_windows_vs_oracle():
+    """observation windows that are not twice the map: small ones, ones with more rows than the row-table encoder's
+    scratch holds (cell-by-cell path), ones wider than 32 cells"""
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (6, 6, 6), 21, 90, full_every=7, obs_window=(20, 18, 6))
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (5, 5, 5), 9, 60, full_every=5, obs_window=(4, 6, 40))
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (7, 7, 7), 30, 80, full_every=9, obs_window=(6, 10, 14))
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (12, 12, 12), 6, 60, full_every=11, obs_window=(36, 34, 8), change_percentage=0.02)
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (3, 3, 3), 40, 70, full_every=3)
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (2, 4, 4), 12, 50, full_every=3)
+
+
 def test_binary_narrow_4096_envs_vs_oracle():
     """BASELINE configs[1]: binary-narrow 16x16, 4096 envs on one MI355X, bit-exact state check vs CPU,
     across an auto-reset boundary (episode = 770 steps)."""
@@ -311,13 +322,13 @@ def test_other_map_shapes_vs_oracle(shape):
                                       ((64, 1), (16, 16)), ((4, 64), (8, 64))])
 def test_degenerate_map_shapes_vs_oracle(shape, ow):
     """single-row / single-column / single-cell maps: empty frontiers, one-lane groups, W = 1 and W = 64 masks"""
-    if shape[1] > 32 and shape[0] <= 16:
-        with pytest.raises(NotImplementedError):
-            _vec("binary", "narrow", shape, 4, obs_window=ow)
-        return
     _rollout_vs_oracle("binary", "narrow", shape, 19, 3 * shape[0] * shape[1] + 30, full_every=3, obs_window=ow)
     if shape[0] * shape[1] >= 9:  # smaller maps have empty zelda target ranges (the reference fails on them too)
         _rollout_vs_oracle("zelda", "turtle", shape, 19, 60, full_every=3, obs_window=ow)
+    if shape[1] > 32:  # the device solver's level rows are 32 bits wide
+        with pytest.raises(NotImplementedError):
+            _vec("sokoban", "narrow", shape, 4, obs_window=ow)
+        return
     _rollout_vs_oracle("sokoban", "narrow", shape, 19, 60, full_every=3, obs_window=ow)
 
 
@@ -495,7 +506,7 @@ def test_gym_adapter_controllable_planes():
         assert np.allclose(obs[0, 0, :4], z["ctrl"][t], rtol=1e-6)
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (32, 64), (48, 40), (20, 33)])
+@pytest.mark.parametrize("shape", [(64, 64), (32, 64), (48, 40), (20, 33), (12, 40), (16, 64), (5, 33)])
 def test_maps_wider_than_32_vs_oracle(shape):
     """64-bit row masks (reference task configs binary_bigger / zelda_bigger are 64x64 with a 128x128 window);
     change_percentage keeps episodes short so the RNG reset path is crossed several times."""
