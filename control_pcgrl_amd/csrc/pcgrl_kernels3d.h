@@ -817,8 +817,13 @@ template <int SC>
 __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch, uint32_t &trip,
                                     bool &overflow, M3Work<SC> *W2, M3Mail *mail PHASE_ARG) {
   // the farthest cell of this plane's first search the last time it ran (+1; 0: none)
-  int guess = mail != nullptr ? (int)__builtin_amdgcn_readfirstlane((int)c.hdr(s)->far1) - 1 : -1;
+  const uint32_t far_word = mail != nullptr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)c.hdr(s)->far1) : 0u;
+  int guess = (int)(far_word & 0xFFFFu) - 1;
   if (guess >= c.n_cells) guess = -1;
+#if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_SPEC)
+  const int guess2 = (int)(far_word >> 16) - 1;  // (development: the far end of the last second search)
+  const int old_start = (int)__builtin_amdgcn_readfirstlane((int)c.hdr(s)->start);
+#endif
   int seq = 0;
   if (guess >= 0) {
     if (c.lane == 0) {
@@ -854,6 +859,8 @@ __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int st
 #if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_SPEC)
     _ph[1] += 1;
     _ph[2] += have2 ? 1 : 0;
+    _ph[3] += (!overflow && far1 == guess2) ? 1 : 0;
+    _ph[4] += (old_start != start_bit) ? 1 : 0;
 #endif
   }
 #if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_SPEC)
@@ -875,7 +882,7 @@ __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int st
     h.max_dist = (uint16_t)max_dist;
     h.n_jump = (uint16_t)n_jump;
     h.mk = mk & ((1u << c.Z) - 1u);
-    h.far1 = (uint32_t)(far1 + 1);
+    h.far1 = (uint32_t)(far1 + 1) | ((uint32_t)(far2 + 1) << 16);
     *c.hdr(s) = h;
   }
 }

@@ -30,7 +30,7 @@ soko = "--sokoban" in sys.argv  # sokoban-wide 16x16, 2048 envs (BASELINE C4)
 n, iters = (1024, 1000) if three_d else ((2048, 2000) if soko else (4096, 2000))
 if three_d:
     if "--m3-spec" in sys.argv:
-        NAMES = ["(count) search pairs", "(count) with a remembered farthest cell", "(count) helper result used", "-", "-", "-", "-"]
+        NAMES = ["(count) search pairs", "(count) with a remembered farthest cell", "(count) helper result used", "(count) farthest cell = the last far END", "(count) start cell changed", "-", "-"]
     elif "--m3-trips" in sys.argv:
         NAMES = ["(count) chain trips", "(count) general trips", "chain-trip cycles", "general-trip cycles", "overlay", "outputs + write-back", "fresh tables"]
     elif "--m3-phases" in sys.argv:
