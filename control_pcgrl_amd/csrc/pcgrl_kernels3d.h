@@ -615,49 +615,52 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
     // ---- general trip: up to 16 entries
     M3_TRIP_KIND(1);
     tr++;
-    const int nb = min(16, tail - head);
-    if (tail - head > RING - 64) {  // (a trip pushes at most 64 entries)
+    const int n_q = tail - head;
+    if (n_q > RING - 64) {  // (a trip pushes at most 64 entries)
       overflow = true;
       break;
     }
-    const bool live = slot_i < nb;
-    const int id = head + (live ? slot_i : 0);
+    // The trip's predicates are lane MASKS in scalar registers (one v_cmp each, combined with scalar ANDs, turned back
+    // into predication with inverse_ballot): a ballot of a combined boolean costs a v_cndmask + v_cmp pair instead.
+    const int nb = min(16, n_q);
+    constexpr uint64_t D0 = 0x1111111111111111ull;  // the direction-0 lane of every entry
+    const uint64_t live_m = M3_BALLOT(slot_i < nb);
+    const int id = head + min(slot_i, nb - 1);  // (lanes beyond the live entries re-read the last one: harmless)
     const uint2 e = W.ent[id & RM];
     const int cell = (int)(e.x & 0xFFFu), parent = (int)((e.x >> 12) & 0x1FFFu);
     const uint32_t len = e.y;
     const uint32_t stamp = ((0x0FFFFFFFu - tr) << 4) | (uint32_t)slot_i;
-    if (live && d == 0) atomicMin(&W.best[cell].y, stamp);
+    if (__builtin_amdgcn_inverse_ballot_w64(live_m & D0)) atomicMin(&W.best[cell].y, stamp);
     const uint2 b = W.best[cell];
     const int m = mv[cell * 4 + d];
-    const bool seen = (b.x >> 24) == ep;
-    // :437-440 (an entry that is not shorter is dropped)
-    const bool accept = live & !(seen & ((b.x & 0xFFFFFFu) <= len));
+    // :437-440 (an entry that is not shorter is dropped): best ^ epoch is the accepted length if the cell was seen in this
+    // search and at least 2^24 otherwise
+    const uint32_t keyv = b.x ^ ep24;
+    const uint64_t accept_m = M3_BALLOT(keyv > len) & live_m;
     // cut the trip before an accept candidate that is not the first popped entry of its cell in this trip
-    const uint64_t dupb = M3_BALLOT(accept & (d == 0) & (b.y != stamp));
-    const int nproc = dupb ? (__builtin_ctzll(dupb) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
-    const bool doit = accept & (slot_i < nproc);
-    const bool acc0 = doit & (d == 0);
-    const bool first = acc0 & !seen;
-    const uint64_t fb = M3_BALLOT(first);
-    if (first) W.order[n_order + m3_below(fb)] = (uint16_t)cell;
-    n_order += __popcll(fb);
-    if (acc0) {
+    const uint64_t dup_m = M3_BALLOT(b.y != stamp) & accept_m & D0;
+    const int nproc = dup_m ? (__builtin_ctzll(dup_m) >> 2) : nb;  // >= 1: slot 0 is always the first of its cell
+    const uint64_t doit_m = accept_m & M3_BALLOT(slot_i < nproc);
+    const uint64_t acc0_m = doit_m & D0;
+    const uint64_t first_m = acc0_m & M3_BALLOT(keyv >= (1u << 24));
+    if (__builtin_amdgcn_inverse_ballot_w64(first_m)) W.order[n_order + m3_below(first_m)] = (uint16_t)cell;
+    n_order += __popcll(first_m);
+    if (__builtin_amdgcn_inverse_ballot_w64(acc0_m)) {
       W.best[cell].x = ep24 | len;
       W.info[cell] = e.x >> 12;
     }
     // successor in direction d: one entry of the move table
     const int tcell = cell + (m >> 5);
     const uint32_t tlen = len + ((uint32_t)m & 3u);
-    bool ok = doit & (m != 0) & (tcell != parent);
-    if (tail - head > 32) {  // never queue what is known to be a no-op when popped
-      const uint32_t bt = W.best[ok ? tcell : 0].x;
-      ok &= !(((bt >> 24) == ep) & ((bt & 0xFFFFFFu) <= tlen));
+    uint64_t ok_m = doit_m & M3_BALLOT(m != 0) & M3_BALLOT(tcell != parent);
+    if (n_q > 32) {  // never queue what is known to be a no-op when popped
+      const uint32_t bt = W.best[tcell].x ^ ep24;  // (tcell is a cell of the map also where there is no move: delta 0)
+      ok_m &= M3_BALLOT(bt > tlen);
     }
-    const uint64_t okb = M3_BALLOT(ok);
-    if (ok)
-      W.ent[(tail + m3_below(okb)) & RM] =
+    if (__builtin_amdgcn_inverse_ballot_w64(ok_m))
+      W.ent[(tail + m3_below(ok_m)) & RM] =
           make_uint2((uint32_t)tcell | ((uint32_t)cell << 12) | (((uint32_t)m & 31u) << 25) | ((uint32_t)d << 30), tlen);
-    const int npush = __popcll(okb);
+    const int npush = __popcll(ok_m);
     tail += npush;
     head += nproc;
 #ifdef PCGRL_PHASE_TIMING
