@@ -768,6 +768,9 @@ struct M3Mail {
   int32_t exit;    // the simulate wave is done with the launch
   int32_t root, slot;
   int32_t ok, far2, max_dist, n_jump;  // results
+  // the region count, also on the helper wave (it does not depend on the searches): job number / completion, the edited
+  // cell (plane bit, plane), kind (0 new AIR cell, 1 removed, 2 count from scratch), count before the edit -> count
+  int32_t rseq, rdone, r_eq, r_ez, r_kind, r_old, r_out;
 };
 __device__ inline int m3_ld(const int32_t *x) { return __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void m3_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -788,16 +791,45 @@ __device__ inline bool m3_second_search(M3Work<SC> &W, const M3Ctx &c, int s, in
 // body of the helper wave: serve the simulate wave's jobs until it leaves
 template <int SC>
 __device__ inline void m3_helper(M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
+  constexpr int PW = M3C<SC>::PW;
   uint32_t epoch = 0, trip = 0;
   for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
-  int seen = 0;
+  PM<PW> notx0, notxl;
+  m3_edge_masks<PW>(c, notx0, notxl);
+  int seen = 0, rseen = 0;
   while (true) {
-    int sq;
-    while ((sq = __builtin_amdgcn_readfirstlane(m3_ld(&m.seq))) == seen) {
+    int sq, rq;
+    while (true) {
+      rq = __builtin_amdgcn_readfirstlane(m3_ld(&m.rseq));
+      sq = __builtin_amdgcn_readfirstlane(m3_ld(&m.seq));
+      if (rq != rseen || sq != seen) break;
       if (__builtin_amdgcn_readfirstlane(m3_ld(&m.exit)) != 0) return;
       __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (rq != rseen) {  // the region count of the edited map (the tile bits in LDS are already those of the new map)
+      rseen = rq;
+      const int eq = __builtin_amdgcn_readfirstlane(m3_ld(&m.r_eq)), ez = __builtin_amdgcn_readfirstlane(m3_ld(&m.r_ez));
+      const int kind = __builtin_amdgcn_readfirstlane(m3_ld(&m.r_kind)), old = __builtin_amdgcn_readfirstlane(m3_ld(&m.r_old));
+      PM<PW> air = c.lane < c.Z ? m3_plane_air<PW>(c.dirt, c, c.lane) : pm_zero<PW>();
+      int out;
+      if (kind == 2) {
+        out = m3_regions<PW>(c, air, notx0, notxl);
+      } else {
+        if (c.lane == ez) {
+          PM<PW> e = pm_zero<PW>();
+          pm_set(e, eq);
+          air = air & ~e;
+        }
+        out = m3_regions_update<PW>(c, air, notx0, notxl, eq, ez, kind == 0, old);
+      }
+      if (c.lane == 0) {
+        m.r_out = out;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        m3_st(&m.rdone, rq);
+      }
+      continue;
+    }
     seen = sq;
     const int root = __builtin_amdgcn_readfirstlane(m3_ld(&m.root)), s = __builtin_amdgcn_readfirstlane(m3_ld(&m.slot));
     for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
@@ -1104,6 +1136,7 @@ template <int MODE, int SC, bool D7 = false>
 __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void m3_kernel(Params p, int cpl) {
   constexpr int PW = M3C<SC>::PW;
   constexpr bool HELP = MODE == M3_STEP && SC == 0;
+  if (MODE == M3_STEP) touch_kernarg(p);  // every line of the argument block in one scalar-memory round trip
   __shared__ M3Env<SC> E;
   __shared__ M3Work<SC> W;
   __shared__ M3Mail mail;
@@ -1139,6 +1172,8 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
     if (threadIdx.x == 0) {
       mail.seq = 0;
       mail.done = 0;
+      mail.rseq = 0;
+      mail.rdone = 0;
       mail.cancel = 0;
       mail.exit = 0;
     }
@@ -1410,7 +1445,19 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
       if (change) {
         const PM<PW> air = plane_of(c.dirt);
         const int32_t st_old[NS] = {st[0], st[1], st[2]};
-        if (flags & ENV_STATS_DIRTY) {  // after pcgrl_update: from scratch, like the reference's get_stats
+        int rjob = 0;
+        if constexpr (HELP) {  // the helper wave counts the regions while this wave searches
+          if (c.lane == 0) {
+            rjob = m3_ld(&mail.rseq) + 1;
+            mail.r_eq = ey * c.X + ex;
+            mail.r_ez = ez;
+            mail.r_kind = (flags & ENV_STATS_DIRTY) ? 2 : (action == 0 ? 0 : 1);
+            mail.r_old = st[0];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            m3_st(&mail.rseq, rjob);
+          }
+          rjob = __builtin_amdgcn_readfirstlane(rjob);
+        } else if (flags & ENV_STATS_DIRTY) {  // after pcgrl_update: from scratch, like the reference's get_stats
           st[0] = m3_regions<PW>(c, air, notx0, notxl);
         } else {
           PM<PW> A = air;  // the planes without the edited cell
@@ -1425,6 +1472,11 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
         M3_MARK(2, 4);  // regions
         m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP ? &mail : nullptr PHASE_PASS);
         over_dirty = true;
+        if constexpr (HELP) {
+          while (__builtin_amdgcn_readfirstlane(m3_ld(&mail.rdone)) != rjob) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          st[0] = __builtin_amdgcn_readfirstlane(m3_ld(&mail.r_out));
+        }
         if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
           for (int i = 0; i < NS; i++) st[i] = st_old[i];
       }
