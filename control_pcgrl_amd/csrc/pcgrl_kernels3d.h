@@ -5,11 +5,15 @@
 // run_dijkstra :422-490, calc_longest_path :503-563, remove_stacked_path_tiles :657-675; envs/pcgrl_env.py:267-342.
 // Map sizes: configs/config.py:153-157 (the stock 15 x 15 x 15) and BASELINE's 7 x 7 x 7.
 //
-// One workgroup per env.  pcgrl_step runs TWO specialised wavefronts over the env (like the 2-D step kernel):
-//   wave 0 "simulate"  action -> statistics (regions, path searches) -> reward / done -> auto-reset -> state write-back
+// One workgroup per env.  pcgrl_step runs specialised wavefronts over the env (like the 2-D step kernel):
+//   wave 0 "simulate"  action -> move-table update -> path searches -> reward / done -> auto-reset -> state write-back
 //   wave 1 "observe"   replays the (trivial) action / reset on its own copy and streams the observation, which shows the
 //                      path overlay of the PREVIOUS statistics update (pcgrl_env.py:298-299 vs :314-323), so it does
 //                      not depend on this step's searches.
+//   wave 2 "helper"    (planes of <= 64 cells) counts the regions and runs the second search of a pair speculatively while
+//                      wave 0 runs the first (see SPECULATION); jobs through an LDS mailbox.
+// The only barrier of the step sits at the END of the waves (the simulate wave overwrites the state only after the observe
+// wave has read it), so no wave's work waits for another's loads.
 // Lane roles inside the simulate wave:
 //   lanes 0..Z-1   one z-plane each as a (Y*X)-bit mask (1 or 4 64-bit words: size class SC): 6-neighbour flood fill =
 //                  shifts by 1 / X inside the lane and a DPP row_shr/row_shl between planes; start candidates
@@ -18,8 +22,8 @@
 //
 // MOVE TABLE.  helper_3D._passable (:214-319) is a pure function of the map around a foothold: for every (cell, direction)
 // at most one of its six rules applies.  The engine keeps that function as a table in HBM (16 bits per cell and
-// direction: path cost, jump flag, height change, target cell - cell; 0 = no move) and MAINTAINS it: an edit of one cell can change the moves
-// of at most 48 (cell, direction) pairs -- the cells whose rules read the edited cell -- which 48 lanes re-evaluate at
+// direction: path cost, jump flag, height change, target cell - cell; 0 = no move) and MAINTAINS it: an edit of one
+// cell can change the moves of at most 48 (cell, direction) pairs -- the cells whose rules read the edited cell -- which 48 lanes re-evaluate at
 // once.  The path search then reads one entry per popped queue entry and direction instead of evaluating the rules.
 //
 // PATH SEARCH.  helper_3D.run_dijkstra is a FIFO label-correcting search whose pop order decides n_jump, the farthest
@@ -29,8 +33,8 @@
 // marking (:531) leaves at most ONE processed candidate per z-plane: the first candidate of the plane in (y, x) order.
 // Everything a plane's pair of searches produces -- the marks, max_dist, n_jump, the path tiles -- is a function of the
 // start cell and of the move-table rows of the cells the searches ACCEPTED (nothing else of the map is read).  The engine
-// keeps, per env and plane, that result together with the set of accepted cells in HBM.  A step edits one cell: a slot is
-// dropped iff a move-table byte of one of its accepted cells actually changed; every other slot is still exact, and the
+// keeps, per env and plane, that result together with the set of accepted cells in the env's record in HBM.  A step edits one cell: a slot is
+// dropped iff a move-table entry of one of its accepted cells actually changed; every other slot is still exact, and the
 // sequential candidate walk re-runs only the searches it needs.
 #pragma once
 #include <hip/hip_runtime.h>
