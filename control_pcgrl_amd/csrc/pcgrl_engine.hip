@@ -488,7 +488,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   p.n_act = (!is3d && cfg->act_window[0] > 0) ? cfg->act_window[0] * cfg->act_window[1] : 1;
   // one padded observation row per lane + the OOB row (+ 2 rows per env of the wave with the static_builds plane)
   // (+ 64 bytes per env of the wave: the observe wave's copy of the RNG streams, see step_kernel)
-  e->lds_bytes = (size_t)(obs_chunks * 16 + 16) * (65 + (cfg->static_tiles ? 16 : 0)) + 64 * 8;
+  e->lds_bytes = (size_t)(obs_chunks * 16 + 32) * (65 + (cfg->static_tiles ? 16 : 0)) + 64 * 8;  // (+32: lds_row_stride may add a chunk)
   p.lds_pair_bytes = (int32_t)e->lds_bytes;
   e->cpl = is3d ? (p.n_cells + 63) / 64 : 0;
   const int H = cfg->dims[0], W = cfg->dims[1];

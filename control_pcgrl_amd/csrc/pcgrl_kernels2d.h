@@ -1032,7 +1032,12 @@ __device__ inline void reset_from_rng(const Grp<LPE> &g, const Params &p, int en
 // One lane assembles one observation row (OW*C bytes) in its own LDS row (row stride = bytes + 16, which keeps
 // 16-byte alignment and makes the 16-byte fills / read-backs bank-conflict free), scatters the one-hot bytes of
 // its map row into it, and streams it out with 16-byte stores.
-__device__ inline int lds_row_stride(int row_bytes) { return ((row_bytes + 15) & ~15) + 16; }
+// (an ODD number of 16-byte chunks: with an even one -- sokoban-wide's 80-byte rows padded to 96 -- lanes r and r + 8
+// of a group start in the same LDS bank)
+__device__ inline int lds_row_stride(int row_bytes) {
+  const int s = ((row_bytes + 15) & ~15) + 16;
+  return (s & 16) ? s : s + 16;
+}
 
 // 16-byte observation store, write-through (sc1): the line leaves the XCD's L2 while the kernel is still running
 // instead of being written back at the kernel boundary (MI355X_MICROARCH.md "boundary" / "publish-large" rows: a
