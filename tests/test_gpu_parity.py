@@ -285,6 +285,30 @@ def test_mc3dmaze_odd_observation_windows_vs_oracle():
     _rollout_vs_oracle("minecraft_3D_maze", "narrow", (2, 4, 4), 12, 50, full_every=3)
 
 
+@pytest.mark.parametrize("shape,n,T,kw", [((7, 7, 7), 1024, 1300, {}), ((15, 15, 15), 64, 500, dict(change_percentage=0.05)),
+                                          ((8, 8, 8), 256, 700, {})])
+def test_mc3dmaze_biased_actions_vs_oracle(shape, n, T, kw):
+    """slowly drifting action bias (long runs of AIR, then of DIRT): big open components, long corridors, deep searches --
+    the maps on which the path search's chain trips, 16-entry trips, ring and speculation all get exercised"""
+    seeds = 5000 + np.arange(n)
+    env = _vec("minecraft_3D_maze", "narrow", shape, n, seeds=seeds, auto_reset=True, **kw)
+    orc = po.OracleVecEnv("minecraft_3D_maze", "narrow", shape, n, seeds=seeds, threads=8, **kw)
+    obs, _ = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.reset())
+    g = torch.Generator().manual_seed(11)
+    for t in range(T):
+        a = (torch.rand(n, generator=g) < 0.5 + 0.45 * np.sin(t / 97.0)).to(torch.int32)
+        obs, rew, done, _, info = env.step(a.to(env.device))
+        want = t % 211 == 0 or t == T - 1
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want)
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL and np.array_equal(done.cpu().numpy(), odone)
+        if want:
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    env.check_errors()
+
+
 def test_binary_narrow_4096_envs_vs_oracle():
     """BASELINE configs[1]: binary-narrow 16x16, 4096 envs on one MI355X, bit-exact state check vs CPU,
     across an auto-reset boundary (episode = 770 steps)."""
