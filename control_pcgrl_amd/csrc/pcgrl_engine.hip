@@ -175,7 +175,8 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
     return fail(PCGRL_EINVAL, "static_prob / n_static_walls need static_tiles = 1");
   }
   if (H < 1 || W < 1 || H > 64 || W > 64) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 64");
-  if (W > 32 && c.problem == PCGRL_PROB_SOKOBAN) return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32");
+  if (c.problem == PCGRL_PROB_SOKOBAN && (W > 32 || H + 2 > SK_MAXDIM))
+    return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32, H <= 62");
   if (c.problem == PCGRL_PROB_SOKOBAN && (c.solver_power < 1 || c.solver_power > SK_MAX_POWER))
     return fail(PCGRL_EUNSUPPORTED, "sokoban: solver_power must be in [1, " + std::to_string(SK_MAX_POWER) +
                                         "] (the device solver's visited table and node ids are sized for that)");

@@ -1043,7 +1043,7 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
   if (obs_base == nullptr) obs_base = p.obs;
   const int o0 = W14 ? 14 : p.cfg.obs_window[0], o1 = W14 ? 14 : p.cfg.obs_window[1], o2 = W14 ? 14 : p.cfg.obs_window[2];
   const int rows = o0 * o1;
-  if (!W14 && (rows + 1 > scratch_rows || o2 > 32)) {
+  if (!W14 && (rows + 1 > scratch_rows || o2 > 32 || o2 < 2)) {  // (o2 == 1: a chunk of 4 cells spans 4 rows, pass 2 reads 2)
     m3_encode_obs_cells(dirt, over, c, p, env, pos, show_path, obs_base);
     return;
   }

@@ -64,7 +64,7 @@ namespace pcgrl {
 #endif
 
 constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
-constexpr int SK_MAXDIM = 34;    // bordered level side (W+2, H+2 <= 34)
+constexpr int SK_MAXDIM = 64;    // bordered level height H+2 (one lane per row, one mask bit per row); W+2 <= 34: 32-bit map rows
 constexpr int SK_VCAP = 1 << 15; // visited table entries (>= 2 x iterations per stage), 16 bytes each, in groups of 8
 constexpr int SK_VGROUPS = SK_VCAP / 8;  // a group = one 128-byte line: a probe reads it with one load (lane l < 8: entry l)
 constexpr size_t SK_VIS_BYTES = 16 * (size_t)SK_VCAP;

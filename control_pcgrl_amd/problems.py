@@ -108,6 +108,9 @@ def target_interval(trg: Target):
     bound is excluded and the grid is integer -- so the zero-loss interval is [lo, last element]."""
     if isinstance(trg, tuple):
         lo, hi = trg
-        n = max(int(math.ceil(hi - lo)), 1)
+        n = int(math.ceil(hi - lo))
+        if n < 1:  # e.g. zelda's nearest-enemy range (5, ceil(w / 2 + 1) * h) on a 1 x 5 map
+            raise ValueError(f"empty target range {trg}: the reference's get_loss fails on it too (min of an empty "
+                             "arange, control_wrappers.py:339) -- the map is too small for this problem's static targets")
         return float(lo), float(lo + n - 1)
     return float(trg), float(trg)

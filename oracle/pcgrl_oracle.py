@@ -165,6 +165,8 @@ def make_config(problem, representation, map_shape, obs_window=None, weights=Non
             cfg.has_trg[i] = 1
             if isinstance(t, tuple):  # control_wrappers.py:337-339: min |arange(lo, hi) - val|
                 vals = np.arange(*t)
+                if len(vals) == 0:  # the reference raises at its first get_loss (min of an empty array)
+                    raise ValueError(f"empty target range {t} for '{k}' on map_shape {map_shape}")
                 cfg.trg_lo[i], cfg.trg_hi[i] = float(vals[0]), float(vals[-1])
             else:
                 cfg.trg_lo[i] = cfg.trg_hi[i] = float(t)

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Differential fuzzer: random supported configurations of the HIP engine against the CPU oracle, step by step.
+
+Every case draws a problem, representation, map shape, observation window, change budget, optional representation
+wrappers (static tiles / action patch) and optional controls from the space the engine accepts
+(csrc/pcgrl_engine.hip validate_config), runs both sides on the same seeds and actions across auto-resets and compares
+stats / reward / done at every step and observations / full state every few steps (bit-exact; rewards to 1e-6 / 1e-9).
+A failing case prints its one-line description, which `--case '<json>'` replays.
+
+Checker-side script (it imports oracle/): lives under tests/, is not collected by pytest; tests/test_gpu_parity.py runs
+a short fixed-seed sweep of it.  On the GPU box:  python tests/fuzz_parity.py --cases 200 --seed 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+N_TILES = {"binary": 2, "zelda": 8, "sokoban": 5, "minecraft_3D_maze": 2}
+
+
+def draw_case(rng):
+    """one random configuration (a JSON-able dict) the engine accepts"""
+    problem = str(rng.choice(["binary", "zelda", "sokoban", "minecraft_3D_maze"], p=[0.35, 0.3, 0.15, 0.2]))
+    case = dict(problem=problem, kw={})
+    kw = case["kw"]
+    if problem == "minecraft_3D_maze":
+        case["rep"] = "narrow"
+        big = rng.random() < 0.25
+        hi = 16 if big else 8
+        shape = [int(rng.integers(1, hi + 1)) for _ in range(3)]
+        case["shape"] = shape
+        if rng.random() < 0.4:  # any window whose volume is a multiple of 4
+            ow = [int(rng.integers(1, 2 * s + 3)) for s in shape]
+            ow[2] += (-ow[2]) % 4 if (ow[0] * ow[1] * ow[2]) % 4 else 0
+            kw["obs_window"] = ow
+        cells = shape[0] * shape[1] * shape[2]
+        case["n_envs"] = int(rng.integers(1, max(2, min(200, 40000 // max(cells, 1)))))
+        if rng.random() < 0.7 or cells > 600:
+            kw["change_percentage"] = float(rng.choice([0.02, 0.05, 0.1, 0.3]))
+        if rng.random() < 0.3:
+            kw["controls"] = [str(k) for k in rng.choice(["regions", "path-length", "n_jump"], size=int(rng.integers(1, 3)), replace=False)]
+        case["steps"] = int(rng.integers(30, 160 if cells <= 600 else 60))
+        case["bias"] = bool(rng.random() < 0.5)
+        return case
+    rep = str(rng.choice(["narrow", "turtle", "wide"], p=[0.45, 0.35, 0.2]))
+    case["rep"] = rep
+    wmax = 32 if problem == "sokoban" else 64
+    r = rng.random()
+    if rep == "wide":  # square maps only; obs_window == map_shape
+        s = int(rng.integers(1, (wmax if r < 0.2 else 20) + 1))
+        shape = [s, s]
+    elif r < 0.15:
+        shape = [int(rng.integers(1, (62 if problem == "sokoban" else 64) + 1)), int(rng.integers(1, wmax + 1))]
+    else:
+        shape = [int(rng.integers(1, 25)), int(rng.integers(1, min(wmax, 34) + 1))]
+    case["shape"] = shape
+    H, W = shape
+    if rep != "wide" and rng.random() < 0.5:
+        kw["obs_window"] = [int(rng.integers(1, 2 * H + 4)), int(rng.integers(1, 2 * W + 4))]
+    if rng.random() < 0.5:
+        kw["change_percentage"] = float(rng.choice([0.05, 0.2, 0.5, 1.0]))
+    if rep != "wide" and rng.random() < 0.3:
+        kw["static_prob"] = float(rng.choice([0.0, 0.1, 0.3, 0.7]))
+        kw["n_static_walls"] = int(rng.integers(0, 6)) if H >= 3 and W >= 3 else 0
+    if rep == "narrow" and rng.random() < 0.25:
+        kw["act_window"] = [int(rng.integers(1, min(H, 5) + 1)), int(rng.integers(1, min(W, 5) + 1))]
+    if rng.random() < 0.25:
+        keys = {"binary": ["regions", "path-length"],
+                "zelda": ["nearest-enemy", "enemies", "player", "key", "door", "regions", "path-length"],
+                "sokoban": ["player", "crate", "ratio", "dist-win", "sol-length", "regions"]}[problem]
+        kw["controls"] = [str(k) for k in rng.choice(keys, size=int(rng.integers(1, 3)), replace=False)]
+    if problem == "sokoban":
+        kw["solver_power"] = int(rng.choice([50, 500, 3000, 10000]))
+    cells = H * W
+    case["n_envs"] = int(rng.integers(1, max(2, min(600, 60000 // cells))))
+    case["steps"] = int(rng.integers(30, 200))
+    case["bias"] = False
+    return case
+
+
+def run_case(case, seed, verbose=False):
+    import torch
+    import pcgrl_oracle as po  # (checker)
+    from control_pcgrl_amd import VecPcgrlEnv
+
+    problem, rep, shape, n, T = case["problem"], case["rep"], tuple(case["shape"]), case["n_envs"], case["steps"]
+    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items()}
+    controls = kw.get("controls")
+    seeds = seed + np.arange(n)
+    ekw = dict(kw)
+    if controls:
+        ekw["reward_dtype"] = torch.float64
+    try:
+        env = VecPcgrlEnv(problem, rep, shape, n, seeds=seeds, auto_reset=True, **ekw)
+    except ValueError as e:  # a configuration the reference cannot run either: the oracle must refuse it as well
+        try:
+            po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, **kw)
+        except ValueError:
+            return -1
+        raise AssertionError(f"the engine refuses ({e}) what the oracle accepts")
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, **kw)
+    rng = np.random.default_rng(seed)
+    bounds = po.cond_bounds(problem, shape) if controls else None
+
+    def queue():
+        trg = {k: rng.random(n) * (bounds[k][1] - bounds[k][0]) + bounds[k][0] for k in controls}
+        env.queue_targets({k: torch.as_tensor(v) for k, v in trg.items()})
+        orc.queue_targets(trg)
+
+    if controls:
+        queue()
+    obs, info = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.reset()), "reset observation"
+    if controls:
+        assert np.allclose(info["ctrl_obs"].cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), "reset ctrl_obs"
+    g = torch.Generator().manual_seed(seed)
+    full_every = int(rng.integers(3, 30))
+    tol = 1e-9 if controls else 1e-6
+    for t in range(T):
+        if controls and t % 37 == 0:
+            queue()
+        size = (n, env.action_entries) if env.action_entries > 1 else (n,)
+        if case.get("bias"):
+            a = (torch.rand(size, generator=g) < 0.5 + 0.45 * np.sin(t / 23.0)).to(torch.int32)
+        else:
+            a = torch.randint(0, env.num_actions, size, generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a.to(env.device))
+        want = t % full_every == 0 or t == T - 1
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want)
+        got = info["stats"].cpu().numpy()
+        if not np.array_equal(got, ostats):
+            bad = np.nonzero((got != ostats).any(axis=1))[0]
+            e = int(bad[0])
+            grid = orc.get_state()["grids"][e].reshape(shape)
+            if problem == "sokoban":  # a level with more crates than the device solver holds is REPORTED (error bit 2)
+                try:
+                    env.check_errors()
+                except NotImplementedError as ex:
+                    if "solver" in str(ex):
+                        return -2
+                    raise
+            raise AssertionError(f"stats @ {t}: {len(bad)} envs, first {e}: got {got[e].tolist()} want {ostats[e].tolist()} "
+                                 f"(done {bool(odone[e])}) oracle grid after the step:\n{grid}")
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward @ {t}"
+        assert np.array_equal(done.cpu().numpy(), odone), f"done @ {t}"
+        if controls:
+            assert np.allclose(info["ctrl_obs"].cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), f"ctrl_obs @ {t}"
+        if want:
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+            st, ost = env.get_state(), orc.get_state()
+            assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"]), f"grids @ {t}"
+            if rep != "wide":
+                assert np.array_equal(st.pos.cpu().numpy()[:, :len(shape)], ost["pos"][:, :len(shape)]), f"pos @ {t}"
+            assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"]), f"iteration @ {t}"
+            assert np.array_equal(st.changes.cpu().numpy(), ost["changes"]), f"changes @ {t}"
+            if env.static_tiles:
+                assert np.array_equal(env.get_static().cpu().numpy(), orc.static_tiles()), f"static mask @ {t}"
+    le, ole = env.last_episode(), orc.last_episode()
+    assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]), "episode counts"
+    assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"]), "final stats"
+    env.check_errors()
+    return int(ole["n_episodes"].sum())
+
+
+def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    failures = []
+    for i in range(n_cases):
+        case = draw_case(rng)
+        cs = int(rng.integers(0, 1 << 30))
+        line = json.dumps(dict(case, seed=cs))
+        t1 = time.time()
+        try:
+            eps = run_case(case, cs)
+            if verbose:
+                print(f"ok   {i:4d} {time.time() - t1:6.1f}s eps={eps:5d} {line}", flush=True)
+        except NotImplementedError as e:  # a configuration the engine refuses: the generator should not have drawn it
+            failures.append((line, f"refused: {e}"))
+            print(f"REFUSED {i:4d} {line}\n     {e}", flush=True)
+            if stop_on_fail:
+                break
+        except AssertionError as e:
+            failures.append((line, str(e)))
+            print(f"FAIL {i:4d} {line}\n     {e}", flush=True)
+            if stop_on_fail:
+                break
+        if budget_s is not None and time.time() - t0 > budget_s:
+            print(f"time budget reached after {i + 1} cases", flush=True)
+            break
+    return failures
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--budget-s", type=float, default=None)
+    ap.add_argument("--keep-going", action="store_true")
+    ap.add_argument("--case", type=str, default=None, help="replay one case (the JSON a failure printed)")
+    ap.add_argument("--dry", action="store_true", help="only print the drawn cases (no GPU needed)")
+    a = ap.parse_args()
+    if a.dry:
+        r = np.random.default_rng(a.seed)
+        for _ in range(a.cases):
+            c = draw_case(r)
+            print(json.dumps(dict(c, seed=int(r.integers(0, 1 << 30)))))
+        sys.exit(0)
+    if a.case:
+        c = json.loads(a.case)
+        s = c.pop("seed")
+        print("episodes:", run_case(c, s, verbose=True))
+        sys.exit(0)
+    f = sweep(a.cases, a.seed, stop_on_fail=not a.keep_going, budget_s=a.budget_s)
+    print(f"{len(f)} failure(s)")
+    sys.exit(1 if f else 0)

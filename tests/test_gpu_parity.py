@@ -283,6 +283,10 @@ def test_mc3dmaze_odd_observation_windows_vs_oracle():
     _rollout_vs_oracle("minecraft_3D_maze", "narrow", (12, 12, 12), 6, 60, full_every=11, obs_window=(36, 34, 8), change_percentage=0.02)
     _rollout_vs_oracle("minecraft_3D_maze", "narrow", (3, 3, 3), 40, 70, full_every=3)
     _rollout_vs_oracle("minecraft_3D_maze", "narrow", (2, 4, 4), 12, 50, full_every=3)
+    # rows of one or two cells (a 16-byte chunk then spans four / two window rows)
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (4, 4, 2), 84, 60, full_every=3, obs_window=(8, 2, 1))
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (6, 6, 5), 33, 60, full_every=5, obs_window=(8, 12, 1))
+    _rollout_vs_oracle("minecraft_3D_maze", "narrow", (5, 5, 3), 33, 60, full_every=5, obs_window=(7, 6, 2))
 
 
 @pytest.mark.parametrize("shape,n,T,kw", [((7, 7, 7), 1024, 1300, {}), ((15, 15, 15), 64, 500, dict(change_percentage=0.05)),
@@ -343,13 +347,13 @@ def test_other_map_shapes_vs_oracle(shape):
 
 
 @pytest.mark.parametrize("shape,ow", [((1, 16), (2, 32)), ((2, 2), (4, 16)), ((3, 3), (6, 16)), ((1, 1), (2, 16)),
-                                      ((64, 1), (16, 16)), ((4, 64), (8, 64))])
+                                      ((64, 1), (16, 16)), ((4, 64), (8, 64)), ((62, 3), (16, 6))])
 def test_degenerate_map_shapes_vs_oracle(shape, ow):
     """single-row / single-column / single-cell maps: empty frontiers, one-lane groups, W = 1 and W = 64 masks"""
     _rollout_vs_oracle("binary", "narrow", shape, 19, 3 * shape[0] * shape[1] + 30, full_every=3, obs_window=ow)
     if shape[0] * shape[1] >= 9:  # smaller maps have empty zelda target ranges (the reference fails on them too)
         _rollout_vs_oracle("zelda", "turtle", shape, 19, 60, full_every=3, obs_window=ow)
-    if shape[1] > 32:  # the device solver's level rows are 32 bits wide
+    if shape[1] > 32 or shape[0] > 62:  # the device solver's level: 32-bit rows, at most 64 of them with the border
         with pytest.raises(NotImplementedError):
             _vec("sokoban", "narrow", shape, 4, obs_window=ow)
         return
@@ -1309,10 +1313,10 @@ def _solvable_rooms(n, seed, shape=(16, 16)):
     return g
 
 
-@pytest.mark.parametrize("shape", [(8, 8), (12, 20), (20, 20), (30, 30), (32, 32)])
+@pytest.mark.parametrize("shape", [(8, 8), (12, 20), (20, 20), (30, 30), (32, 32), (33, 17), (45, 6), (62, 32)])
 def test_sokoban_solver_other_map_shapes_vs_oracle(shape):
-    """the device solver with its helper wavefronts behind the lanes-per-env families it supports (8 / 16 / 32 lanes per
-    env: a bordered level is at most 34 x 34):
+    """the device solver with its helper wavefronts behind the lanes-per-env families it supports (8 / 16 / 32 / 64 lanes
+    per env: a bordered level is at most 64 rows of 34 cells):
     playable rooms inside maps off the 16x16 point, one level per workgroup (pcgrl_stats_for_grids)"""
     g = _solvable_rooms(96, 31 + shape[0], shape)
     want = po.stats_for_grids("sokoban", g, solver_power=2000)
@@ -1504,3 +1508,11 @@ def test_step_graph_replay_vs_oracle(problem, rep):
         assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL
     assert np.array_equal(obs.cpu().numpy(), oobs)
     env.check_errors()
+
+
+def test_fuzz_sweep_fixed_seed():
+    """tests/fuzz_parity.py: 250 random supported configurations (problem x representation x map shape x window x change
+    budget x wrappers x controls) against the oracle, every step.  Longer sweeps: python tests/fuzz_parity.py --cases N"""
+    import fuzz_parity
+    failures = fuzz_parity.sweep(250, 20261002, verbose=False, stop_on_fail=False)
+    assert not failures, failures[:3]

@@ -183,3 +183,16 @@ def test_bench_solver_active_maps_are_playable():
     assert a.shape == (32, 96) and (a % 5 <= 1).all() and a.min() >= 0 and a.max() < 1280
     for i in range(96):
         assert set((a[:, i] // 5).tolist()) <= set(cells[i].tolist())
+
+
+def test_empty_static_target_range_is_refused_like_the_reference():
+    """zelda's nearest-enemy target is the range (5, ceil(w / 2 + 1) * h): on a 1 x 5 map np.arange(5, 4) is empty and the
+    reference's get_loss raises (min of an empty array, control_wrappers.py:339) -- so do the host config builder and the
+    oracle, instead of inventing an interval (found by tests/fuzz_parity.py)."""
+    from control_pcgrl_amd.vec_env import build_config
+    with pytest.raises(ValueError, match="empty target range"):
+        build_config("zelda", "narrow", (1, 5))
+    with pytest.raises(ValueError, match="empty target range"):
+        po.make_config("zelda", "narrow", (1, 5))
+    build_config("zelda", "narrow", (2, 5))  # (5, 8): fine
+    po.make_config("zelda", "narrow", (2, 5))
