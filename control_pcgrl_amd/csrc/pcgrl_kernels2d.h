@@ -1716,7 +1716,9 @@ void step_kernel(Params p) {
   // After pcgrl_update the statistics are stale (ENV_STATS_DIRTY): from scratch.  The compile-time 16x16 kernels carry
   // no code for it (it costs them 4 % at large batches): while stale envs may exist the host launches the general kernel
   // (Params::no_fast), which also drops the PREFLOOD plane it does not maintain.
-  const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change && map_changed;
+  // (stale: whenever the representation reports a change -- also a build that static tiles undid: the reference then calls
+  // get_stats on the current map, which the pcgrl_update calls before have edited)
+  const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change;
   if constexpr (FAST) {
     // Which kernel runs is a HOST decision (Params::no_fast) that a captured HIP graph freezes: a graph captured before
     // pcgrl_update and replayed after it lands here with stale statistics.  Never silently: the launch raises error
@@ -1903,7 +1905,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
       }
     } else {
       const bool restat = change && map_changed;
-      const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && restat;  // first changing step after pcgrl_update
+      const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change;  // first changing step after pcgrl_update
       if constexpr (FAST) {  // (see step_kernel: a captured launch replayed after pcgrl_update)
         if ((flags & ENV_STATS_DIRTY) != 0 && restat && active && g.row == 0) atomicOr(p.err, 8);
       }
@@ -2032,7 +2034,8 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
       pos[0] = p.cfg.act_window[0] > 0 ? (p.cfg.act_window[0] - 1) / 2 : 0;
       pos[1] = p.cfg.act_window[0] > 0 ? (p.cfg.act_window[1] - 1) / 2 : 0;
     }
-    if (p.init_pos && p.cfg.representation != PCGRL_REP_WIDE) {
+    // (with an action patch the position is a function of the step counter alone: init_pos is ignored)
+    if (p.init_pos && p.cfg.representation != PCGRL_REP_WIDE && p.cfg.act_window[0] <= 0) {
       pos[0] = p.init_pos[(size_t)e * 3 + 0];
       pos[1] = p.init_pos[(size_t)e * 3 + 1];
     }

@@ -111,7 +111,9 @@ void pcgrl_destroy(pcgrl_handle h);
 int pcgrl_seed(pcgrl_handle h, const uint64_t *seeds);
 
 /* d_mask NULL = every env.  d_init_grids (uint8 [N][cells]) / d_init_pos (int32 [N][3]) non-NULL: start
- * from the given maps / agent positions instead of drawing them (no RNG consumption). */
+ * from the given maps / agent positions instead of drawing them (no RNG consumption).  Injected maps carry no static
+ * tiles; d_init_pos is ignored by the wide representation and with cfg.act_window (the patch position is a function
+ * of the step counter alone). */
 int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_grids, const int32_t *d_init_pos,
                 void *stream);
 

@@ -49,6 +49,7 @@ def draw_case(rng):
             kw["controls"] = [str(k) for k in rng.choice(["regions", "path-length", "n_jump"], size=int(rng.integers(1, 3)), replace=False)]
         case["steps"] = int(rng.integers(30, 160 if cells <= 600 else 60))
         case["bias"] = bool(rng.random() < 0.5)
+        case["mode"] = "mixed" if rng.random() < 0.5 else "step"
         return case
     rep = str(rng.choice(["narrow", "turtle", "wide"], p=[0.45, 0.35, 0.2]))
     case["rep"] = rep
@@ -82,7 +83,8 @@ def draw_case(rng):
     cells = H * W
     case["n_envs"] = int(rng.integers(1, max(2, min(600, 60000 // cells))))
     case["steps"] = int(rng.integers(30, 200))
-    case["bias"] = False
+    case["bias"] = bool(problem == "binary" and rng.random() < 0.2)
+    case["mode"] = "mixed" if rng.random() < 0.5 else "step"
     return case
 
 
@@ -98,8 +100,12 @@ def run_case(case, seed, verbose=False):
     ekw = dict(kw)
     if controls:
         ekw["reward_dtype"] = torch.float64
+
+    def make_engine():
+        return VecPcgrlEnv(problem, rep, shape, n, seeds=seeds, auto_reset=True, **ekw)
+
     try:
-        env = VecPcgrlEnv(problem, rep, shape, n, seeds=seeds, auto_reset=True, **ekw)
+        env = make_engine()
     except ValueError as e:  # a configuration the reference cannot run either: the oracle must refuse it as well
         try:
             po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, **kw)
@@ -109,63 +115,150 @@ def run_case(case, seed, verbose=False):
     orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, **kw)
     rng = np.random.default_rng(seed)
     bounds = po.cond_bounds(problem, shape) if controls else None
+    g = torch.Generator().manual_seed(seed)
+    tol = 1e-9 if controls else 1e-6
+    n_tiles = N_TILES[problem]
 
     def queue():
         trg = {k: rng.random(n) * (bounds[k][1] - bounds[k][0]) + bounds[k][0] for k in controls}
         env.queue_targets({k: torch.as_tensor(v) for k, v in trg.items()})
         orc.queue_targets(trg)
 
+    def draw_actions(t, lead=()):
+        size = tuple(lead) + ((n, env.action_entries) if env.action_entries > 1 else (n,))
+        if case.get("bias"):
+            return (torch.rand(size, generator=g) < 0.5 + 0.45 * np.sin(t / 23.0)).to(torch.int32)
+        return torch.randint(0, env.num_actions, size, generator=g, dtype=torch.int32)
+
+    def check_stats(got, want, odone, what):
+        if np.array_equal(got, want):
+            return True
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        e = int(bad[0])
+        if problem == "sokoban":  # a level with more crates than the device solver holds is REPORTED (error bit 2)
+            try:
+                env.check_errors()
+            except NotImplementedError as ex:
+                if "solver" in str(ex):
+                    return False
+                raise
+        grid = orc.get_state()["grids"][e].reshape(shape)
+        raise AssertionError(f"stats {what}: {len(bad)} envs, first {e}: got {got[e].tolist()} want {want[e].tolist()} "
+                             f"(done {None if odone is None else bool(odone[e])}) oracle grid afterwards:\n{grid}")
+
+    def check_state(what):
+        st, ost = env.get_state(), orc.get_state()
+        assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"]), f"grids {what}"
+        if rep != "wide":
+            assert np.array_equal(st.pos.cpu().numpy()[:, :len(shape)], ost["pos"][:, :len(shape)]), f"pos {what}"
+        assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"]), f"iteration {what}"
+        assert np.array_equal(st.changes.cpu().numpy(), ost["changes"]), f"changes {what}"
+        assert np.allclose(st.ep_return.cpu().numpy(), ost["ep_return"], atol=1e-6), f"ep_return {what}"
+        if env.static_tiles:
+            assert np.array_equal(env.get_static().cpu().numpy(), orc.static_tiles()), f"static mask {what}"
+
+    def check_ctrl(what):
+        if controls:
+            assert np.allclose(env.ctrl_obs.cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), f"ctrl_obs {what}"
+
     if controls:
         queue()
     obs, info = env.reset()
     assert np.array_equal(obs.cpu().numpy(), orc.reset()), "reset observation"
-    if controls:
-        assert np.allclose(info["ctrl_obs"].cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), "reset ctrl_obs"
-    g = torch.Generator().manual_seed(seed)
+    check_ctrl("after reset")
     full_every = int(rng.integers(3, 30))
-    tol = 1e-9 if controls else 1e-6
-    for t in range(T):
-        if controls and t % 37 == 0:
+    mixed = case.get("mode") == "mixed"
+    t = 0
+    trace = case.setdefault("_trace", [])
+    while t < T:
+        if controls and rng.random() < 0.05:
             queue()
-        size = (n, env.action_entries) if env.action_entries > 1 else (n,)
-        if case.get("bias"):
-            a = (torch.rand(size, generator=g) < 0.5 + 0.45 * np.sin(t / 23.0)).to(torch.int32)
+        ev = "step"
+        if mixed:
+            ev = str(rng.choice(["step", "rollout", "update_refresh", "update_step", "swap", "masked_reset", "inject", "observe"],
+                                p=[0.3, 0.25, 0.08, 0.08, 0.08, 0.08, 0.08, 0.05]))
+        what = f"@ {t} ({ev})"
+        trace.append(f"{t}:{ev}")
+        if ev == "step":
+            for _ in range(int(rng.integers(1, 8)) if mixed else 1):
+                what = f"@ {t} ({ev})"
+                a = draw_actions(t)
+                obs, rew, done, _, info = env.step(a.to(env.device))
+                want = t % full_every == 0 or t >= T - 1
+                oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want)
+                if not check_stats(info["stats"].cpu().numpy(), ostats, odone, what):
+                    return -2
+                assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward {what}"
+                assert np.array_equal(done.cpu().numpy(), odone), f"done {what}"
+                check_ctrl(what)
+                if want:
+                    assert np.array_equal(obs.cpu().numpy(), oobs), f"obs {what}"
+                    check_state(what)
+                t += 1
+        elif ev == "rollout":
+            K = int(rng.integers(2, 13))
+            want = str(rng.choice(["all", "last", "none"]))
+            a = draw_actions(t, lead=(K,))
+            obs, rew, done, stats = env.rollout(a.to(env.device), want_obs=want)
+            rew, done, stats = rew.cpu().numpy().astype(np.float64), done.cpu().numpy(), stats.cpu().numpy()
+            obs = None if obs is None else obs.cpu().numpy()
+            for k in range(K):
+                oobs, orew, odone, ostats = orc.step(a[k].numpy(), auto_reset=True, want_obs=True)
+                if not check_stats(stats[k], ostats, odone, f"{what} step {k}/{K}"):
+                    return -2
+                assert np.max(np.abs(rew[k] - orew)) <= tol, f"reward {what} step {k}/{K}"
+                assert np.array_equal(done[k], odone), f"done {what} step {k}/{K}"
+                if want == "all":
+                    assert np.array_equal(obs[k], oobs), f"obs {what} step {k}/{K}"
+            if want == "last":
+                assert np.array_equal(obs, oobs), f"last obs {what}"
+            check_ctrl(what)
+            check_state(what)
+            t += K
+        elif ev in ("update_refresh", "update_step"):
+            for _ in range(int(rng.integers(1, 5))):
+                a = draw_actions(t)
+                assert np.array_equal(env.update(a.to(env.device)).cpu().numpy(), orc.update(a.numpy())), f"update obs {what}"
+            if ev == "update_refresh":
+                if not check_stats(env.refresh_stats().cpu().numpy(), orc.refresh_stats(), None, what):
+                    return -2
+            t += 1
+        elif ev == "swap":  # checkpoint into a fresh engine and go on with that one
+            sd = env.state_dict()
+            env2 = make_engine()
+            env2.load_state_dict(sd)
+            env.check_errors()
+            env.close()
+            env = env2
+            assert np.array_equal(env.observe().cpu().numpy(), orc.observe()), f"obs {what}"
+            check_state(what)
+            t += 1
+        elif ev == "masked_reset":
+            mask = (rng.random(n) < rng.random()).astype(np.uint8)
+            obs, _ = env.reset(mask=mask)
+            assert np.array_equal(obs.cpu().numpy(), orc.reset(mask=mask)), f"obs {what}"
+            check_ctrl(what)
+            check_state(what)
+            t += 1
+        elif ev == "inject":
+            mask = (rng.random(n) < rng.random()).astype(np.uint8)
+            grids = rng.integers(0, n_tiles, size=(n,) + shape, dtype=np.uint8)
+            if rng.random() < 0.5:  # sparse maps: long paths, playable levels
+                grids = np.where(rng.random((n,) + shape) < 0.8, np.uint8(0 if problem != "sokoban" else 0), grids).astype(np.uint8)
+            pos = np.stack([rng.integers(0, s, size=n) for s in shape], axis=1).astype(np.int32)
+            obs, _ = env.reset(mask=mask, init_grids=grids, init_pos=pos)
+            assert np.array_equal(obs.cpu().numpy(), orc.reset(mask=mask, init_grids=grids, init_pos=pos)), f"obs {what}"
+            if not check_stats(env.get_state().stats.cpu().numpy(), orc.get_state()["stats"], None, what):
+                return -2
+            check_state(what)
+            t += 1
         else:
-            a = torch.randint(0, env.num_actions, size, generator=g, dtype=torch.int32)
-        obs, rew, done, _, info = env.step(a.to(env.device))
-        want = t % full_every == 0 or t == T - 1
-        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want)
-        got = info["stats"].cpu().numpy()
-        if not np.array_equal(got, ostats):
-            bad = np.nonzero((got != ostats).any(axis=1))[0]
-            e = int(bad[0])
-            grid = orc.get_state()["grids"][e].reshape(shape)
-            if problem == "sokoban":  # a level with more crates than the device solver holds is REPORTED (error bit 2)
-                try:
-                    env.check_errors()
-                except NotImplementedError as ex:
-                    if "solver" in str(ex):
-                        return -2
-                    raise
-            raise AssertionError(f"stats @ {t}: {len(bad)} envs, first {e}: got {got[e].tolist()} want {ostats[e].tolist()} "
-                                 f"(done {bool(odone[e])}) oracle grid after the step:\n{grid}")
-        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward @ {t}"
-        assert np.array_equal(done.cpu().numpy(), odone), f"done @ {t}"
-        if controls:
-            assert np.allclose(info["ctrl_obs"].cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), f"ctrl_obs @ {t}"
-        if want:
-            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
-            st, ost = env.get_state(), orc.get_state()
-            assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"]), f"grids @ {t}"
-            if rep != "wide":
-                assert np.array_equal(st.pos.cpu().numpy()[:, :len(shape)], ost["pos"][:, :len(shape)]), f"pos @ {t}"
-            assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"]), f"iteration @ {t}"
-            assert np.array_equal(st.changes.cpu().numpy(), ost["changes"]), f"changes @ {t}"
-            if env.static_tiles:
-                assert np.array_equal(env.get_static().cpu().numpy(), orc.static_tiles()), f"static mask @ {t}"
+            assert np.array_equal(env.observe().cpu().numpy(), orc.observe()), f"obs {what}"
+            t += 1
     le, ole = env.last_episode(), orc.last_episode()
     assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]), "episode counts"
     assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"]), "final stats"
+    assert np.array_equal(le.ep_len.cpu().numpy(), ole["ep_len"]), "episode lengths"
     env.check_errors()
     return int(ole["n_episodes"].sum())
 
@@ -181,6 +274,7 @@ def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
         t1 = time.time()
         try:
             eps = run_case(case, cs)
+            case.pop("_trace", None)
             if verbose:
                 print(f"ok   {i:4d} {time.time() - t1:6.1f}s eps={eps:5d} {line}", flush=True)
         except NotImplementedError as e:  # a configuration the engine refuses: the generator should not have drawn it
@@ -190,7 +284,7 @@ def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
                 break
         except AssertionError as e:
             failures.append((line, str(e)))
-            print(f"FAIL {i:4d} {line}\n     {e}", flush=True)
+            print(f"FAIL {i:4d} {line}\n     {e}\n     events: {' '.join(case.get('_trace', [])[-12:])}", flush=True)
             if stop_on_fail:
                 break
         if budget_s is not None and time.time() - t0 > budget_s:
@@ -217,7 +311,10 @@ if __name__ == "__main__":
     if a.case:
         c = json.loads(a.case)
         s = c.pop("seed")
-        print("episodes:", run_case(c, s, verbose=True))
+        try:
+            print("episodes:", run_case(c, s, verbose=True))
+        finally:
+            print("events:", " ".join(c.get("_trace", [])))
         sys.exit(0)
     f = sweep(a.cases, a.seed, stop_on_fail=not a.keep_going, budget_s=a.budget_s)
     print(f"{len(f)} failure(s)")

@@ -955,27 +955,33 @@ def test_auto_reset_every_few_steps_4096_envs_vs_oracle(problem, rep):
     _rollout_vs_oracle(problem, rep, (16, 16), n, 1500, seed0=31, full_every=211, threads=16, change_percentage=0.001)
 
 
-@pytest.mark.parametrize("problem,rep,shape", [("binary", "narrow", (16, 16)), ("binary", "turtle", (20, 24)),
-                                               ("zelda", "narrow", (16, 16)), ("sokoban", "turtle", (16, 16)),
-                                               ("binary", "narrow", (40, 48)), ("minecraft_3D_maze", "narrow", (7, 7, 7)),
-                                               ("minecraft_3D_maze", "narrow", (10, 10, 10))])
-def test_update_then_step_without_refresh_vs_oracle(problem, rep, shape):
+@pytest.mark.parametrize("problem,rep,shape,kw", [
+    ("binary", "narrow", (16, 16), {}), ("binary", "turtle", (20, 24), {}), ("zelda", "narrow", (16, 16), {}),
+    ("sokoban", "turtle", (16, 16), {}), ("binary", "narrow", (40, 48), {}), ("minecraft_3D_maze", "narrow", (7, 7, 7), {}),
+    ("minecraft_3D_maze", "narrow", (10, 10, 10), {}),
+    # static tiles: a build on a static tile is undone but still reported as a change -- the reference then recomputes
+    # the statistics of the (updated) map; found by tests/fuzz_parity.py
+    ("binary", "turtle", (15, 30), dict(static_prob=0.3, n_static_walls=2)),
+    ("zelda", "narrow", (12, 12), dict(static_prob=0.7, n_static_walls=2)),
+    ("binary", "narrow", (8, 9), dict(static_prob=0.5, n_static_walls=0, act_window=[1, 3]))])
+def test_update_then_step_without_refresh_vs_oracle(problem, rep, shape, kw):
     """pcgrl_update leaves the statistics stale; the next CHANGING pcgrl_step must recompute them from scratch (the
     reference's get_stats, pcgrl_env.py:314-323) -- not incrementally from the stale masks -- and non-changing steps in
     between keep reporting the old values (the reference's _rep_stats)."""
     n = 192
     seeds = 900 + np.arange(n)
-    env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=False)
-    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds)
+    env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=False, **kw)
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, **kw)
     env.reset(); orc.reset()
     g = torch.Generator().manual_seed(5)
+    size = (n, env.action_entries) if env.action_entries > 1 else (n,)
     for rnd in range(4):
-        for t in range(25):
-            a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        for t in range(3 if kw else 25):
+            a = torch.randint(0, env.num_actions, size, generator=g, dtype=torch.int32)
             env.update(a.to(env.device), want_obs=(t % 2 == 0))
             orc.update(a.numpy())
         for t in range(30):
-            a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+            a = torch.randint(0, env.num_actions, size, generator=g, dtype=torch.int32)
             if rnd == 3:  # through the rollout kernel
                 _, rew, done, stats = env.rollout(a.to(env.device)[None], want_obs="none")
                 rew, stats = rew[0], stats[0]
@@ -1516,3 +1522,28 @@ def test_fuzz_sweep_fixed_seed():
     import fuzz_parity
     failures = fuzz_parity.sweep(250, 20261002, verbose=False, stop_on_fail=False)
     assert not failures, failures[:3]
+
+
+def test_injected_maps_with_action_patch_ignore_init_pos():
+    """with an action patch the edit position is a function of the step counter alone: a masked reset that injects maps
+    AND positions starts at the first patch centre, like the oracle (found by tests/fuzz_parity.py)"""
+    n, shape, kw = 45, (20, 28), dict(act_window=[4, 3])
+    seeds = 77 + np.arange(n)
+    env = _vec("binary", "narrow", shape, n, seeds=seeds, auto_reset=True, **kw)
+    orc = po.OracleVecEnv("binary", "narrow", shape, n, seeds=seeds, **kw)
+    assert np.array_equal(env.reset()[0].cpu().numpy(), orc.reset())
+    rng = np.random.default_rng(3)
+    g = torch.Generator().manual_seed(3)
+    for rnd in range(3):
+        mask = (rng.random(n) < 0.6).astype(np.uint8)
+        grids = rng.integers(0, 2, size=(n,) + shape, dtype=np.uint8)
+        pos = np.stack([rng.integers(0, s, size=n) for s in shape], axis=1).astype(np.int32)
+        obs, _ = env.reset(mask=mask, init_grids=grids, init_pos=pos)
+        assert np.array_equal(obs.cpu().numpy(), orc.reset(mask=mask, init_grids=grids, init_pos=pos)), f"obs after inject {rnd}"
+        for t in range(12):
+            a = torch.randint(0, 2, (n, 12), generator=g, dtype=torch.int32)
+            obs, rew, done, _, info = env.step(a.to(env.device))
+            oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True)
+            assert np.array_equal(info["stats"].cpu().numpy(), ostats) and np.array_equal(obs.cpu().numpy(), oobs), (rnd, t)
+    assert np.array_equal(env.get_state().pos.cpu().numpy()[:, :2], orc.get_state()["pos"][:, :2])
+    env.check_errors()
