@@ -26,8 +26,25 @@ import numpy as np  # noqa: E402
 N_TILES = {"binary": 2, "zelda": 8, "sokoban": 5, "minecraft_3D_maze": 2}
 
 
+STAT_KEYS = {"binary": ["regions", "path-length"],
+             "zelda": ["player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length"],
+             "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length", "ratio"],
+             "minecraft_3D_maze": ["regions", "path-length", "n_jump"]}
+
+
 def draw_case(rng):
     """one random configuration (a JSON-able dict) the engine accepts"""
+    case = _draw_case(rng)
+    kw = case["kw"]
+    if rng.random() < 0.25:
+        kw["weights"] = {k: int(rng.integers(0, 6)) for k in STAT_KEYS[case["problem"]]}
+    if rng.random() < 0.25:
+        kw["max_board_scans"] = int(rng.integers(1, 4))
+    case["auto_reset"] = bool(rng.random() < 0.8)
+    return case
+
+
+def _draw_case(rng):
     problem = str(rng.choice(["binary", "zelda", "sokoban", "minecraft_3D_maze"], p=[0.35, 0.3, 0.15, 0.2]))
     case = dict(problem=problem, kw={})
     kw = case["kw"]
@@ -88,6 +105,32 @@ def draw_case(rng):
     return case
 
 
+def random_grids(rng, problem, m, shape):
+    """maps of several kinds: uniform noise, sparse noise (long paths), and -- sokoban / zelda -- playable levels (exactly
+    one player, matching crates and targets / one key and one door), which is where the solver and the path searches run"""
+    n_tiles = N_TILES[problem]
+    g = rng.integers(0, n_tiles, size=(m,) + tuple(shape), dtype=np.uint8)
+    kind = rng.random()
+    if kind < 0.35:
+        g = np.where(rng.random(g.shape) < rng.choice([0.5, 0.8, 0.95]), np.uint8(0), g).astype(np.uint8)
+    elif kind < 0.7 and problem in ("sokoban", "zelda") and int(np.prod(shape)) >= 6:
+        cells = int(np.prod(shape))
+        flat = g.reshape(m, cells)
+        for i in range(m):
+            row = np.where(rng.random(cells) < rng.choice([0.3, 0.6, 0.9]), 0, 1).astype(np.uint8)  # empty / solid
+            if problem == "sokoban":  # tiles: 0 empty 1 solid 2 player 3 crate 4 target
+                k = int(rng.integers(1, min(4, (cells - 1) // 2) + 1))
+                where = rng.permutation(cells)[:1 + 2 * k]
+                row[where] = [2] + [3] * k + [4] * k
+            else:  # zelda tiles: 0 empty 1 solid 2 player 3 key 4 door 5.. enemies
+                ne = int(rng.integers(0, min(4, cells - 3) + 1))
+                where = rng.permutation(cells)[:3 + ne]
+                row[where] = [2, 3, 4] + [int(rng.integers(5, 8)) for _ in range(ne)]
+            flat[i] = row
+        g = flat.reshape((m,) + tuple(shape))
+    return g
+
+
 def run_case(case, seed, verbose=False):
     import torch
     import pcgrl_oracle as po  # (checker)
@@ -96,13 +139,14 @@ def run_case(case, seed, verbose=False):
     problem, rep, shape, n, T = case["problem"], case["rep"], tuple(case["shape"]), case["n_envs"], case["steps"]
     kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items()}
     controls = kw.get("controls")
+    auto = bool(case.get("auto_reset", True))
     seeds = seed + np.arange(n)
     ekw = dict(kw)
     if controls:
         ekw["reward_dtype"] = torch.float64
 
     def make_engine():
-        return VecPcgrlEnv(problem, rep, shape, n, seeds=seeds, auto_reset=True, **ekw)
+        return VecPcgrlEnv(problem, rep, shape, n, seeds=seeds, auto_reset=auto, **ekw)
 
     try:
         env = make_engine()
@@ -170,13 +214,16 @@ def run_case(case, seed, verbose=False):
     mixed = case.get("mode") == "mixed"
     t = 0
     trace = case.setdefault("_trace", [])
+    cur_static = None
     while t < T:
         if controls and rng.random() < 0.05:
             queue()
         ev = "step"
         if mixed:
-            ev = str(rng.choice(["step", "rollout", "update_refresh", "update_step", "swap", "masked_reset", "inject", "observe"],
-                                p=[0.3, 0.25, 0.08, 0.08, 0.08, 0.08, 0.08, 0.05]))
+            ev = str(rng.choice(["step", "rollout", "update_refresh", "update_step", "swap", "masked_reset", "inject", "observe",
+                                 "sfg", "set_static"], p=[0.28, 0.22, 0.08, 0.08, 0.07, 0.08, 0.09, 0.03, 0.04, 0.03]))
+            if ev == "set_static" and not env.static_tiles:
+                ev = "step"
         what = f"@ {t} ({ev})"
         trace.append(f"{t}:{ev}")
         if ev == "step":
@@ -185,7 +232,7 @@ def run_case(case, seed, verbose=False):
                 a = draw_actions(t)
                 obs, rew, done, _, info = env.step(a.to(env.device))
                 want = t % full_every == 0 or t >= T - 1
-                oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=want)
+                oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=auto, want_obs=want)
                 if not check_stats(info["stats"].cpu().numpy(), ostats, odone, what):
                     return -2
                 assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward {what}"
@@ -203,7 +250,7 @@ def run_case(case, seed, verbose=False):
             rew, done, stats = rew.cpu().numpy().astype(np.float64), done.cpu().numpy(), stats.cpu().numpy()
             obs = None if obs is None else obs.cpu().numpy()
             for k in range(K):
-                oobs, orew, odone, ostats = orc.step(a[k].numpy(), auto_reset=True, want_obs=True)
+                oobs, orew, odone, ostats = orc.step(a[k].numpy(), auto_reset=auto, want_obs=True)
                 if not check_stats(stats[k], ostats, odone, f"{what} step {k}/{K}"):
                     return -2
                 assert np.max(np.abs(rew[k] - orew)) <= tol, f"reward {what} step {k}/{K}"
@@ -226,6 +273,8 @@ def run_case(case, seed, verbose=False):
         elif ev == "swap":  # checkpoint into a fresh engine and go on with that one
             sd = env.state_dict()
             env2 = make_engine()
+            if cur_static is not None:  # (host-side settings are the caller's to carry over, like the constructor's)
+                env2.set_static(static_prob=cur_static[0], n_static_walls=cur_static[1])
             env2.load_state_dict(sd)
             env.check_errors()
             env.close()
@@ -242,15 +291,36 @@ def run_case(case, seed, verbose=False):
             t += 1
         elif ev == "inject":
             mask = (rng.random(n) < rng.random()).astype(np.uint8)
-            grids = rng.integers(0, n_tiles, size=(n,) + shape, dtype=np.uint8)
-            if rng.random() < 0.5:  # sparse maps: long paths, playable levels
-                grids = np.where(rng.random((n,) + shape) < 0.8, np.uint8(0 if problem != "sokoban" else 0), grids).astype(np.uint8)
+            grids = random_grids(rng, problem, n, shape)
             pos = np.stack([rng.integers(0, s, size=n) for s in shape], axis=1).astype(np.int32)
             obs, _ = env.reset(mask=mask, init_grids=grids, init_pos=pos)
             assert np.array_equal(obs.cpu().numpy(), orc.reset(mask=mask, init_grids=grids, init_pos=pos)), f"obs {what}"
             if not check_stats(env.get_state().stats.cpu().numpy(), orc.get_state()["stats"], None, what):
                 return -2
             check_state(what)
+            t += 1
+        elif ev == "sfg":  # pcgrl_stats_for_grids: any batch size, its own scratch engine
+            m = int(rng.integers(1, 300))
+            grids = random_grids(rng, problem, m, shape)
+            got = env.stats_for_grids(torch.as_tensor(grids).to(env.device)).cpu().numpy()
+            want_s = po.stats_for_grids(problem, grids, solver_power=kw.get("solver_power", 10000))
+            if not np.array_equal(got, want_s):
+                bad = np.nonzero((got != want_s).any(axis=1))[0]
+                if problem == "sokoban":
+                    try:
+                        env.check_errors()
+                    except NotImplementedError as ex:
+                        if "solver" in str(ex):
+                            return -2
+                        raise
+                raise AssertionError(f"stats_for_grids {what}: {len(bad)} of {m} grids, first {int(bad[0])}: got "
+                                     f"{got[bad[0]].tolist()} want {want_s[bad[0]].tolist()}\n{grids[bad[0]]}")
+            t += 1
+        elif ev == "set_static":  # takes effect at the next reset
+            sp, nw = float(rng.choice([0.0, 0.2, 0.6])), int(rng.integers(0, 4)) if min(shape) >= 3 else 0
+            cur_static = (sp, nw)
+            env.set_static(static_prob=sp, n_static_walls=nw)
+            orc.set_static(static_prob=sp, n_static_walls=nw)
             t += 1
         else:
             assert np.array_equal(env.observe().cpu().numpy(), orc.observe()), f"obs {what}"
