@@ -53,6 +53,8 @@ def _draw_case(rng):
         big = rng.random() < 0.25
         hi = 16 if big else 8
         shape = [int(rng.integers(1, hi + 1)) for _ in range(3)]
+        if rng.random() < 0.2:  # BASELINE's shape: the compile-time 7^3 / 14^3 kernels
+            shape = [7, 7, 7]
         case["shape"] = shape
         if rng.random() < 0.4:  # any window whose volume is a multiple of 4
             ow = [int(rng.integers(1, 2 * s + 3)) for s in shape]
@@ -79,9 +81,12 @@ def _draw_case(rng):
         shape = [int(rng.integers(1, (62 if problem == "sokoban" else 64) + 1)), int(rng.integers(1, wmax + 1))]
     else:
         shape = [int(rng.integers(1, 25)), int(rng.integers(1, min(wmax, 34) + 1))]
+    headline = rng.random() < 0.2  # BASELINE's 16 x 16 maps with the default window: the compile-time (FAST) kernels
+    if headline:
+        shape = [16, 16]
     case["shape"] = shape
     H, W = shape
-    if rep != "wide" and rng.random() < 0.5:
+    if rep != "wide" and rng.random() < 0.5 and not headline:
         kw["obs_window"] = [int(rng.integers(1, 2 * H + 4)), int(rng.integers(1, 2 * W + 4))]
     if rng.random() < 0.5:
         kw["change_percentage"] = float(rng.choice([0.05, 0.2, 0.5, 1.0]))
@@ -99,6 +104,8 @@ def _draw_case(rng):
         kw["solver_power"] = int(rng.choice([50, 500, 3000, 10000]))
     cells = H * W
     case["n_envs"] = int(rng.integers(1, max(2, min(600, 60000 // cells))))
+    if rng.random() < 0.05:  # several workgroups per CU, partial last workgroup
+        case["n_envs"] = int(rng.integers(600, max(601, min(9000, 600000 // cells))))
     case["steps"] = int(rng.integers(30, 200))
     case["bias"] = bool(problem == "binary" and rng.random() < 0.2)
     case["mode"] = "mixed" if rng.random() < 0.5 else "step"
@@ -221,7 +228,7 @@ def run_case(case, seed, verbose=False):
         ev = "step"
         if mixed:
             ev = str(rng.choice(["step", "rollout", "update_refresh", "update_step", "swap", "masked_reset", "inject", "observe",
-                                 "sfg", "set_static"], p=[0.28, 0.22, 0.08, 0.08, 0.07, 0.08, 0.09, 0.03, 0.04, 0.03]))
+                                 "sfg", "set_static", "graph"], p=[0.26, 0.21, 0.08, 0.08, 0.07, 0.08, 0.09, 0.03, 0.04, 0.03, 0.03]))
             if ev == "set_static" and not env.static_tiles:
                 ev = "step"
         what = f"@ {t} ({ev})"
@@ -299,6 +306,31 @@ def run_case(case, seed, verbose=False):
                 return -2
             check_state(what)
             t += 1
+        elif ev == "graph":  # pcgrl_step captured in a HIP graph (static action buffer), replayed with fresh actions
+            static_a = draw_actions(t).to(env.device)
+            env.step(static_a)  # (eager warm-up; the oracle follows)
+            oobs, orew, odone, ostats = orc.step(static_a.cpu().numpy(), auto_reset=auto, want_obs=False)
+            graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    obs, rew, done, _, info = env.step(static_a)
+            torch.cuda.current_stream().wait_stream(side)
+            R = int(rng.integers(2, 12))
+            for r in range(R):
+                a = draw_actions(t + r)
+                static_a.copy_(a)
+                graph.replay()
+                oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=auto, want_obs=True)
+                if not check_stats(info["stats"].cpu().numpy(), ostats, odone, f"{what} replay {r}/{R}"):
+                    return -2
+                assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward {what} replay {r}/{R}"
+                assert np.array_equal(done.cpu().numpy(), odone), f"done {what} replay {r}/{R}"
+                assert np.array_equal(obs.cpu().numpy(), oobs), f"obs {what} replay {r}/{R}"
+            check_ctrl(what)
+            check_state(what)
+            del graph
+            t += R + 1
         elif ev == "sfg":  # pcgrl_stats_for_grids: any batch size, its own scratch engine
             m = int(rng.integers(1, 300))
             grids = random_grids(rng, problem, m, shape)
@@ -329,7 +361,12 @@ def run_case(case, seed, verbose=False):
     assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]), "episode counts"
     assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"]), "final stats"
     assert np.array_equal(le.ep_len.cpu().numpy(), ole["ep_len"]), "episode lengths"
-    env.check_errors()
+    try:
+        env.check_errors()
+    except NotImplementedError as ex:  # > 128 crates in a level whose statistics happened to agree anyway
+        if problem == "sokoban" and "solver" in str(ex):
+            return -2
+        raise
     return int(ole["n_episodes"].sum())
 
 
