@@ -41,6 +41,8 @@ def draw_case(rng):
     if rng.random() < 0.25:
         kw["max_board_scans"] = int(rng.integers(1, 4))
     case["auto_reset"] = bool(rng.random() < 0.8)
+    if rng.random() < 0.1:
+        case["mode"] = "adapter"
     return case
 
 
@@ -370,6 +372,89 @@ def run_case(case, seed, verbose=False):
     return int(ole["n_episodes"].sum())
 
 
+def run_adapter_case(case, seed):
+    """the same configuration through PcgrlVectorEnv (ray.rllib VectorEnv call shape): vector_reset / vector_step / reset_at
+    per finished env, per-env targets through the sub-env handles, against the oracle without auto-reset"""
+    import pcgrl_oracle as po  # (checker)
+    from control_pcgrl_amd import PcgrlVectorEnv
+
+    problem, rep, shape, T = case["problem"], case["rep"], tuple(case["shape"]), min(case["steps"], 80)
+    n = min(case["n_envs"], 48)
+    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items() if k != "solver_power"}
+    controls = kw.get("controls") or []
+    seeds = seed + np.arange(n)
+    cfg = {"task": {"problem": problem, "map_shape": list(shape), "obs_window": kw.get("obs_window"), "weights": kw.get("weights")},
+           "representation": rep, "change_percentage": kw.get("change_percentage"), "max_board_scans": kw.get("max_board_scans", 3),
+           "controls": controls or None, "act_window": kw.get("act_window"), "static_prob": kw.get("static_prob"),
+           "n_static_walls": kw.get("n_static_walls")}
+    try:
+        env = PcgrlVectorEnv(cfg, num_envs=n, seeds=[int(x) for x in seeds])
+    except ValueError:
+        try:
+            po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, **kw)
+        except ValueError:
+            return -1
+        raise AssertionError("the adapter refuses what the oracle accepts")
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, **kw)
+    rng = np.random.default_rng(seed)
+    K2 = 2 * len(controls)
+    bounds = po.cond_bounds(problem, shape) if controls else None
+    subs = env.get_sub_environments()
+    keys = STAT_KEYS[problem]
+
+    def new_targets(envs):
+        for i in envs:
+            trg = {k: float(rng.random() * (bounds[k][1] - bounds[k][0]) + bounds[k][0]) for k in controls}
+            subs[int(i)].set_trgs(trg)
+            m = np.zeros(n, np.uint8)
+            m[int(i)] = 1
+            orc.queue_targets(trg, mask=m)
+
+    def check_obs(o, want, ctrl, what):
+        assert np.array_equal(np.asarray(o)[..., K2:].astype(np.uint8), want), f"obs {what}"
+        if K2:
+            planes = np.asarray(o)[..., :K2].reshape(-1, K2)
+            assert np.all(planes == planes[0]) and np.allclose(planes[0], ctrl, rtol=1e-6, atol=1e-7), f"control planes {what}"
+
+    if controls:
+        new_targets(range(n))
+    obs, infos = env.vector_reset()
+    oobs = orc.reset()
+    octrl = orc.ctrl_obs() if controls else [None] * n
+    for i in range(n):
+        check_obs(obs[i], oobs[i], octrl[i], f"after vector_reset env {i}")
+    entries = env.vec.action_entries
+    hi = env.vec.spec.n_tiles if entries > 1 else env.vec.num_actions
+    for t in range(T):
+        a = rng.integers(0, hi, size=(n, entries) if entries > 1 else (n,))
+        obs, rew, term, trunc, infos = env.vector_step([x for x in a] if entries > 1 else a.tolist())
+        oobs, orew, odone, ostats = orc.step(a, auto_reset=False, want_obs=True)
+        octrl = orc.ctrl_obs() if controls else [None] * n
+        assert term == odone.tolist() and trunc == term, f"done @ {t}"
+        assert np.max(np.abs(np.asarray(rew, np.float64) - orew)) <= 1e-5 * max(1.0, float(np.max(np.abs(orew)))), f"reward @ {t}"
+        for i in range(n):
+            check_obs(obs[i], oobs[i], octrl[i], f"@ {t} env {i}")
+        for i in rng.integers(0, n, size=3):
+            info = infos[int(i)]
+            assert [info[k] for k in keys] == ostats[int(i)].tolist(), f"info @ {t} env {i}"
+            assert subs[int(i)].unwrapped._rep_stats == dict(zip(keys, ostats[int(i)].tolist())), f"sub-env stats @ {t}"
+        fin = np.nonzero(odone)[0]
+        if len(fin):
+            if controls:
+                new_targets(fin)
+            m = np.zeros(n, np.uint8)
+            m[fin] = 1
+            oobs = orc.reset(mask=m)
+            octrl = orc.ctrl_obs() if controls else [None] * n
+            for i in rng.permutation(fin):
+                o, info = env.reset_at(int(i))
+                assert info == {}
+                check_obs(o, oobs[int(i)], octrl[int(i)], f"reset_at({i}) @ {t}")
+    env.vec.check_errors()
+    env.close()
+    return int(orc.last_episode()["n_episodes"].sum())
+
+
 def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
     rng = np.random.default_rng(seed)
     t0 = time.time()
@@ -380,7 +465,7 @@ def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
         line = json.dumps(dict(case, seed=cs))
         t1 = time.time()
         try:
-            eps = run_case(case, cs)
+            eps = run_adapter_case(case, cs) if case.get("mode") == "adapter" else run_case(case, cs)
             case.pop("_trace", None)
             if verbose:
                 print(f"ok   {i:4d} {time.time() - t1:6.1f}s eps={eps:5d} {line}", flush=True)
@@ -419,7 +504,7 @@ if __name__ == "__main__":
         c = json.loads(a.case)
         s = c.pop("seed")
         try:
-            print("episodes:", run_case(c, s, verbose=True))
+            print("episodes:", run_adapter_case(c, s) if c.get("mode") == "adapter" else run_case(c, s, verbose=True))
         finally:
             print("events:", " ".join(c.get("_trace", [])))
         sys.exit(0)
