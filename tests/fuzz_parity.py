@@ -43,6 +43,8 @@ def draw_case(rng):
     case["auto_reset"] = bool(rng.random() < 0.8)
     if rng.random() < 0.1:
         case["mode"] = "adapter"
+    r = rng.random()
+    case["seed_kind"] = "same" if r < 0.05 else ("huge" if r < 0.1 else "range")
     return case
 
 
@@ -150,6 +152,10 @@ def run_case(case, seed, verbose=False):
     controls = kw.get("controls")
     auto = bool(case.get("auto_reset", True))
     seeds = seed + np.arange(n)
+    if case.get("seed_kind") == "same":
+        seeds = np.full(n, seed)
+    elif case.get("seed_kind") == "huge":
+        seeds = (np.uint64(0xFFFFFFFFFFFFFF00) - np.arange(n, dtype=np.uint64) * np.uint64(0x123456789ABCD)).astype(np.uint64)
     ekw = dict(kw)
     if controls:
         ekw["reward_dtype"] = torch.float64
@@ -214,6 +220,19 @@ def run_case(case, seed, verbose=False):
         if controls:
             assert np.allclose(env.ctrl_obs.cpu().numpy(), orc.ctrl_obs(), rtol=1e-6, atol=1e-7), f"ctrl_obs {what}"
 
+    totals = np.zeros(3 + len(STAT_KEYS[problem]))
+
+    def orc_step(a, want_obs):
+        r = orc.step(a, auto_reset=auto, want_obs=want_obs)
+        d = r[2]
+        if auto and d.any():  # what pcgrl_reduce_episodes sums: the episodes that ended by auto-reset
+            le = orc.last_episode()
+            totals[0] += le["ep_return"][d].sum()
+            totals[1] += le["ep_len"][d].sum()
+            totals[2] += d.sum()
+            totals[3:] += le["final_stats"][d].sum(0)
+        return r
+
     if controls:
         queue()
     obs, info = env.reset()
@@ -241,7 +260,7 @@ def run_case(case, seed, verbose=False):
                 a = draw_actions(t)
                 obs, rew, done, _, info = env.step(a.to(env.device))
                 want = t % full_every == 0 or t >= T - 1
-                oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=auto, want_obs=want)
+                oobs, orew, odone, ostats = orc_step(a.numpy(), want)
                 if not check_stats(info["stats"].cpu().numpy(), ostats, odone, what):
                     return -2
                 assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward {what}"
@@ -252,14 +271,14 @@ def run_case(case, seed, verbose=False):
                     check_state(what)
                 t += 1
         elif ev == "rollout":
-            K = int(rng.integers(2, 13))
+            K = int(rng.integers(2, 13)) if rng.random() < 0.85 else int(rng.integers(13, 41))
             want = str(rng.choice(["all", "last", "none"]))
             a = draw_actions(t, lead=(K,))
             obs, rew, done, stats = env.rollout(a.to(env.device), want_obs=want)
             rew, done, stats = rew.cpu().numpy().astype(np.float64), done.cpu().numpy(), stats.cpu().numpy()
             obs = None if obs is None else obs.cpu().numpy()
             for k in range(K):
-                oobs, orew, odone, ostats = orc.step(a[k].numpy(), auto_reset=auto, want_obs=True)
+                oobs, orew, odone, ostats = orc_step(a[k].numpy(), True)
                 if not check_stats(stats[k], ostats, odone, f"{what} step {k}/{K}"):
                     return -2
                 assert np.max(np.abs(rew[k] - orew)) <= tol, f"reward {what} step {k}/{K}"
@@ -311,7 +330,7 @@ def run_case(case, seed, verbose=False):
         elif ev == "graph":  # pcgrl_step captured in a HIP graph (static action buffer), replayed with fresh actions
             static_a = draw_actions(t).to(env.device)
             env.step(static_a)  # (eager warm-up; the oracle follows)
-            oobs, orew, odone, ostats = orc.step(static_a.cpu().numpy(), auto_reset=auto, want_obs=False)
+            oobs, orew, odone, ostats = orc_step(static_a.cpu().numpy(), False)
             graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -323,7 +342,7 @@ def run_case(case, seed, verbose=False):
                 a = draw_actions(t + r)
                 static_a.copy_(a)
                 graph.replay()
-                oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=auto, want_obs=True)
+                oobs, orew, odone, ostats = orc_step(a.numpy(), True)
                 if not check_stats(info["stats"].cpu().numpy(), ostats, odone, f"{what} replay {r}/{R}"):
                     return -2
                 assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= tol, f"reward {what} replay {r}/{R}"
@@ -363,6 +382,9 @@ def run_case(case, seed, verbose=False):
     assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]), "episode counts"
     assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"]), "final stats"
     assert np.array_equal(le.ep_len.cpu().numpy(), ole["ep_len"]), "episode lengths"
+    if auto:
+        red = env.reduce_episodes().cpu().numpy()
+        assert np.allclose(red, totals, rtol=1e-12, atol=1e-6), f"reduce_episodes {red.tolist()} vs {totals.tolist()}"
     try:
         env.check_errors()
     except NotImplementedError as ex:  # > 128 crates in a level whose statistics happened to agree anyway
