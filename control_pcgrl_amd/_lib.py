@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(CSRC, "libpcgrl_amd.so")
 # translation units (compiled in parallel, see csrc/pcgrl_dispatch.h) and the headers they depend on
 UNITS = ["pcgrl_engine.hip", "pcgrl_k_binary32.hip", "pcgrl_k_binary64.hip", "pcgrl_k_zelda32.hip", "pcgrl_k_zelda64.hip",
          "pcgrl_k_sokoban32_8.hip", "pcgrl_k_sokoban32_16.hip", "pcgrl_k_sokoban32_32.hip",
-         "pcgrl_k_sokoban32_64.hip", "pcgrl_k_3d.hip"]
+         "pcgrl_k_sokoban32_64.hip", "pcgrl_k_sokoban64_32.hip", "pcgrl_k_sokoban64_64.hip", "pcgrl_k_3d.hip"]
 HEADERS = ["pcgrl_kernels2d.h", "pcgrl_kernels3d.h", "pcgrl_sokoban.h", "pcgrl_common.h", "pcgrl_dispatch.h"]
 SOURCES = UNITS + HEADERS
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pcgrl_amd.h")

@@ -30,6 +30,12 @@ inline hipError_t launch_sokoban32(KernelId id, int lpe, const Params &p, size_t
     default: return launch_sokoban32_64(id, p, lds, s);
   }
 }
+// maps wider than 32: 64-bit row masks, 32 or 64 lanes per env
+hipError_t launch_sokoban64_32(KernelId id, const Params &p, size_t lds, hipStream_t s);
+hipError_t launch_sokoban64_64(KernelId id, const Params &p, size_t lds, hipStream_t s);
+inline hipError_t launch_sokoban64(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s) {
+  return lpe == 32 ? launch_sokoban64_32(id, p, lds, s) : launch_sokoban64_64(id, p, lds, s);
+}
 hipError_t launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s);
 
 }  // namespace pcgrl

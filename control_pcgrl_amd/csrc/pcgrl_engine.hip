@@ -175,8 +175,8 @@ static int validate(const pcgrl_config &c, int &lpe, int64_t &obs_bytes, int &ob
     return fail(PCGRL_EINVAL, "static_prob / n_static_walls need static_tiles = 1");
   }
   if (H < 1 || W < 1 || H > 64 || W > 64) return fail(PCGRL_EUNSUPPORTED, "map_shape: need 1 <= H <= 64, 1 <= W <= 64");
-  if (c.problem == PCGRL_PROB_SOKOBAN && (W > 32 || H + 2 > SK_MAXDIM))
-    return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver supports W <= 32, H <= 62");
+  if (c.problem == PCGRL_PROB_SOKOBAN && (W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM))
+    return fail(PCGRL_EUNSUPPORTED, "sokoban: the device solver's level (map + border) is at most 64 x 64: need H, W <= 62");
   if (c.problem == PCGRL_PROB_SOKOBAN && (c.solver_power < 1 || c.solver_power > SK_MAX_POWER))
     return fail(PCGRL_EUNSUPPORTED, "sokoban: solver_power must be in [1, " + std::to_string(SK_MAX_POWER) +
                                         "] (the device solver's visited table and node ids are sized for that)");
@@ -237,7 +237,7 @@ static hipError_t launch(KernelId id, int lpe, const Params &p, size_t lds, hipS
     case PCGRL_PROB_MC3DMAZE: return launch_3d(id, p, cpl, s);
     case PCGRL_PROB_BINARY: return wide64 ? launch_binary64(id, lpe, p, lds, s) : launch_binary32(id, lpe, p, lds, s);
     case PCGRL_PROB_ZELDA: return wide64 ? launch_zelda64(id, lpe, p, lds, s) : launch_zelda32(id, lpe, p, lds, s);
-    default: return launch_sokoban32(id, lpe, p, lds, s);  // validate() rejects sokoban maps wider than 32
+    default: return wide64 ? launch_sokoban64(id, lpe, p, lds, s) : launch_sokoban32(id, lpe, p, lds, s);
   }
 }
 
@@ -429,7 +429,9 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
   if (h->spread_left > 0) {
     h->spread_left--;
     p.spread = 1;
-    p.sk_helpers = 3;  // ... and three more wavefronts per env run the A* stages next to the BFS stage
+    // ... and three more wavefronts per env run the A* stages next to the BFS stage, when their heaps fit the CU's 160 KiB
+    // of LDS next to the observation staging rows (they do for every window up to about 2 x 62 cells per row)
+    p.sk_helpers = h->lds_bytes + 3 * (size_t)SK_HELPER_LDS + 4096 <= 160 * 1024 ? 3 : 0;
   }
 }
 

@@ -580,9 +580,9 @@ __device__ __attribute__((always_inline)) inline void touch_kernarg(const Params
                "s"(kw[208 < sizeof(Params) / 4 ? 208 : 0]));
 }
 
-template <int LPE>
-__device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid, uint32_t player,
-                              uint32_t crate, uint32_t target, int &dist_win, int &sol_len);
+template <int LPE, typename M>
+__device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player, M crate, M target,
+                              int &dist_win, int &sol_len);
 // helper wavefronts of the solver (pcgrl_sokoban.h): kernels launched with Params::sk_helpers carry three of them per
 // workgroup, behind the simulate / observe waves
 __device__ inline void sokoban_helper(const Params &p, int k, uint32_t *lds_heap);
@@ -716,8 +716,7 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     int sol_len = 0;
     bool need = active && n_player == 1 && n_crate == n_target && n_crate > 0 && regions == 1;
     if (__ballot(need) != 0) {
-      if constexpr (sizeof(M) == 4) sokoban_solve(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
-      else if (need && g.row == 0) atomicOr(p.err, 2);  // the solver supports W <= 32
+      sokoban_solve<LPE, M>(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
     }
     st[0] = n_player;
     st[1] = n_crate;

@@ -64,7 +64,7 @@ namespace pcgrl {
 #endif
 
 constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
-constexpr int SK_MAXDIM = 64;    // bordered level height H+2 (one lane per row, one mask bit per row); W+2 <= 34: 32-bit map rows
+constexpr int SK_MAXDIM = 64;    // bordered level side (H+2, W+2 <= 64: one lane / one mask bit per row and per column)
 constexpr int SK_VCAP = 1 << 15; // visited table entries (>= 2 x iterations per stage), 16 bytes each, in groups of 8
 constexpr int SK_VGROUPS = SK_VCAP / 8;  // a group = one 128-byte line: a probe reads it with one load (lane l < 8: entry l)
 constexpr size_t SK_VIS_BYTES = 16 * (size_t)SK_VCAP;
@@ -831,9 +831,9 @@ __device__ inline void sokoban_helpers_release() {
 // Called by every lane of the wave in uniform control flow; `need` is uniform per group.  Groups that need the
 // solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
 // and never waits for a slot while holding one.
-template <int LPE>
-__device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, uint32_t solid,
-                                                        uint32_t player, uint32_t crate, uint32_t target, int &dist_win, int &sol_len) {
+template <int LPE, typename M>
+__device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player,
+                                                        M crate, M target, int &dist_win, int &sol_len) {
   (void)env;
   const SokoPool &pool = *(const SokoPool *)p.soko;
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
@@ -869,7 +869,16 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
     if (g.lane == 0 && p.solver_seen != nullptr) __hip_atomic_fetch_add(p.solver_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // the level: the group's rows are broadcast to the wave; level coords = map coords + 1 (sokoban_prob.py:107-124:
     // one-tile solid border around the map); crates / targets are listed in row-major order (engine.py:170-188)
-    const uint64_t full = (1ull << (W + 2)) - 1ull;
+    const uint64_t full = W + 2 >= 64 ? ~0ull : (1ull << (W + 2)) - 1ull;
+    auto row_of = [&](M v, int src) -> uint64_t {  // lane src's row mask, broadcast
+      if constexpr (sizeof(M) == 4) {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, src);
+      } else {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+      }
+    };
     int px = 0, py = 0, ncr = 0, ntg = 0;
     if (g.lane == 0) {
       s_level.w = W + 2;
@@ -881,28 +890,27 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
     }
     for (int r = 0; r < H; r++) {
       const int src = gi * LPE + r;
-      const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)solid, src), pl = (uint32_t)__builtin_amdgcn_readlane((int)player, src);
-      const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crate, src), tg = (uint32_t)__builtin_amdgcn_readlane((int)target, src);
+      const uint64_t sm = row_of(solid, src), pl = row_of(player, src), cr = row_of(crate, src), tg = row_of(target, src);
       if (g.lane == 0) {
-        s_level.solid[r + 1] = ((uint64_t)sm << 1) | 1ull | (1ull << (W + 1));
-        s_level.tgt[r + 1] = (uint64_t)tg << 1;
+        s_level.solid[r + 1] = (sm << 1) | 1ull | (1ull << (W + 1));
+        s_level.tgt[r + 1] = tg << 1;
       }
       if (pl) {
-        px = __builtin_ctz(pl) + 1;
+        px = __builtin_ctzll(pl) + 1;
         py = r + 1;
       }
-      // lane j (< 32) owns bit j of the row: list entry = count so far + rank of the bit
-      const uint32_t below = g.lane < 32 ? ((1u << g.lane) - 1u) : 0u;
-      if (g.lane < 32 && ((cr >> g.lane) & 1u)) {
-        const int k = ncr + __popc(cr & below);
+      // lane j owns bit j of the row (W <= 62): list entry = count so far + rank of the bit
+      const uint64_t below = (1ull << g.lane) - 1ull;
+      if ((cr >> g.lane) & 1ull) {
+        const int k = ncr + __popcll(cr & below);
         if (k < SK_MAXC) s_level.root[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
       }
-      if (g.lane < 32 && ((tg >> g.lane) & 1u)) {
-        const int k = ntg + __popc(tg & below);
+      if ((tg >> g.lane) & 1ull) {
+        const int k = ntg + __popcll(tg & below);
         if (k < SK_MAXC) s_level.target[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
       }
-      ncr += __popc(cr);
-      ntg += __popc(tg);
+      ncr += __popcll(cr);
+      ntg += __popcll(tg);
     }
     int dw = dist_win, sl = sol_len;
     if (ncr > SK_MAXC || ntg > SK_MAXC || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {

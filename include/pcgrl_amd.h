@@ -79,7 +79,7 @@ typedef struct {
   int32_t problem;        /* PCGRL_PROB_* */
   int32_t representation; /* PCGRL_REP_*  */
   int32_t ndim;           /* 2 or 3 */
-  int32_t dims[3];        /* cfg.task.map_shape: 2-D {H, W, 1}, H, W <= 64 (sokoban: W <= 32, H <= 62); 3-D {Z, Y, X}, each <= 16
+  int32_t dims[3];        /* cfg.task.map_shape: 2-D {H, W, 1}, H, W <= 64 (sokoban: H, W <= 62); 3-D {Z, Y, X}, each <= 16
                            * (BASELINE's 7 x 7 x 7, the reference's stock 15 x 15 x 15: configs/config.py:153-157) */
   int32_t obs_window[3];  /* cfg.task.obs_window (wide: must equal map_shape) */
   int32_t max_iterations; /* prod(map_shape) * cfg.max_board_scans + 1     (envs/pcgrl_env.py:241) */

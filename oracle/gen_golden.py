@@ -666,6 +666,8 @@ SHAPE_CONFIGS = {
     "sokoban_narrow_20x20": ("sokoban", "narrow", (20, 20), None, 80),
     "sokoban_narrow_40x30": ("sokoban", "narrow", (40, 30), None, 80),
     "sokoban_wide_8x8": ("sokoban", "wide", (8, 8), None, 50),
+    "sokoban_narrow_24x40": ("sokoban", "narrow", (24, 40), None, 80),   # wider than 32: 64-bit row masks (round 3)
+    "sokoban_turtle_36x36": ("sokoban", "turtle", (36, 36), None, 60),
 }
 
 
@@ -1010,6 +1012,44 @@ def gen_stats_sokoban_solver_shapes():
               int((stats[:, 5] > 0).sum()), "failed with dist", int(((stats[:, 4] > 0) & (stats[:, 4] != shape[0] * shape[1] * (shape[0] + shape[1]))).sum()), flush=True)
     np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver_shapes.npz"), stat_keys=np.array(STAT_KEYS["sokoban"]), **out)
 
+
+def gen_stats_sokoban_solver_wide():
+    """the same kind of levels on maps wider than 32 cells (the engine's 64-bit row-mask kernels): 20 x 40, 48 x 33, 62 x 62"""
+    rng = np.random.default_rng(34)
+    E, S, P, C, T = range(5)
+    out = {}
+    for shape, n in (((20, 40), 7), ((48, 33), 6), ((62, 62), 6)):
+        core = _problem("sokoban", shape)
+        grids = []
+        while len(grids) < n:
+            g = np.full(shape, S, np.uint8)
+            h, w = int(rng.integers(3, 7)), int(rng.integers(3, 7))
+            # rooms that straddle column 32 or sit in the right half now and then
+            y0 = int(rng.integers(0, shape[0] - h + 1))
+            x0 = int(rng.integers(max(0, 30 - w), shape[1] - w + 1)) if rng.random() < 0.7 else int(rng.integers(0, shape[1] - w + 1))
+            g[y0:y0 + h, x0:x0 + w] = E
+            for _ in range(int(rng.integers(0, 3))):
+                g[y0 + int(rng.integers(h)), x0 + int(rng.integers(w))] = S
+            free = np.argwhere(g == E)
+            k = int(rng.integers(1, 4))
+            if len(free) < 1 + 2 * k:
+                continue
+            sel = free[rng.permutation(len(free))[: 1 + 2 * k]]
+            for (y, x), t in zip(sel, [P] + [C] * k + [T] * k):
+                g[y, x] = t
+            grids.append(g)
+        grids = np.array(grids, np.uint8)
+        stats = np.array([_get_stats(core, "sokoban", g) for g in grids], np.int32)
+        key = f"{shape[0]}x{shape[1]}"
+        out["grids_" + key], out["stats_" + key] = grids, stats
+        print("stats_sokoban_solver_wide", key, grids.shape, "one-region", int((stats[:, 3] == 1).sum()), "solved",
+              int((stats[:, 5] > 0).sum()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver_wide.npz"), stat_keys=np.array(STAT_KEYS["sokoban"]), **out)
+
+
+if __name__ == "__main__" and "sokowide" in sys.argv[1:]:
+    gen_stats_sokoban_solver_wide()
+    sys.exit(0)
 
 if __name__ == "__main__" and "corners" in sys.argv[1:]:
     for i, name in enumerate(EXT_SHAPE_CONFIGS):

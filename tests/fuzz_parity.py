@@ -76,7 +76,7 @@ def _draw_case(rng):
         return case
     rep = str(rng.choice(["narrow", "turtle", "wide"], p=[0.45, 0.35, 0.2]))
     case["rep"] = rep
-    wmax = 32 if problem == "sokoban" else 64
+    wmax = 62 if problem == "sokoban" else 64
     r = rng.random()
     if rep == "wide":  # square maps only; obs_window == map_shape
         s = int(rng.integers(1, (wmax if r < 0.2 else 20) + 1))

@@ -353,7 +353,7 @@ def test_degenerate_map_shapes_vs_oracle(shape, ow):
     _rollout_vs_oracle("binary", "narrow", shape, 19, 3 * shape[0] * shape[1] + 30, full_every=3, obs_window=ow)
     if shape[0] * shape[1] >= 9:  # smaller maps have empty zelda target ranges (the reference fails on them too)
         _rollout_vs_oracle("zelda", "turtle", shape, 19, 60, full_every=3, obs_window=ow)
-    if shape[1] > 32 or shape[0] > 62:  # the device solver's level: 32-bit rows, at most 64 of them with the border
+    if shape[1] > 62 or shape[0] > 62:  # the device solver's level is at most 64 x 64 cells with its border
         with pytest.raises(NotImplementedError):
             _vec("sokoban", "narrow", shape, 4, obs_window=ow)
         return
@@ -1319,10 +1319,11 @@ def _solvable_rooms(n, seed, shape=(16, 16)):
     return g
 
 
-@pytest.mark.parametrize("shape", [(8, 8), (12, 20), (20, 20), (30, 30), (32, 32), (33, 17), (45, 6), (62, 32)])
+@pytest.mark.parametrize("shape", [(8, 8), (12, 20), (20, 20), (30, 30), (32, 32), (33, 17), (45, 6), (62, 32), (20, 40),
+                                   (6, 62), (48, 33), (62, 62)])
 def test_sokoban_solver_other_map_shapes_vs_oracle(shape):
     """the device solver with its helper wavefronts behind the lanes-per-env families it supports (8 / 16 / 32 / 64 lanes
-    per env: a bordered level is at most 64 rows of 34 cells):
+    per env, 32- / 64-bit row masks: a bordered level is at most 64 x 64):
     playable rooms inside maps off the 16x16 point, one level per workgroup (pcgrl_stats_for_grids)"""
     g = _solvable_rooms(96, 31 + shape[0], shape)
     want = po.stats_for_grids("sokoban", g, solver_power=2000)
@@ -1335,13 +1336,15 @@ def test_sokoban_solver_other_map_shapes_vs_oracle(shape):
 
 def test_golden_sokoban_solver_other_shapes_known_answers():
     """solver-firing levels on 8 x 8, 20 x 20 and 30 x 30 maps: the reference's SokobanCtrlProblem.get_stats answers"""
-    z = np.load(os.path.join(GOLDEN, "stats_sokoban_solver_shapes.npz"))
-    for key in ("8x8", "20x20", "30x30"):
-        grids = z["grids_" + key]
-        env = _vec("sokoban", "narrow", grids.shape[1:], 1, auto_reset=False)
-        got = env.stats_for_grids(torch.as_tensor(grids)).cpu().numpy()
-        assert np.array_equal(got, z["stats_" + key]), f"{key}: got {got.tolist()} want {z['stats_' + key].tolist()}"
-        env.check_errors()
+    for fname, keys in (("stats_sokoban_solver_shapes.npz", ("8x8", "20x20", "30x30")),
+                        ("stats_sokoban_solver_wide.npz", ("20x40", "48x33", "62x62"))):  # (wide: 64-bit row masks)
+        z = np.load(os.path.join(GOLDEN, fname))
+        for key in keys:
+            grids = z["grids_" + key]
+            env = _vec("sokoban", "narrow", grids.shape[1:], 1, auto_reset=False)
+            got = env.stats_for_grids(torch.as_tensor(grids)).cpu().numpy()
+            assert np.array_equal(got, z["stats_" + key]), f"{key}: got {got.tolist()} want {z['stats_' + key].tolist()}"
+            env.check_errors()
 
 
 def test_loss_integer_and_float64_forms_agree():

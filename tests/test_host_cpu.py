@@ -43,8 +43,8 @@ def test_create_rejects_bad_configs_without_gpu():
     cfg, _, _ = build_config("binary", "wide", (16, 16), obs_window=(32, 32))
     assert L.pcgrl_create(C.byref(cfg), 4, 0, C.byref(h)) == 1  # EINVAL: wide needs obs_window == map_shape
     assert b"obs_window" in L.pcgrl_last_error()
-    cfg, _, _ = build_config("sokoban", "narrow", (16, 48))
-    assert L.pcgrl_create(C.byref(cfg), 4, 0, C.byref(h)) == 2  # EUNSUPPORTED: the device solver's level rows are 32 bits wide
+    cfg, _, _ = build_config("sokoban", "narrow", (16, 63))
+    assert L.pcgrl_create(C.byref(cfg), 4, 0, C.byref(h)) == 2  # EUNSUPPORTED: the device solver's level is at most 64 x 64 with its border
     cfg, _, _ = build_config("minecraft_3D_maze", "narrow", (17, 7, 7))
     assert L.pcgrl_create(C.byref(cfg), 4, 0, C.byref(h)) == 2  # EUNSUPPORTED: 3-D maps up to 16 x 16 x 16
     with pytest.raises(ValueError):
