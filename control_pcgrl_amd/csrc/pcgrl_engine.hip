@@ -338,15 +338,25 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_episodes_kernel(Params p, 
 // lanes -> wave by an xor butterfly, waves in wave order)
 __global__ __launch_bounds__(1024) void reduce_episodes_small_kernel(Params p, double *out, int clear) {
   __shared__ double sh[16][RED_W];
+  const int cols = 3 + p.cfg.n_stats;
+  // The totals sit in the envs' second state line, which only episode ends touch: cold in HBM.  All of a thread's
+  // counters are requested before the first is looked at, so their latencies overlap (n_envs <= 16384: 16 per thread).
+  int64_t cnt[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int e = (int)threadIdx.x + 1024 * i;
+    cnt[i] = e < p.n_envs ? p.st[e].acc.n : 0;
+  }
   double ret = 0.0;
   int64_t v[RED_W - 1];
   for (int k = 0; k < RED_W - 1; k++) v[k] = 0;
-  for (int e = (int)threadIdx.x; e < p.n_envs; e += 1024) {
-    EpAcc *A = &p.st[e].acc;
-    if (A->n == 0) continue;  // nothing finished in this env since the last clearing call
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if (cnt[i] == 0) continue;  // nothing finished in this env since the last clearing call
+    EpAcc *A = &p.st[(int)threadIdx.x + 1024 * i].acc;
     ret += A->sum_return;
     v[0] += A->sum_len;
-    v[1] += A->n;
+    v[1] += cnt[i];
     for (int k = 0; k < PCGRL_MAX_STATS; k++) v[2 + k] += A->sum_stats[k];
     if (clear) {
       A->sum_return = 0.0;
@@ -358,12 +368,15 @@ __global__ __launch_bounds__(1024) void reduce_episodes_small_kernel(Params p, d
   double w[RED_W];
   w[0] = ret;
   for (int k = 1; k < RED_W; k++) w[k] = (double)v[k - 1];
-  for (int k = 0; k < RED_W; k++)
+#pragma unroll
+  for (int k = 0; k < RED_W; k++) {
+    if (k >= cols) break;  // (uniform: only the problem's own statistics are summed)
     for (int o = 32; o >= 1; o >>= 1) w[k] += __shfl_xor(w[k], o, 64);
+  }
   if ((threadIdx.x & 63) == 0)
     for (int k = 0; k < RED_W; k++) sh[threadIdx.x >> 6][k] = w[k];
   __syncthreads();
-  if (threadIdx.x < 3 + (unsigned)p.cfg.n_stats) {
+  if ((int)threadIdx.x < cols) {
     double s = 0.0;
     for (int i = 0; i < 16; i++) s += sh[i][threadIdx.x];
     out[threadIdx.x] = s;
