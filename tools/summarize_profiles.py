@@ -53,6 +53,7 @@ def summarize(w, stats_rows):
     if kt:
         rows = [r for r in csv.DictReader(open(kt)) if dom in r["Kernel_Name"]
                 and (is_m3_step(r["Kernel_Name"]) or dom == "step_kernel")]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # (the trace is not always written in time order)
         if len(rows) > 2:
             gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
             r0 = rows[0]
