@@ -811,6 +811,7 @@ __device__ inline void m3_helper(M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_
       __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_s_setprio(3);  // a job is on the simulate wave's critical path (the polling above runs at priority 0)
     if (rq != rseen) {  // the region count of the edited map (the tile bits in LDS are already those of the new map)
       rseen = rq;
       const int eq = __builtin_amdgcn_readfirstlane(m3_ld(&m.r_eq)), ez = __builtin_amdgcn_readfirstlane(m3_ld(&m.r_ez));
@@ -832,6 +833,7 @@ __device__ inline void m3_helper(M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         m3_st(&m.rdone, rq);
       }
+      __builtin_amdgcn_s_setprio(0);
       continue;
     }
     seen = sq;
@@ -847,6 +849,7 @@ __device__ inline void m3_helper(M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       m3_st(&m.done, sq);
     }
+    __builtin_amdgcn_s_setprio(0);
   }
 }
 
