@@ -41,8 +41,11 @@ def draw_case(rng):
     if rng.random() < 0.25:
         kw["max_board_scans"] = int(rng.integers(1, 4))
     case["auto_reset"] = bool(rng.random() < 0.8)
-    if rng.random() < 0.1:
+    r = rng.random()
+    if r < 0.1:
         case["mode"] = "adapter"
+    elif r < 0.15:
+        case["mode"] = "gym"
     r = rng.random()
     case["seed_kind"] = "same" if r < 0.05 else ("huge" if r < 0.1 else "range")
     return case
@@ -477,6 +480,72 @@ def run_adapter_case(case, seed):
     return int(orc.last_episode()["n_episodes"].sum())
 
 
+def run_gym_case(case, seed):
+    """the same configuration as ONE env behind make_env(cfg), the reference's gym call shape (rl/envs.py:28-81)"""
+    from types import SimpleNamespace as NS
+    import pcgrl_oracle as po  # (checker)
+    from control_pcgrl_amd import make_env
+
+    problem, rep, shape, T = case["problem"], case["rep"], tuple(case["shape"]), min(case["steps"], 60)
+    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items() if k != "solver_power"}
+    controls = kw.get("controls") or []
+    cfg = NS(representation=rep, max_board_scans=kw.get("max_board_scans", 3), change_percentage=kw.get("change_percentage"),
+             controls=controls or None, act_window=kw.get("act_window"), static_prob=kw.get("static_prob"),
+             n_static_walls=kw.get("n_static_walls"),
+             task=NS(problem=problem, map_shape=shape, obs_window=kw.get("obs_window"), weights=kw.get("weights")),
+             multiagent=NS(n_agents=0))
+    try:
+        env = make_env(cfg)
+    except ValueError:
+        try:
+            po.OracleVecEnv(problem, rep, shape, 1, seeds=[seed], **kw)
+        except ValueError:
+            return -1
+        raise AssertionError("make_env refuses what the oracle accepts")
+    env.unwrapped.seed(int(seed))
+    orc = po.OracleVecEnv(problem, rep, shape, 1, seeds=[seed], **kw)
+    rng = np.random.default_rng(seed)
+    K2 = 2 * len(controls)
+    bounds = po.cond_bounds(problem, shape) if controls else None
+    keys = STAT_KEYS[problem]
+
+    def new_targets():
+        trg = {k: float(rng.random() * (bounds[k][1] - bounds[k][0]) + bounds[k][0]) for k in controls}
+        env.set_trgs(trg)
+        orc.queue_targets(trg)
+
+    def check_obs(o, want, what):
+        assert o.dtype == np.float32 and np.array_equal(o[..., K2:].astype(np.uint8), want), f"obs {what}"
+        if K2:
+            planes = o[..., :K2].reshape(-1, K2)
+            assert np.all(planes == planes[0]) and np.allclose(planes[0], orc.ctrl_obs()[0], rtol=1e-6, atol=1e-7), f"control planes {what}"
+
+    if controls:
+        new_targets()
+    obs, info = env.reset()
+    assert info == {}
+    check_obs(obs, orc.reset()[0], "after reset")
+    entries = env._vec.action_entries
+    hi = env._vec.spec.n_tiles if entries > 1 else env._vec.num_actions
+    for t in range(T):
+        a = rng.integers(0, hi, size=(1, entries) if entries > 1 else (1,))
+        obs, r, d, tr, info = env.step(a[0] if entries > 1 else int(a[0]))
+        oobs, orew, odone, ostats = orc.step(a, auto_reset=False, want_obs=True)
+        check_obs(obs, oobs[0], f"@ {t}")
+        assert abs(r - orew[0]) <= 1e-5 * max(1.0, abs(orew[0])) and d == bool(odone[0]) and tr == d, f"reward / done @ {t}"
+        assert [info[k] for k in keys] == ostats[0].tolist() and env.unwrapped._rep_stats == dict(zip(keys, ostats[0].tolist())), f"stats @ {t}"
+        ost = orc.get_state()
+        assert info["iterations"] == int(ost["iteration"][0]) and info["changes"] == int(ost["changes"][0]), f"counters @ {t}"
+        if d:
+            if controls:
+                new_targets()
+            obs, info = env.reset()
+            check_obs(obs, orc.reset()[0], f"reset after {t}")
+    env._vec.check_errors()
+    env.close()
+    return int(orc.last_episode()["n_episodes"].sum())
+
+
 def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
     rng = np.random.default_rng(seed)
     t0 = time.time()
@@ -487,7 +556,7 @@ def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
         line = json.dumps(dict(case, seed=cs))
         t1 = time.time()
         try:
-            eps = run_adapter_case(case, cs) if case.get("mode") == "adapter" else run_case(case, cs)
+            eps = {"adapter": run_adapter_case, "gym": run_gym_case}.get(case.get("mode"), run_case)(case, cs)
             case.pop("_trace", None)
             if verbose:
                 print(f"ok   {i:4d} {time.time() - t1:6.1f}s eps={eps:5d} {line}", flush=True)
@@ -526,7 +595,7 @@ if __name__ == "__main__":
         c = json.loads(a.case)
         s = c.pop("seed")
         try:
-            print("episodes:", run_adapter_case(c, s) if c.get("mode") == "adapter" else run_case(c, s, verbose=True))
+            print("episodes:", {"adapter": run_adapter_case, "gym": run_gym_case}.get(c.get("mode"), run_case)(c, s))
         finally:
             print("events:", " ".join(c.get("_trace", [])))
         sys.exit(0)
