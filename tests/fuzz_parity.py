@@ -64,7 +64,7 @@ def _draw_case(rng):
             shape = [7, 7, 7]
         case["shape"] = shape
         if rng.random() < 0.4:  # any window whose volume is a multiple of 4
-            ow = [int(rng.integers(1, 2 * s + 3)) for s in shape]
+            ow = [int(rng.integers(1, (3 * s + 6) if rng.random() < 0.1 else (2 * s + 3))) for s in shape]
             ow[2] += (-ow[2]) % 4 if (ow[0] * ow[1] * ow[2]) % 4 else 0
             kw["obs_window"] = ow
         cells = shape[0] * shape[1] * shape[2]
@@ -95,11 +95,15 @@ def _draw_case(rng):
     H, W = shape
     if rep != "wide" and rng.random() < 0.5 and not headline:
         kw["obs_window"] = [int(rng.integers(1, 2 * H + 4)), int(rng.integers(1, 2 * W + 4))]
+        if rng.random() < 0.1:  # far beyond the map on every side (rows of padding only)
+            kw["obs_window"] = [int(rng.integers(2 * H, 3 * H + 8)), int(rng.integers(2 * W, 3 * W + 8))]
     if rng.random() < 0.5:
-        kw["change_percentage"] = float(rng.choice([0.05, 0.2, 0.5, 1.0]))
+        kw["change_percentage"] = float(rng.choice([0.001, 0.05, 0.2, 0.5, 1.0]))
     if rep != "wide" and rng.random() < 0.3:
-        kw["static_prob"] = float(rng.choice([0.0, 0.1, 0.3, 0.7]))
-        kw["n_static_walls"] = int(rng.integers(0, 6)) if H >= 3 and W >= 3 else 0
+        kw["static_prob"] = float(rng.choice([0.0, 0.1, 0.3, 0.7, 1.0]))
+        kw["n_static_walls"] = int(rng.integers(0, 12 if rng.random() < 0.2 else 6)) if H >= 3 and W >= 3 else 0
+        if rng.random() < 0.15:
+            kw["static_eval"] = True
     if rep == "narrow" and rng.random() < 0.25:
         kw["act_window"] = [int(rng.integers(1, min(H, 5) + 1)), int(rng.integers(1, min(W, 5) + 1))]
     if rng.random() < 0.25:
@@ -305,7 +309,7 @@ def run_case(case, seed, verbose=False):
             sd = env.state_dict()
             env2 = make_engine()
             if cur_static is not None:  # (host-side settings are the caller's to carry over, like the constructor's)
-                env2.set_static(static_prob=cur_static[0], n_static_walls=cur_static[1])
+                env2.set_static(static_prob=cur_static[0], n_static_walls=cur_static[1], eval_mode=cur_static[2])
             env2.load_state_dict(sd)
             env.check_errors()
             env.close()
@@ -374,9 +378,10 @@ def run_case(case, seed, verbose=False):
             t += 1
         elif ev == "set_static":  # takes effect at the next reset
             sp, nw = float(rng.choice([0.0, 0.2, 0.6])), int(rng.integers(0, 4)) if min(shape) >= 3 else 0
-            cur_static = (sp, nw)
-            env.set_static(static_prob=sp, n_static_walls=nw)
-            orc.set_static(static_prob=sp, n_static_walls=nw)
+            ev_mode = bool(rng.random() < 0.3)
+            cur_static = (sp, nw, ev_mode)
+            env.set_static(static_prob=sp, n_static_walls=nw, eval_mode=ev_mode)
+            orc.set_static(static_prob=sp, n_static_walls=nw, eval_mode=ev_mode)
             t += 1
         else:
             assert np.array_equal(env.observe().cpu().numpy(), orc.observe()), f"obs {what}"
@@ -405,7 +410,7 @@ def run_adapter_case(case, seed):
 
     problem, rep, shape, T = case["problem"], case["rep"], tuple(case["shape"]), min(case["steps"], 80)
     n = min(case["n_envs"], 48)
-    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items() if k != "solver_power"}
+    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items() if k not in ("solver_power", "static_eval")}
     controls = kw.get("controls") or []
     seeds = seed + np.arange(n)
     cfg = {"task": {"problem": problem, "map_shape": list(shape), "obs_window": kw.get("obs_window"), "weights": kw.get("weights")},
@@ -487,7 +492,7 @@ def run_gym_case(case, seed):
     from control_pcgrl_amd import make_env
 
     problem, rep, shape, T = case["problem"], case["rep"], tuple(case["shape"]), min(case["steps"], 60)
-    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items() if k != "solver_power"}
+    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items() if k not in ("solver_power", "static_eval")}
     controls = kw.get("controls") or []
     cfg = NS(representation=rep, max_board_scans=kw.get("max_board_scans", 3), change_percentage=kw.get("change_percentage"),
              controls=controls or None, act_window=kw.get("act_window"), static_prob=kw.get("static_prob"),
