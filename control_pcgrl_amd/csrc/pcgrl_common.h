@@ -83,7 +83,7 @@ struct Params {
   int32_t trg_lo_i[PCGRL_MAX_STATS], trg_hi_i[PCGRL_MAX_STATS];
   int32_t int_targets;
   int32_t spread;         // sokoban step: one env per wave pair (see step_kernel)
-  int32_t sk_helpers;     // sokoban: helper wavefronts per workgroup for the solver's A* stages (0 or 3, see pcgrl_sokoban.h)
+  int32_t sk_helpers;     // sokoban: A* stages run by helper wavefronts (0 or 3; two waves per stage, see pcgrl_sokoban.h)
   // per-call I/O
   const int32_t *actions;
   uint8_t *obs;

@@ -65,7 +65,7 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
   // stale statistics (after pcgrl_update) are only handled by the general step / rollout kernels
   const bool fast = fast_cfg && !(p.no_fast && (id == K_STEP || id == K_ROLLOUT) && !p.update_only);
   // sokoban with p.sk_helpers: the solver's helper wavefronts ride behind the simulate / observe waves
-  const unsigned helper_threads = PROB == PCGRL_PROB_SOKOBAN ? 64u * (unsigned)p.sk_helpers : 0u;
+  const unsigned helper_threads = PROB == PCGRL_PROB_SOKOBAN ? 2u * 64u * (unsigned)p.sk_helpers : 0u;  // (heap + expander wave per stage)
   const size_t helper_lds = PROB == PCGRL_PROB_SOKOBAN ? (size_t)p.sk_helpers * SK_HELPER_LDS : 0;  // (their A* heaps)
   hipError_t e = hipSuccess;
   switch (id) {

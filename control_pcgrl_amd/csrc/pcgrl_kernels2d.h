@@ -586,6 +586,9 @@ __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool 
 // helper wavefronts of the solver (pcgrl_sokoban.h): kernels launched with Params::sk_helpers carry three of them per
 // workgroup, behind the simulate / observe waves
 __device__ inline void sokoban_helper(const Params &p, int k, uint32_t *lds_heap);
+// ... each with an expander wave behind it (A* stage k = heap wave k + expander wave k, see sk_stage_heap): kernels
+// launched with sk_helpers = 3 carry 2 * 3 helper wavefronts, the heap waves first
+__device__ inline void sokoban_expander(const Params &p, int k);
 constexpr int SK_HELPER_LDS = 32 * 1024;  // dynamic LDS per helper wave (the top of its A* heap), behind the kernel's own
 __device__ inline void sokoban_helpers_init();
 __device__ inline void sokoban_helpers_release();
@@ -1566,7 +1569,7 @@ template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
 #ifndef PCGRL_STEP_WAVES
 #define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
 #endif
-__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 320 : 128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : 1)
+__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 512 : 128 * PAIRS, (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : 1)
 void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
@@ -1586,8 +1589,11 @@ void step_kernel(Params p) {
     if (wave >= 2 * PAIRS) {
       if (wave == 2 * PAIRS) sokoban_helpers_init();
       __syncthreads();
-      sokoban_helper(p, wave - 2 * PAIRS + 1,
-                     (uint32_t *)(lds_all + (size_t)PAIRS * p.lds_pair_bytes + (size_t)(wave - 2 * PAIRS) * SK_HELPER_LDS));
+      const int j = wave - 2 * PAIRS;
+      if (j < p.sk_helpers)
+        sokoban_helper(p, j + 1, (uint32_t *)(lds_all + (size_t)PAIRS * p.lds_pair_bytes + (size_t)j * SK_HELPER_LDS));
+      else
+        sokoban_expander(p, j - p.sk_helpers + 1);
       return;
     }
   }
@@ -2190,18 +2196,19 @@ __global__ __launch_bounds__(64) void last_episode_kernel(Params p) {
 
 // Problem.get_stats on caller-provided byte grids (no engine state)
 template <int PROB, int LPE, typename M>
-__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 256 : 64) void stats_for_grids_kernel(Params p) {
+__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 448 : 64) void stats_for_grids_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   Grp<LPE> g;
   g.init();
-  const bool helped = PROB == PCGRL_PROB_SOKOBAN && p.sk_helpers != 0;  // waves 1..3: the solver's helpers
+  const bool helped = PROB == PCGRL_PROB_SOKOBAN && p.sk_helpers != 0;  // waves 1..3: the solver's heap waves, 4..6: their expanders
   if constexpr (PROB == PCGRL_PROB_SOKOBAN) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave >= 1) {
       if (wave == 1) sokoban_helpers_init();
       __syncthreads();
       extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
-      sokoban_helper(p, wave, (uint32_t *)(lds_all + (size_t)(wave - 1) * SK_HELPER_LDS));
+      if (wave - 1 < p.sk_helpers) sokoban_helper(p, wave, (uint32_t *)(lds_all + (size_t)(wave - 1) * SK_HELPER_LDS));
+      else sokoban_expander(p, wave - p.sk_helpers);
       return;
     }
     if (helped) __syncthreads();

@@ -124,9 +124,22 @@ struct SokoMail {
   int32_t cancel_after;  // stages with a larger index stop
   int32_t done[SK_STAGES], won[SK_STAGES], h[SK_STAGES], depth[SK_STAGES];
 };
+// A* stage k of a helped cascade runs on TWO helper wavefronts (see sk_stage_heap): the heap wave posts the node it is
+// about to pop, the expander wave answers with that node's children (or "won").
+constexpr int SK_JOB_START = -2, SK_JOB_END = -3;
+struct SokoPipe {
+  int32_t jseq, rseq;     // job posted by the heap wave / answered by the expander
+  int32_t cur;            // node to expand, or SK_JOB_START (new search: slot, px, py, b2) / SK_JOB_END (report the best node)
+  int32_t slot, px, py, b2;
+  // answer (two 16-byte words, read by the heap wave with one LDS round trip): won, n, h, depth -- won + the node's
+  // (h, depth); START: h = the root's heuristic; END: the best node's -- and the open-list entries of the children in push order
+  alignas(16) sk_u32x4 res;
+  sk_u32x4 item;
+};
 struct SokoShared {
   SokoLevel level;
   SokoMail mail;
+  SokoPipe pipe[SK_STAGES];
 };
 __device__ inline SokoShared &sk_shared() {
   __shared__ SokoShared s;
@@ -685,7 +698,7 @@ __device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int s
 
 // node 0 of the bound workspace = the level's root state (crates in c.lv->root)
 template <bool BIG>
-__device__ inline void sk_root(SokoCtx &c, int px, int py) {
+__device__ inline int sk_root(SokoCtx &c, int px, int py) {
   SkCrates<BIG> root;
   root.c0 = c.lane < c.ncr ? c.lv->root[c.lane] : SK_NOCRATE;
   root.c1 = (BIG && c.lane + 64 < c.ncr) ? c.lv->root[c.lane + 64] : SK_NOCRATE;
@@ -699,6 +712,214 @@ __device__ inline void sk_root(SokoCtx &c, int px, int py) {
     n0.px = px;
     n0.py = py;
     c.nodes[0] = n0.pack();
+  }
+  return h0;
+}
+
+// ---- an A* stage on two wavefronts.  An iteration is pop -> expand -> push the children, and the pop is a chain of
+// dependent heap reads that touches no node record, while the expansion touches no heap entry.  The node the pop will
+// return is the heap's root before the sift, so the heap wave posts it first and sifts while the expander wave loads
+// the record, tests win / visited, builds the children and their open-list entries; the heap wave then pushes those
+// entries in the same order.  Same pops, same pushes, same visited set as the one-wave stage -- an iteration costs the
+// heap operations alone (tools/solver_phase.py: 3 600 + 1 200 of 7 400 cycles).
+__device__ __attribute__((always_inline)) inline void sk_pipe_post(SokoPipe &pp, int lane, int seq, int cur) {
+  if (lane == 0) {
+    pp.cur = cur;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    sk_st(&pp.jseq, seq);
+  }
+}
+__device__ __attribute__((always_inline)) inline void sk_pipe_wait(SokoPipe &pp, int seq) {
+  while (__builtin_amdgcn_readfirstlane(sk_ld(&pp.rseq)) != seq) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// heap wave of stage k: c.hl / c.q hold the open list; `seq` is the pipe's job counter (kept by this wave).
+// The node an iteration pops is known one iteration ahead: after the pop the heap's root is `new_top`, and a child takes
+// its place only with a strictly smaller key (heapq's sift-up compares with <), the first such child first -- so the next
+// job is posted BEFORE the children are pushed and the expander works on it during the pushes and the next sift.  It is
+// posted only if that iteration is certain to run (the iteration limit is known; a cancelled stage's result is unused).
+__device__ __attribute__((always_inline)) inline bool sk_stage_heap(SokoCtx &c, SokoPipe &pp, int &seq, int max_iter, int h_root, int &res_h,
+                                                          int &res_depth, const int32_t *cancel, int my_stage) {
+  int tail = 1, iters = 0;
+  bool won = false;
+  sk_hq_store<false>(c, 0, (uint32_t)(2 * h_root) << 16, c.lane == 0);
+  bool live = sk_u(sk_ld(cancel)) >= my_stage;
+  bool more = max_iter > 0 && live;
+  if (more) sk_pipe_post(pp, c.lane, ++seq, 0);  // the root
+  while (more) {
+    iters++;
+    tail = sk_u(tail);
+    uint32_t new_top = 0;
+    (void)sk_heappop(c, tail, &new_top);  // (returns the entry of the node posted for this iteration)
+    sk_pipe_wait(pp, seq);
+    const sk_u32x4 r = pp.res, it = pp.item;  // (one round trip for both)
+    if (sk_u((int)r.x) != 0) {
+      won = true;
+      res_h = sk_u((int)r.z);
+      res_depth = sk_u((int)r.w);
+      break;
+    }
+    const int n = sk_u((int)r.y);
+    const uint32_t items[4] = {(uint32_t)sk_u((int)it.x), (uint32_t)sk_u((int)it.y), (uint32_t)sk_u((int)it.z), (uint32_t)sk_u((int)it.w)};
+    if ((iters & 15) == 0) live = sk_u(sk_ld(cancel)) >= my_stage;  // (a cancelled stage's result is unused: no hurry)
+    more = iters < max_iter && (tail > 0 || n > 0) && live;
+    if (more) {  // the root after the pushes below
+      uint32_t next = tail > 0 ? new_top : items[0];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (i < n && sk_key_lt(items[i], next)) next = items[i];
+      sk_pipe_post(pp, c.lane, ++seq, (int)(next & 0xFFFFu));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < n) sk_heappush(c, tail, items[i]);
+  }
+  sk_pipe_post(pp, c.lane, ++seq, SK_JOB_END);
+  sk_pipe_wait(pp, seq);
+  if (!won) {
+    const sk_u32x4 r = pp.res;
+    res_h = sk_u((int)r.z);
+    res_depth = sk_u((int)r.w);
+  }
+  return won;
+}
+
+// expander wave: one node of the search bound to c (AStarAgent.getSolution's loop body without the heap, engine.py:104-119)
+template <bool BIG>
+__device__ __attribute__((always_inline)) inline void sk_expand(SokoCtx &c, SokoPipe &pp, int cur, int b2, int &best, int &best_h, int &best_depth) {
+  const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
+  SokoNode nd = SokoNode::unpack(c.nodes[cur]);
+  SkCrates<BIG> cr;
+  cr.load(c, cur);
+  nd.depth = sk_u(nd.depth);
+  nd.h = sk_u(nd.h);
+  nd.px = sk_u(nd.px);
+  nd.py = sk_u(nd.py);
+  const int px = nd.px, py = nd.py;
+  if (c.lv->ntg == c.ncr && c.ncr > 0 && cr.count_on(c.lv->tgt) == c.ncr) {  // checkWin engine.py:272-280
+    if (c.lane == 0) pp.res = sk_u32x4{1u, 0u, (uint32_t)nd.h, (uint32_t)nd.depth};
+    return;
+  }
+  const SkKey key = sk_key(c, px, py, cr);
+  const bool seen = sk_visited_test_and_set(c, cur, key, cr);
+  int n = 0;
+  uint32_t items[4] = {0u, 0u, 0u, 0u};
+  if (!seen) {
+    if (best < 0 || nd.h < best_h || (nd.h == best_h && nd.depth < best_depth)) {  // engine.py:66-69
+      best = cur;
+      best_h = nd.h;
+      best_depth = nd.depth;
+    }
+    const int n_dead = cr.count_on(c.lv->dead);
+    // Node.getChildren engine.py:14-25 + State.update :298-328
+    for (int d = 0; d < 4; d++) {
+      const int nx = px + DX[d], ny = py + DY[d];
+      if (nx < 0 || ny < 0 || nx > c.lv->w - 1 || ny > c.lv->h - 1 || sk_bit(c.lv->solid, nx, ny)) continue;
+      const int moved = cr.at(nx, ny);
+      SkCrates<BIG> ch = cr;
+      int h = nd.h;  // the heuristic depends on the crates only
+      if (moved >= 0) {
+        const int bx = nx + DX[d], by = ny + DY[d];
+        if (!sk_free_cell(c, cr, bx, by)) continue;
+        // engine.py:22-23 checkDeadlock over all crates of the child
+        const int ndead = n_dead - (sk_bit(c.lv->dead, nx, ny) ? 1 : 0) + (sk_bit(c.lv->dead, bx, by) ? 1 : 0);
+        if (ndead > 0) continue;
+        const uint32_t np = (uint32_t)bx | ((uint32_t)by << 8);
+        if (!BIG || moved < 64) ch.c0 = c.lane == moved ? np : ch.c0;
+        else ch.c1 = c.lane == moved - 64 ? np : ch.c1;
+        h = sk_heuristic(c, ch);
+      }
+      if (c.n_nodes >= c.max_nodes) {  // cannot happen (<= 1 + 4 * iterations nodes per stage); reported if it does
+        c.pool_full = true;
+        continue;
+      }
+      const int k = c.n_nodes++;
+      ch.store(c, k);
+      if (c.lane == 0) {
+        SokoNode nn;
+        nn.parent = cur;
+        nn.depth = nd.depth + 1;
+        nn.h = h;
+        nn.px = nx;
+        nn.py = ny;
+        c.nodes[k] = nn.pack();
+      }
+      const uint32_t item = ((uint32_t)(2 * h + b2 * (nd.depth + 1)) << 16) | (uint32_t)k;
+#pragma unroll
+      for (int i = 0; i < 4; i++) items[i] = i == n ? item : items[i];
+      n++;
+    }
+  }
+  if (c.lane == 0) {
+    pp.res = sk_u32x4{0u, (uint32_t)n, 0u, 0u};
+    pp.item = sk_u32x4{items[0], items[1], items[2], items[3]};
+  }
+}
+
+// Body of expander wave k (1..3): serves the heap wave of stage k until the simulate wave leaves.
+__device__ __attribute__((always_inline)) inline void sokoban_expander(const Params &p, int k) {
+  const SokoPool &pool = *(const SokoPool *)p.soko;
+  SokoShared &sh = sk_shared();
+  SokoMail &m = sh.mail;
+  SokoPipe &pp = sh.pipe[k];
+  SokoCtx c;
+  c.lv = &sh.level;
+  c.lane = (int)(threadIdx.x & 63);
+  c.pool_full = false;
+  c.hl = (uint32_t SK_LDS *)nullptr;
+  c.hcap = 0;
+  c.dbg = nullptr;
+  c.ncr = 0;
+  c.cstride = 0;
+  int seen = 0, best = -1, best_h = 0, best_depth = 0, b2 = 0;
+  while (true) {
+    int s;
+    while ((s = __builtin_amdgcn_readfirstlane(sk_ld(&pp.jseq))) == seen) {
+      if (__builtin_amdgcn_readfirstlane(sk_ld(&m.exit)) != 0) return;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    seen = s;
+    const int cur = sk_u(sk_ld(&pp.cur));
+    if (cur == SK_JOB_START) {  // a new search: workspace k of the slot, a fresh visited epoch, node 0 = the root
+      const int slot = sk_u(sk_ld(&pp.slot)), px = sk_u(sk_ld(&pp.px)), py = sk_u(sk_ld(&pp.py));
+      b2 = sk_u(sk_ld(&pp.b2));
+      c.ncr = sk_u(sh.level.ncr);
+      c.cstride = (c.ncr + 3) & ~3;
+      sk_bind(c, pool, slot, k);
+      uint32_t *epoch_word = &pool.epochs[slot * SK_STAGES + k];
+      uint32_t ep = 0;
+      if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
+      ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+      if (ep == 0) {  // wrapped: start over with a clean table
+        for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = sk_u32x4{0u, 0u, 0u, 0u};
+        if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
+        ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+      }
+      c.epoch = ep;
+      c.n_nodes = 1;
+      best = -1;
+      best_h = best_depth = 0;
+      const int h0 = c.ncr > 64 ? sk_root<true>(c, px, py) : sk_root<false>(c, px, py);
+      if (c.lane == 0) pp.res = sk_u32x4{0u, 0u, (uint32_t)h0, 0u};
+    } else if (cur == SK_JOB_END) {
+      if (c.lane == 0) {
+        pp.res = sk_u32x4{0u, 0u, (uint32_t)best_h, (uint32_t)best_depth};
+        if (c.pool_full) atomicOr(p.err, 2);
+      }
+      c.pool_full = false;
+    } else {
+      c.n_nodes = sk_u(c.n_nodes);
+      if (c.ncr > 64) sk_expand<true>(c, pp, cur, b2, best, best_h, best_depth);
+      else sk_expand<false>(c, pp, cur, b2, best, best_h, best_depth);
+      best = sk_u(best);
+      best_h = sk_u(best_h);
+      best_depth = sk_u(best_depth);
+    }
+    if (c.lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      sk_st(&pp.rseq, s);
+    }
   }
 }
 
@@ -776,7 +997,7 @@ __device__ __attribute__((always_inline)) inline void sokoban_helper(const Param
 #else
   c.dbg = nullptr;
 #endif
-  int seen = 0;
+  int seen = 0, pipe_seq = 0;
   while (true) {
     int s;
     while ((s = __builtin_amdgcn_readfirstlane(sk_ld(&m.seq))) == seen) {
@@ -792,14 +1013,18 @@ __device__ __attribute__((always_inline)) inline void sokoban_helper(const Param
     int h = 0, depth = 0;
     bool won = false;
     if (__builtin_amdgcn_readfirstlane(sk_ld(&m.cancel_after)) >= k) {
-      const int b2 = 3 - k;  // balance 1, 0.5, 0
-      if (c.ncr > 64) {
-        sk_root<true>(c, px, py);
-        won = sk_stage<true>(c, pool, slot, b2, power, h, depth, nullptr, &m.cancel_after, k);
-      } else {
-        sk_root<false>(c, px, py);
-        won = sk_stage<false>(c, pool, slot, b2, power, h, depth, nullptr, &m.cancel_after, k);
+      // this wave keeps the open list; its expander wave owns the node records and the visited set (sk_stage_heap)
+      SokoPipe &pp = sh.pipe[k];
+      if (c.lane == 0) {
+        pp.slot = slot;
+        pp.px = px;
+        pp.py = py;
+        pp.b2 = 3 - k;  // balance 1, 0.5, 0
       }
+      sk_pipe_post(pp, c.lane, ++pipe_seq, SK_JOB_START);
+      sk_pipe_wait(pp, pipe_seq);
+      const int h_root = sk_u((int)pp.res.z);
+      won = sk_stage_heap(c, pp, pipe_seq, power, h_root, h, depth, &m.cancel_after, k);
     }
     if (c.lane == 0) {
       if (won) atomicMin(&m.cancel_after, k);
@@ -809,8 +1034,6 @@ __device__ __attribute__((always_inline)) inline void sokoban_helper(const Param
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       sk_st(&m.done[k], s);
     }
-    if (c.pool_full && c.lane == 0) atomicOr(p.err, 2);
-    c.pool_full = false;
   }
 }
 // first helper wave, before the workgroup barrier: an empty mailbox
@@ -820,7 +1043,11 @@ __device__ inline void sokoban_helpers_init() {
     m.seq = 0;
     m.exit = 0;
     m.cancel_after = SK_STAGES;
-    for (int k = 0; k < SK_STAGES; k++) m.done[k] = 0;
+    for (int k = 0; k < SK_STAGES; k++) {
+      m.done[k] = 0;
+      sk_shared().pipe[k].jseq = 0;
+      sk_shared().pipe[k].rseq = 0;
+    }
   }
 }
 // simulate wave, when it leaves the kernel

@@ -402,6 +402,18 @@ def run_case(case, seed, verbose=False):
     return int(ole["n_episodes"].sum())
 
 
+def _final_check(vec, problem):
+    """pcgrl_poll_error at the end of a case; False: a sokoban level beyond the device solver's 128 crates was met
+    (reported, the statistics of that step kept their solver-less values)"""
+    try:
+        vec.check_errors()
+    except NotImplementedError as ex:
+        if problem == "sokoban" and "solver" in str(ex):
+            return False
+        raise
+    return True
+
+
 def run_adapter_case(case, seed):
     """the same configuration through PcgrlVectorEnv (ray.rllib VectorEnv call shape): vector_reset / vector_step / reset_at
     per finished env, per-env targets through the sub-env handles, against the oracle without auto-reset"""
@@ -480,9 +492,9 @@ def run_adapter_case(case, seed):
                 o, info = env.reset_at(int(i))
                 assert info == {}
                 check_obs(o, oobs[int(i)], octrl[int(i)], f"reset_at({i}) @ {t}")
-    env.vec.check_errors()
+    ok = _final_check(env.vec, problem)
     env.close()
-    return int(orc.last_episode()["n_episodes"].sum())
+    return int(orc.last_episode()["n_episodes"].sum()) if ok else -2
 
 
 def run_gym_case(case, seed):
@@ -546,9 +558,9 @@ def run_gym_case(case, seed):
                 new_targets()
             obs, info = env.reset()
             check_obs(obs, orc.reset()[0], f"reset after {t}")
-    env._vec.check_errors()
+    ok = _final_check(env._vec, problem)
     env.close()
-    return int(orc.last_episode()["n_episodes"].sum())
+    return int(orc.last_episode()["n_episodes"].sum()) if ok else -2
 
 
 def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
