@@ -563,13 +563,15 @@ def run_gym_case(case, seed):
     return int(orc.last_episode()["n_episodes"].sum()) if ok else -2
 
 
-def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None):
+def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None, only=None):
     rng = np.random.default_rng(seed)
     t0 = time.time()
     failures = []
     for i in range(n_cases):
         case = draw_case(rng)
         cs = int(rng.integers(0, 1 << 30))
+        if only and case["problem"] not in only:
+            continue
         line = json.dumps(dict(case, seed=cs))
         t1 = time.time()
         try:
@@ -601,6 +603,7 @@ if __name__ == "__main__":
     ap.add_argument("--keep-going", action="store_true")
     ap.add_argument("--case", type=str, default=None, help="replay one case (the JSON a failure printed)")
     ap.add_argument("--dry", action="store_true", help="only print the drawn cases (no GPU needed)")
+    ap.add_argument("--only", type=str, default=None, help="comma-separated problems to keep (the others are drawn and skipped)")
     a = ap.parse_args()
     if a.dry:
         r = np.random.default_rng(a.seed)
@@ -616,6 +619,6 @@ if __name__ == "__main__":
         finally:
             print("events:", " ".join(c.get("_trace", [])))
         sys.exit(0)
-    f = sweep(a.cases, a.seed, stop_on_fail=not a.keep_going, budget_s=a.budget_s)
+    f = sweep(a.cases, a.seed, stop_on_fail=not a.keep_going, budget_s=a.budget_s, only=a.only.split(",") if a.only else None)
     print(f"{len(f)} failure(s)")
     sys.exit(1 if f else 0)
