@@ -44,6 +44,7 @@ struct pcgrl_engine {
   size_t lds_bytes = 0;
   int cpl = 0;  // 3-D: cells per lane of the reset RNG split
   int32_t *seen_host = nullptr;  // sokoban: host-mapped counter of device solver runs
+  int soko_slots = 0;            // sokoban: workspace slots of the current pool (p.soko)
   int32_t seen_last = 0, spread_left = 0;
   bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
@@ -551,7 +552,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     p.jump_b = djb;
   }
   if (cfg->problem == PCGRL_PROB_SOKOBAN) {
-    CREATE_CHK(sokoban_alloc(p, e->allocs, 64 / lpe));
+    CREATE_CHK(sokoban_alloc(p, e->allocs, 64 / lpe, 0, &e->soko_slots));
     CREATE_CHK(hipHostMalloc((void **)&e->seen_host, sizeof(int32_t), hipHostMallocMapped));
     *e->seen_host = 0;
     CREATE_CHK(hipHostGetDevicePointer((void **)&p.solver_seen, e->seen_host, 0));
@@ -863,6 +864,19 @@ static int stats_engine_for(const pcgrl_config &cfg, int device, pcgrl_handle *o
 int pcgrl_stats_for_grids_h(pcgrl_handle h, int32_t n, const uint8_t *d_grids, int32_t *d_stats, void *stream) {
   if (!h || n < 1 || !d_grids || !d_stats) return fail(PCGRL_EINVAL, "pcgrl_stats_for_grids_h: bad arguments");
   ON_DEVICE(h->device);
+  if (h->p.soko) {
+    // One level per workgroup, at most one such workgroup per CU: up to 256 searches run at once, each in a workspace
+    // slot.  The pool is sized for the engine's own envs; a batch that is much larger gets a larger pool the first time
+    // (synchronous, up to 256 slots = 11.8 GB at the default solver_power; the old pool stays allocated until destroy:
+    // launches in flight on other streams keep using it).
+    const int need = std::min(256, sokoban_slots_for(n));
+    if (need > h->soko_slots) {
+      Params grown = h->p;
+      hipError_t e = sokoban_alloc(grown, h->allocs, 0, need, &h->soko_slots);
+      if (e != hipSuccess) return fail(PCGRL_EHIP, std::string("pcgrl_stats_for_grids_h: solver workspace: ") + hipGetErrorString(e));
+      h->p.soko = grown.soko;
+    }
+  }
   Params p = h->p;
   p.n_envs = n;  // the kernel touches no per-env engine state
   p.init_grids = d_grids;

@@ -1550,3 +1550,20 @@ def test_injected_maps_with_action_patch_ignore_init_pos():
             assert np.array_equal(info["stats"].cpu().numpy(), ostats) and np.array_equal(obs.cpu().numpy(), oobs), (rnd, t)
     assert np.array_equal(env.get_state().pos.cpu().numpy()[:, :2], orc.get_state()["pos"][:, :2])
     env.check_errors()
+
+
+def test_stats_for_grids_large_sokoban_batch_on_a_small_engine():
+    """a batch much larger than the engine's own env count grows the solver's workspace pool once (one level per workgroup,
+    up to 256 searches at a time); answers equal the oracle's before and after the growth"""
+    g = _solvable_rooms(700, 5)
+    want = po.stats_for_grids("sokoban", g, solver_power=1500)
+    env = _vec("sokoban", "narrow", (16, 16), 1, solver_power=1500)
+    small = env.stats_for_grids(torch.as_tensor(g[:3]).to(env.device)).cpu().numpy()
+    assert np.array_equal(small, want[:3])
+    for _ in range(2):
+        got = env.stats_for_grids(torch.as_tensor(g).to(env.device)).cpu().numpy()
+        assert np.array_equal(got, want)
+    env.reset()
+    a = torch.zeros(1, dtype=torch.int32, device=env.device)
+    env.step(a)  # the engine's own step path uses the grown pool, too
+    env.check_errors()
