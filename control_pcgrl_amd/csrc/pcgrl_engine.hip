@@ -870,6 +870,8 @@ int pcgrl_stats_for_grids_h(pcgrl_handle h, int32_t n, const uint8_t *d_grids, i
     // (synchronous, up to 256 slots = 11.8 GB at the default solver_power; the old pool stays allocated until destroy:
     // launches in flight on other streams keep using it).
     const int need = std::min(256, sokoban_slots_for(n));
+    static std::mutex grow_mu;  // (the handle-less entry point shares its hidden engines between threads)
+    std::lock_guard<std::mutex> lock(grow_mu);
     if (need > h->soko_slots) {
       Params grown = h->p;
       hipError_t e = sokoban_alloc(grown, h->allocs, 0, need, &h->soko_slots);
