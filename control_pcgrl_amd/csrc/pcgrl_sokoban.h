@@ -19,10 +19,11 @@
 // batch; a wavefront holds at most one slot at a time (no lock cycles however many envs need solving at once).
 //
 // The four stages of the cascade are independent searches from the same root: only which results are USED depends on
-// the order.  Kernels launched with Params::sk_helpers = 3 carry three helper wavefronts per workgroup that run the A*
-// stages speculatively (each in its own quarter of the slot) while the simulate wave runs the BFS stage; a stage is
-// cancelled as soon as an earlier one has won (or the BFS stage has expanded the whole state space), so the launch
-// waits for the longest single stage instead of the sum of four.
+// the order.  Kernels launched with Params::sk_helpers = 3 carry helper wavefronts that run the three A* stages
+// speculatively (each in its own quarter of the slot) while the simulate wave runs the BFS stage; a stage is cancelled as
+// soon as an earlier one has won (or the BFS stage has expanded the whole state space), so the launch waits for the
+// longest single stage instead of the sum of four.  Each helped A* stage is a pair of wavefronts -- one keeps the open
+// list, the other expands nodes one iteration ahead (sk_stage_heap / sokoban_expander).
 #pragma once
 #include <hip/hip_runtime.h>
 
