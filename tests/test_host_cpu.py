@@ -196,3 +196,33 @@ def test_empty_static_target_range_is_refused_like_the_reference():
         po.make_config("zelda", "narrow", (1, 5))
     build_config("zelda", "narrow", (2, 5))  # (5, 8): fine
     po.make_config("zelda", "narrow", (2, 5))
+
+
+def test_fuzzer_draws_only_configurations_the_engine_validates():
+    """tests/fuzz_parity.py's generator stays inside the accepted configuration space: every drawn case builds a config on
+    the host and passes pcgrl_create's validation (which runs before any HIP call: without a GPU the call then fails
+    with PCGRL_EHIP, never EINVAL / EUNSUPPORTED), or is refused by host and oracle alike (empty target ranges)."""
+    import ctypes as C
+    import fuzz_parity
+    from control_pcgrl_amd import _lib
+    from control_pcgrl_amd.vec_env import build_config
+    L = _lib.lib()
+    rng = np.random.default_rng(12345)
+    refused = 0
+    for i in range(400):
+        case = fuzz_parity.draw_case(rng)
+        kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items()}
+        try:
+            cfg, _, _ = build_config(case["problem"], case["rep"], tuple(case["shape"]), **kw)
+        except ValueError:
+            with pytest.raises(ValueError):
+                po.make_config(case["problem"], case["rep"], tuple(case["shape"]), **kw)
+            refused += 1
+            continue
+        po.make_config(case["problem"], case["rep"], tuple(case["shape"]), **kw)
+        h = C.c_void_p()
+        rc = L.pcgrl_create(C.byref(cfg), case["n_envs"], 0, C.byref(h))
+        assert rc not in (1, 2), (case, L.pcgrl_last_error())
+        if rc == 0:  # (a GPU is present after all)
+            L.pcgrl_destroy(h)
+    assert refused < 40
