@@ -45,7 +45,21 @@ ALGO_BYTES = {"binary-narrow": 4 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               "zelda-turtle-bfs": 4 + 257 + 32 * 32 * 9 + (4 + 1 + 28 + 2),
               # "solver-active" sokoban: playable levels (one player, k crates / targets, one region) so that the device
               # solver (engine.py BFS / A* cascade) runs inside the step launches
-              "sokoban-wide-solver": 4 + 257 + 16 * 16 * 5 + (4 + 1 + 28 + 0)}
+              "sokoban-wide-solver": 4 + 257 + 16 * 16 * 5 + (4 + 1 + 28 + 0),
+              # the reference's stock task configs off the 16x16 point: configs/task/binary_big.yaml:5-6,
+              # binary_bigger.yaml:5-6, zelda_big.yaml:5-6, configs/config.py:153-157 (MinecraftConfig 15^3, crop 30^3);
+              # same formula: action + map read / 1 B write + uint8 one-hot window + reward / done / stats / pos
+              "binary_big-narrow": 4 + (32 * 32 + 1) + 64 * 64 * 3 + (4 + 1 + 8 + 2),
+              "binary_bigger-narrow": 4 + (64 * 64 + 1) + 128 * 128 * 3 + (4 + 1 + 8 + 2),
+              "zelda_big-turtle": 4 + (32 * 32 + 1) + 64 * 64 * 9 + (4 + 1 + 28 + 2),
+              "minecraft_3D_maze-narrow-15": 4 + (15 ** 3 + 1) + 30 ** 3 * 4 + (4 + 1 + 12 + 3),
+              # evolution driver's call pattern (evo/evolve.py:1083-1120): n_cells x rep.update (+ observation), then one
+              # get_stats; per update: action + map read / 1 B write + observation + pos; the statistics pass adds
+              # (map read + stats) once per n_cells updates
+              "binary-narrow-evo": 4 + 257 + 32 * 32 * 3 + 2 + (256 + 8) / 256,
+              # Problem.get_stats on caller maps (pcgrl_stats_for_grids): map read + the statistics
+              "binary-stats-for-grids": 256 + 8,
+              "zelda-stats-for-grids": 256 + 28}
 # BASELINE.json configs: (problem, representation, map_shape, envs per GPU)
 WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtle": ("zelda", "turtle", (16, 16), 4096),
              "sokoban-wide": ("sokoban", "wide", (16, 16), 2048),
@@ -53,7 +67,13 @@ WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtl
              "binary-narrow-static": ("binary", "narrow", (16, 16), 4096, dict(static_prob=0.3, n_static_walls=3)),
              "binary-narrow-patch3x3": ("binary", "narrow", (16, 16), 4096, dict(act_window=[3, 3])),
              "zelda-turtle-bfs": ("zelda", "turtle", (16, 16), 4096),
-             "sokoban-wide-solver": ("sokoban", "wide", (16, 16), 2048)}
+             "sokoban-wide-solver": ("sokoban", "wide", (16, 16), 2048),
+             "binary_big-narrow": ("binary", "narrow", (32, 32), 4096), "binary_bigger-narrow": ("binary", "narrow", (64, 64), 4096),
+             "zelda_big-turtle": ("zelda", "turtle", (32, 32), 4096),
+             "minecraft_3D_maze-narrow-15": ("minecraft_3D_maze", "narrow", (15, 15, 15), 1024),
+             "binary-narrow-evo": ("binary", "narrow", (16, 16), 4096),
+             "binary-stats-for-grids": ("binary", "narrow", (16, 16), 65536),
+             "zelda-stats-for-grids": ("zelda", "narrow", (16, 16), 65536)}
 BFS_ACTIONS = [0, 1, 2, 3, 4 + 0, 4 + 1, 4 + 5, 4 + 6, 4 + 7]  # turtle moves, then empty / solid / bat / scorpion / spider
 
 
@@ -110,8 +130,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=-1, help="timed launches (default 20000; fewer for the big-map workloads)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed launches before them (default steps / 10)")
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's)")
     ap.add_argument("--workload", default="binary-narrow", choices=sorted(ALGO_BYTES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,18 +144,20 @@ def main():
                          "report it as `open_loop_rollout`; 0 = skip")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / sharding only (gloo, no GPU, nothing timed): what the CPU test of the N > 1 path runs")
+    ap.add_argument("--rllib-adapter", type=int, default=-1,
+                    help="1 / 0: time PcgrlVectorEnv.vector_step (the RLlib VectorEnv call shape, host arrays out) as the secondary "
+                         "object `rllib_adapter`; default: on for the headline workload")
     ap.add_argument("--rollout-launches", type=int, default=200, help="timed pcgrl_rollout launches of the secondary figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
-        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU
-        # (counting devices does not initialise them), and the ranks are ordinary child processes -- never an exec of a
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It never loads a GPU runtime (the device count
+        # comes from the kernel driver's topology files), and the ranks are ordinary child processes -- never an exec of a
         # process that holds a GPU.
         if not args.dry_run and not os.environ.get("PCGRL_BENCH_SINGLE_DEVICE"):
-            import torch
-            have = torch.cuda.device_count()
-            if args.gpus > have:
+            have = gpus_without_runtime()
+            if have is not None and args.gpus > have:
                 sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s): one rank per GPU, nothing was started")
         sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
@@ -191,7 +213,14 @@ def main():
     total_envs = N * world
     solver_active = args.workload == "sokoban-wide-solver"
     bfs_active = args.workload == "zelda-turtle-bfs" or solver_active  # "injected maps" workloads
-    env = VecPcgrlEnv(problem, rep, shape, N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world),
+    evo = args.workload.endswith("-evo")              # K x pcgrl_update (+ obs), one pcgrl_refresh_stats per n_cells updates
+    sfg = args.workload.endswith("-stats-for-grids")  # one pcgrl_stats_for_grids_h launch over N caller maps per step
+    if args.steps < 0:  # defaults sized so that a plain run finishes within a minute or two whatever the launch costs
+        K = args.steps = {"minecraft_3D_maze-narrow-15": 2000, "binary_bigger-narrow": 5000}.get(args.workload, 2000 if sfg else 20000)
+    if args.warmup < 0:
+        W = args.warmup = max(K // 10, 5)
+    # (stats-for-grids: the maps are the caller's; the engine behind the handle only lends its scratch)
+    env = VecPcgrlEnv(problem, rep, shape, 4096 if sfg else N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world)[:4096 if sfg else N],
                       auto_reset=not bfs_active, **wkw)
     inject = None
     if solver_active:
@@ -220,7 +249,35 @@ def main():
     base, stride = actions.data_ptr(), N * env.action_entries * 4
     step_raw = env.step_raw
 
+    EVO_K = int(np.prod(shape))  # evo/evolve.py:2054-2066: N_STEPS = max_changes = n_cells for narrow
+    sfg_maps = sfg_out = None
+    if sfg:  # maps with a density of their own each (what a population of generators hands to get_stats)
+        grng = np.random.default_rng(4242 + rank)
+        nt = env.spec.n_tiles
+        pr = grng.random((N, nt)) ** 2
+        pr /= pr.sum(1, keepdims=True)
+        u = grng.random((N, EVO_K))
+        sfg_host = (u[:, :, None] >= np.cumsum(pr, 1)[:, None, :]).sum(2).clip(0, nt - 1).astype(np.uint8)
+        sfg_maps = torch.as_tensor(sfg_host, device=dev).contiguous()
+        sfg_out = torch.empty((N, env.n_stats), dtype=torch.int32, device=dev)
+
     def run_eager(n, first=0):
+        if sfg:
+            for k in range(n):
+                rc = env._L.pcgrl_stats_for_grids_h(env._h, N, sfg_maps.data_ptr(), sfg_out.data_ptr(), sptr)
+                if rc:
+                    raise RuntimeError(f"pcgrl_stats_for_grids_h rc={rc}")
+            return
+        if evo:
+            for k in range(first, first + n):
+                rc = env._L.pcgrl_update(env._h, base + (k % POOL) * stride, env._ptrs[0], sptr)
+                if rc:
+                    raise RuntimeError(f"pcgrl_update rc={rc}")
+                if (k + 1) % EVO_K == 0:
+                    rc = env._L.pcgrl_refresh_stats(env._h, env._ptrs[3], sptr)
+                    if rc:
+                        raise RuntimeError(f"pcgrl_refresh_stats rc={rc}")
+            return
         if inject is None:  # n launches issued by one call into the library (a C host's loop: no per-launch ctypes cost)
             rc = env.step_seq_raw(base, stride // 4, POOL, first % POOL, n, sptr) if n > 0 else 0
             if rc:
@@ -240,6 +297,8 @@ def main():
     # (hipGraphUpload: no launch), so that the timed region is a single replay; the W warm-up steps are eager launches.
     G_short = K if 2 <= K <= 125 else 0
     G = args.graph_steps if args.graph_steps >= 0 else ((125 if K >= 250 else G_short) if inject is None else 0)
+    if evo or sfg:
+        G = 0
     graph = None
     if G > 0:
         # (thread-local capture mode: with N > 1 ranks the RCCL watchdog thread queries events while this thread captures;
@@ -298,7 +357,7 @@ def main():
 
     def measure_rollout():
         rollout = None
-        if GR > 0 and not wkw and not bfs_active and POOL >= GR:  # (bfs-active needs the periodic map injection)
+        if GR > 0 and not wkw and not bfs_active and not evo and not sfg and POOL >= GR:  # (bfs-active needs the periodic map injection)
             R = max(args.rollout_launches, 1)
             obs_r = torch.empty((GR, N) + env.obs_shape, dtype=torch.uint8, device=dev)
             rew_r = torch.empty((GR, N), dtype=torch.float32, device=dev)
@@ -369,7 +428,7 @@ def main():
         count (graph of 20 fills, HIP events).  At 13.7 MB (4096 binary envs) a fill ends after ~4.2 us = 0.40 of the
         8 TB/s spec peak -- launch ramp and drain of one short kernel -- and ~0.86 of it from 200 MB up.  Reported next to
         the roofline as context for `frac`; measured before the timed region; never `value`."""
-        nbytes = ALGO_BYTES[args.workload] * N
+        nbytes = int(ALGO_BYTES[args.workload] * N)
         if rank != 0 or nbytes > (8 << 30):
             return None
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -428,20 +487,25 @@ def main():
 
     if rank == 0:
         value = total_envs * K / elapsed
-        bytes_per_launch = ALGO_BYTES[args.workload] * N
+        bytes_per_launch = int(ALGO_BYTES[args.workload] * N)
         achieved = bytes_per_launch / (elapsed / K) / 1e9          # same clock as `value`
         achieved_ev = bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # HIP events around the K launches
         traffic, traffic_src = profiled_traffic(args.workload, N)
         out = {
             "metric": "env-steps/sec at N envs/GPU (binary 16x16), 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "maps/s" if sfg else "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, "
                                    + ("playable levels (one player, 1-3 crates / targets, one room) re-injected every 8 steps, floor / "
                                       "wall edits in and around the room, no auto-reset, " if solver_active else
                                       "injected maps with one player / key / door, random moves and empty / solid / enemy "
-                                      "placements, no auto-reset, " if bfs_active else "uniform random actions, auto-reset, ")
+                                      "placements, no auto-reset, " if bfs_active else
+                                      f"evolution-driver pattern (evo/evolve.py:1083-1120): one pcgrl_update launch (rep.update + observation) per "
+                                      f"step, one pcgrl_refresh_stats (get_stats) every {EVO_K} steps, uniform random actions, " if evo else
+                                      f"Problem.get_stats on {N} caller maps resident in HBM per launch (pcgrl_stats_for_grids_h, evo/evolve.py:1106-1115), "
+                                      "maps drawn with a tile distribution of their own each; a 'step' is one launch, value = maps/s, " if sfg else
+                                      "uniform random actions, auto-reset, ")
                                    + "uint8 one-hot obs (channel-last)",
                        "envs_per_gpu": N, "global_envs": total_envs, "episode_len": int(env.cfg.max_iterations) + 1,
                        # (SURVEY 8(d) says torch.randint per step; the action source is not the hot path, so the rows are drawn
@@ -453,7 +517,8 @@ def main():
                                        (shard_env_range(total_envs, r, world) for r in range(world))]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel",
+                         "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel (update_only)" if evo
+                         else "pcgrl::stats_for_grids_kernel" if sfg else "pcgrl::step_kernel",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "clock": "wall clock of the timed region / steps (the clock of `value`)",
                          "achieved_hip_events": achieved_ev, "frac_hip_events": achieved_ev / HBM_PEAK_GBS,
@@ -480,12 +545,36 @@ def main():
                                  "envs_with_one_player_at_end": (st[:, 0] == 1).float().mean().item()}
         if rollout is not None:
             out["open_loop_rollout"] = rollout
+        if args.rllib_adapter > 0 or (args.rllib_adapter < 0 and args.workload == "binary-narrow" and args.envs == 0):
+            out["rllib_adapter"] = rllib_adapter_bench(problem, rep, shape, dev)
         if not args.no_cpu_baseline:  # rank 0 only, also with N > 1 ranks (the others wait at the closing barrier)
-            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT)
+            out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT,
+                                               mode="evo" if evo else "sfg" if sfg else "step", maps=sfg_host if sfg else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def gpus_without_runtime():
+    """GPUs this process may use, counted from /sys/class/kfd (a node with simd_count > 0 is a GPU) and the *_VISIBLE_DEVICES
+    lists -- no HIP / HSA call, so the launcher stays a process that has never opened the GPU.  None = cannot tell."""
+    import glob
+    n = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    for f in files:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+        except Exception:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def launch_ranks(n):
@@ -527,6 +616,46 @@ def launch_ranks(n):
     return max(abs(rc) for rc in rcs)
 
 
+def rllib_adapter_bench(problem, rep, shape, dev, sizes=(20, 2000, 4096), seconds=0.7):
+    """The RLlib-shaped boundary (control_pcgrl_amd/rllib_env.py, the reference's fleet is 12 workers x 20 envs:
+    rl/utils.py:396-415): env-steps/s of vector_step + the reset_at calls RLlib makes for finished envs, host arrays out,
+    random actions from host memory.  Secondary figure, never `value`."""
+    import numpy as np
+    from control_pcgrl_amd.rllib_env import PcgrlVectorEnv
+    cfg = {"task": {"problem": problem, "map_shape": list(shape), "obs_window": None, "weights": None}, "representation": rep}
+    rows = []
+    for n in sizes:
+        for name, direct in (("float32", None), ("uint8", False), ("uint8", True)):
+            venv = PcgrlVectorEnv(cfg, num_envs=n, device=dev, seeds=1000 + np.arange(n), obs_dtype=np.dtype(name),
+                                  direct_host_outputs=direct)
+            venv.vector_reset()
+            rng = np.random.default_rng(5)
+            acts = [rng.integers(0, venv.vec.num_actions, size=n) for _ in range(16)]
+
+            def loop(limit):
+                t0 = time.perf_counter()
+                k = resets = 0
+                while time.perf_counter() - t0 < limit:
+                    obs, rew, done, trunc, infos = venv.vector_step(acts[k % 16])
+                    k += 1
+                    if any(done):
+                        for i in np.nonzero(done)[0]:
+                            venv.reset_at(int(i))
+                            resets += 1
+                return k, resets, time.perf_counter() - t0
+
+            loop(0.15)
+            k, resets, dt = loop(seconds)
+            rows.append({"envs": n, "obs_dtype": name, "env_steps_per_s": n * k / dt, "host_us_per_vector_step": dt / k * 1e6,
+                         "calls": k, "reset_at_calls": resets, "kernel_writes_host_memory": bool(venv._direct),
+                         "d2h_bytes_per_call": 0 if venv._direct else int(venv._total), "pinned_blocks": len(venv._free) + 1,
+                         "obs_bytes_handed_out_per_call": int(n * np.prod(venv.observation_space.shape) * np.dtype(name).itemsize)})
+            venv.close()
+    return {"unit": "env-steps/s", "what": "PcgrlVectorEnv.vector_step(actions) -> (obs list, rewards, dones, truncateds, infos) + reset_at for "
+            "finished envs; one pcgrl_step launch and one device->host copy per call (or none: kernel_writes_host_memory); the arrays "
+            "of a call are never rewritten (a pinned block of their own, recycled when they are garbage)", "rows": rows}
+
+
 def profiled_traffic(workload, n_envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r*_summary.json: WRITE_SIZE + 2 x FETCH_SIZE, see DESIGN.md section 5) and where the number comes from;
@@ -546,7 +675,8 @@ def profiled_traffic(workload, n_envs):
     return best
 
 
-def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=False, solver_active=False, reinject=128):
+def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=False, solver_active=False, reinject=128,
+                 mode="step", maps=None):
     """The oracle (a C port of the reference's algorithm, OpenMP over envs) on the host cores of this box:
     same workload, bounded sample."""
     import numpy as np
@@ -565,7 +695,39 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
         pass
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
+    def rate_sfg(threads, seconds):  # Problem.get_stats over the same maps, OpenMP over maps
+        t0 = time.perf_counter()
+        steps = 0
+        sub = maps[:max(2048, min(len(maps), 4096 * threads))]
+        while True:
+            po.stats_for_grids(problem, sub.reshape((len(sub),) + tuple(shape)), threads=threads)
+            steps += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+        return len(sub) * steps / dt, steps, dt
+
+    def rate_evo(threads, seconds):  # n_cells x rep.update (+ observation), then one get_stats, OpenMP over envs
+        orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads)
+        orc.reset()
+        period = int(np.prod(shape))
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            orc.update(acts[steps % 64])
+            steps += 1
+            if steps % period == 0:
+                orc.refresh_stats()
+            if steps >= 5 and time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+        return n_envs * steps / dt, steps, dt
+
     def rate(threads, seconds):
+        if mode == "sfg":
+            return rate_sfg(threads, seconds)
+        if mode == "evo":
+            return rate_evo(threads, seconds)
         orc = po.OracleVecEnv(problem, rep, shape, n_envs, seeds=0x5EED + np.arange(n_envs), threads=threads,
                               **(wkw or {}))
         maps = sa_maps if solver_active else (bfs_active_maps(n_envs, 77) if bfs_active else None)
@@ -615,10 +777,12 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
                 break
     except Exception:
         pass
-    return {"value": value, "unit": "env-steps/s", "cores": best_threads, "cpu_model": model, "usable_cores": avail,
-            "kind": "port", "one_core": one_core,
-            "sample": f"{steps} steps x {n_envs} envs of the same workload ({dt:.1f} s, OpenMP over envs with "
-                      f"{best_threads} threads of {avail} usable cores, obs encoded as uint8)"}
+    return {"value": value, "unit": "maps/s" if mode == "sfg" else "env-steps/s", "cores": best_threads, "cpu_model": model,
+            "usable_cores": avail, "kind": "port", "one_core": one_core,
+            "sample": (f"{steps} passes of Problem.get_stats over a {min(len(maps), 4096 * best_threads)}-map slice of the same maps "
+                       f"({dt:.1f} s, OpenMP over maps with {best_threads} threads of {avail} usable cores)" if mode == "sfg" else
+                       f"{steps} steps x {n_envs} envs of the same workload ({dt:.1f} s, OpenMP over envs with "
+                       f"{best_threads} threads of {avail} usable cores, obs encoded as uint8)")}
 
 
 if __name__ == "__main__":

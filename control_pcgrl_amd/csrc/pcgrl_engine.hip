@@ -427,6 +427,35 @@ __global__ __launch_bounds__(256) void masked_rows_copy_kernel(uint32_t *dst, co
 // sokoban: while the device solver has been running in recent launches, step with one env per wavefront (every search gets
 // a wave of its own); otherwise 64 / LPE envs share a wave.  The counter lives in host-mapped memory: reading it costs
 // nothing and may lag a launch or two, which only delays the switch.
+// sokoban: the solver's workspace pool is allocated at full size (one slot per four envs, sokoban_slots_for) the first time
+// the solver has been SEEN running, not at pcgrl_create: until then at most SK_SLOTS_AT_CREATE slots exist (searches
+// beyond the pool wait for a slot: speed, not results).  Synchronous (hipMalloc + a device synchronise), once per engine,
+// never while `stream` is being captured; launches issued earlier (or frozen in a HIP graph) keep using the pool they were
+// issued with, which stays allocated until pcgrl_destroy.
+static void soko_pool_for(pcgrl_engine *h, Params &p, int want, hipStream_t stream) {
+  if (!h->p.soko || h->soko_slots >= want) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream != nullptr && (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {
+    (void)hipGetLastError();
+    return;
+  }
+  Params grown = h->p;
+  int got = 0;
+  if (sokoban_alloc(grown, h->allocs, want, &got) == hipSuccess) {
+    h->p.soko = grown.soko;
+    p.soko = grown.soko;
+    h->soko_slots = got;
+  } else {
+    (void)hipGetLastError();
+    h->soko_slots = want;  // (out of memory: the engine keeps the pool it has and does not try again)
+  }
+}
+
+static void soko_pool_lazy(pcgrl_engine *h, Params &p, hipStream_t stream) {
+  if (!h->seen_host || h->soko_slots >= sokoban_slots_for(h->p.n_envs)) return;
+  if (*(volatile int32_t *)h->seen_host != 0) soko_pool_for(h, p, sokoban_slots_for(h->p.n_envs), stream);
+}
+
 static void choose_spread(pcgrl_engine *h, Params &p) {
   if (!h->seen_host || h->p.ext) return;
   static const int force = getenv("PCGRL_FORCE_SPREAD") ? atoi(getenv("PCGRL_FORCE_SPREAD")) : 0;  // development: 1 = spread, 2 = + helpers
@@ -552,7 +581,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     p.jump_b = djb;
   }
   if (cfg->problem == PCGRL_PROB_SOKOBAN) {
-    CREATE_CHK(sokoban_alloc(p, e->allocs, 64 / lpe, 0, &e->soko_slots));
+    CREATE_CHK(sokoban_alloc(p, e->allocs, std::min(SK_SLOTS_AT_CREATE, sokoban_slots_for(n_envs)), &e->soko_slots));
     CREATE_CHK(hipHostMalloc((void **)&e->seen_host, sizeof(int32_t), hipHostMallocMapped));
     *e->seen_host = 0;
     CREATE_CHK(hipHostGetDevicePointer((void **)&p.solver_seen, e->seen_host, 0));
@@ -621,6 +650,7 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
   if (!h) return fail(PCGRL_EINVAL, "pcgrl_reset: null handle");
   ON_DEVICE(h->device);
   Params p = h->p;
+  soko_pool_lazy(h, p, (hipStream_t)stream);
   p.mask = d_mask;
   p.init_grids = d_init_grids;
   p.init_pos = d_init_pos;
@@ -635,6 +665,7 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   ON_DEVICE(h->device);
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
+  soko_pool_lazy(h, p, (hipStream_t)stream);
   choose_spread(h, p);
   p.actions = d_actions;
   p.auto_reset = auto_reset;
@@ -666,6 +697,7 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_step_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
+  soko_pool_lazy(h, p, (hipStream_t)stream);
   choose_spread(h, p);
   p.actions = d_actions;
   p.auto_reset = auto_reset;
@@ -687,6 +719,7 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
   ON_DEVICE(h->device);
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
+  soko_pool_lazy(h, p, (hipStream_t)stream);
   p.actions = d_actions;
   p.n_steps = n_steps;
   p.auto_reset = auto_reset;
@@ -864,22 +897,18 @@ static int stats_engine_for(const pcgrl_config &cfg, int device, pcgrl_handle *o
 int pcgrl_stats_for_grids_h(pcgrl_handle h, int32_t n, const uint8_t *d_grids, int32_t *d_stats, void *stream) {
   if (!h || n < 1 || !d_grids || !d_stats) return fail(PCGRL_EINVAL, "pcgrl_stats_for_grids_h: bad arguments");
   ON_DEVICE(h->device);
-  if (h->p.soko) {
+  Params p;
+  {
     // One level per workgroup, at most one such workgroup per CU: up to 256 searches run at once, each in a workspace
-    // slot.  The pool is sized for the engine's own envs; a batch that is much larger gets a larger pool the first time
-    // (synchronous, up to 256 slots = 11.8 GB at the default solver_power; the old pool stays allocated until destroy:
-    // launches in flight on other streams keep using it).
-    const int need = std::min(256, sokoban_slots_for(n));
-    static std::mutex grow_mu;  // (the handle-less entry point shares its hidden engines between threads)
+    // slot.  A batch that is much larger than the pool gets a larger pool the first time (synchronous, up to 256 slots =
+    // 11.8 GB at the default solver_power; the old pool stays allocated until destroy: launches in flight on other streams
+    // keep using it).  The handle-less entry point shares its hidden engines between threads: the pool is grown and the
+    // launch parameters are read under one lock.
+    static std::mutex grow_mu;
     std::lock_guard<std::mutex> lock(grow_mu);
-    if (need > h->soko_slots) {
-      Params grown = h->p;
-      hipError_t e = sokoban_alloc(grown, h->allocs, 0, need, &h->soko_slots);
-      if (e != hipSuccess) return fail(PCGRL_EHIP, std::string("pcgrl_stats_for_grids_h: solver workspace: ") + hipGetErrorString(e));
-      h->p.soko = grown.soko;
-    }
+    p = h->p;
+    if (h->p.soko) soko_pool_for(h, p, std::min(256, sokoban_slots_for(n)), (hipStream_t)stream);
   }
-  Params p = h->p;
   p.n_envs = n;  // the kernel touches no per-env engine state
   p.init_grids = d_grids;
   p.stats_out = d_stats;
@@ -944,9 +973,40 @@ int pcgrl_set_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_grid
 
 static size_t state_section(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
+// The image starts with one 256-byte header section: what it was exported from.  pcgrl_import_state refuses an image whose
+// header does not match the importing engine (another config -- even one with the same byte size, e.g. other weights or
+// targets --, another batch size, another per-env layout / library version) instead of importing it silently.
+struct StateHeader {
+  uint64_t magic;        // "PCGRLST1"
+  uint64_t fingerprint;  // FNV-1a over the config fields, n_envs, the library version string and every array's bytes per env
+  int32_t n_envs, n_arrays;
+  uint64_t total_bytes;
+};
+static constexpr uint64_t STATE_MAGIC = 0x3154534c52474350ull;  // "PCGRLST1", little endian
+static constexpr size_t STATE_HDR_BYTES = 256;
+
+static uint64_t state_fingerprint(pcgrl_handle h) {
+  uint64_t x = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    for (size_t i = 0; i < n; i++) x = (x ^ ((const uint8_t *)p)[i]) * 1099511628211ull;
+  };
+  const pcgrl_config &c = h->p.cfg;  // field by field: the struct's padding bytes are not part of the config
+#define MIX(f) mix(&c.f, sizeof(c.f))
+  MIX(problem); MIX(representation); MIX(ndim); MIX(dims); MIX(obs_window); MIX(max_iterations); MIX(max_changes); MIX(n_stats);
+  MIX(has_trg); MIX(weights); MIX(trg_lo); MIX(trg_hi); MIX(solver_power); MIX(n_ctrl); MIX(ctrl_idx); MIX(ctrl_range);
+  MIX(act_window); MIX(static_tiles); MIX(n_static_walls); MIX(static_eval); MIX(static_prob);
+#undef MIX
+  const int32_t n = h->p.n_envs;
+  mix(&n, sizeof(n));
+  const char *v = pcgrl_version();
+  mix(v, strlen(v));
+  for (auto &a : h->state_arrays) mix(&a.second, sizeof(a.second));
+  return x;
+}
+
 int64_t pcgrl_state_bytes(pcgrl_handle h) {
   if (!h) return -1;
-  size_t total = 0;
+  size_t total = STATE_HDR_BYTES;
   for (auto &a : h->state_arrays) total += state_section(a.second * (size_t)h->p.n_envs);
   return (int64_t)total;
 }
@@ -954,7 +1014,12 @@ int64_t pcgrl_state_bytes(pcgrl_handle h) {
 int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out, void *stream) {
   if (!h || !d_buf) return fail(PCGRL_EINVAL, "pcgrl_export_state: bad arguments");
   ON_DEVICE(h->device);
-  size_t off = 0;
+  uint8_t hdr_bytes[STATE_HDR_BYTES] = {0};
+  StateHeader hdr{STATE_MAGIC, state_fingerprint(h), h->p.n_envs, (int32_t)h->state_arrays.size(), (uint64_t)pcgrl_state_bytes(h)};
+  memcpy(hdr_bytes, &hdr, sizeof(hdr));
+  // (pageable source: the runtime stages it before the call returns, so the stack buffer may go away)
+  HIPCHK(hipMemcpyAsync(d_buf, hdr_bytes, STATE_HDR_BYTES, hipMemcpyHostToDevice, (hipStream_t)stream));
+  size_t off = STATE_HDR_BYTES;
   for (auto &a : h->state_arrays) {
     const size_t bytes = a.second * (size_t)h->p.n_envs;
     HIPCHK(hipMemcpyAsync(d_buf + off, a.first, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -967,7 +1032,15 @@ int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out,
 int pcgrl_import_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_buf, int32_t maybe_stale, void *stream) {
   if (!h || !d_buf) return fail(PCGRL_EINVAL, "pcgrl_import_state: bad arguments");
   ON_DEVICE(h->device);
-  size_t off = 0;
+  // the header is checked on the host before anything is overwritten: one small copy and a wait for `stream`
+  StateHeader hdr{};
+  HIPCHK(hipMemcpyAsync(&hdr, d_buf, sizeof(hdr), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  if (hdr.magic != STATE_MAGIC) return fail(PCGRL_EINVAL, "pcgrl_import_state: not a pcgrl_export_state image (bad magic)");
+  if (hdr.n_envs != h->p.n_envs || hdr.n_arrays != (int32_t)h->state_arrays.size() || hdr.total_bytes != (uint64_t)pcgrl_state_bytes(h) ||
+      hdr.fingerprint != state_fingerprint(h))
+    return fail(PCGRL_EINVAL, "pcgrl_import_state: the image was exported by an engine with another config, batch size or library version");
+  size_t off = STATE_HDR_BYTES;
   for (auto &a : h->state_arrays) {
     const size_t bytes = a.second * (size_t)h->p.n_envs;
     if (d_mask == nullptr) {
@@ -1022,7 +1095,7 @@ int pcgrl_poll_error(pcgrl_handle h) {
     HIPCHK(hipMemset(h->p.err, 0, sizeof(flags)));
     if (flags[0] & 1) return fail(PCGRL_EACTION, "an action was outside the action space (the reference raises IndexError)");
     if (flags[0] & 2) return fail(PCGRL_EUNSUPPORTED, "sokoban solver: level exceeds the device solver's limits");
-    if (flags[0] & 4) return fail(PCGRL_EUNSUPPORTED, "3-D maze path search: more live queue entries than the search ring holds (1024 for planes of <= 64 cells, else 4096); the statistics of that step were kept at their previous values");
+    if (flags[0] & 4) return fail(PCGRL_EUNSUPPORTED, "3-D maze path search: more live queue entries than the search ring holds (512 for planes of <= 64 cells, else 4096); the statistics of that step were kept at their previous values and are recomputed from scratch at the env's next changing step");
     if (flags[0] & 8)
       return fail(PCGRL_ESTALE, "a step launch issued before pcgrl_update (a replayed HIP graph?) met statistics that pcgrl_update "
                                 "left stale: re-capture after pcgrl_update or call pcgrl_refresh_stats first (include/pcgrl_amd.h, HIP graphs)");

@@ -965,6 +965,7 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
     }
   }
   M3_MARK(3, 6);  // path searches (incl. the search loops counted in [3])
+  if (overflow) return;  // reported by the caller; the overlay and the statistics stay those of the last finished update
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
   // path tile (x,y,z) is drawn at array index [x][y][z]
   for (int i = c.lane; i < c.L.nw; i += 64) c.over[i] = 0;
@@ -1401,6 +1402,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
     const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;
     const size_t N = (size_t)p.n_envs;
     bool any_reset = false, whole_record = false, edited = false, mv_chg = false, upd_exit = false, over_dirty = false;
+    bool ovf_any = false;
     int mv_cell = 0, col_word = 0;
     for (int k = 0; k < K; k++) {
       const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
@@ -1486,6 +1488,16 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
         if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
           for (int i = 0; i < NS; i++) st[i] = st_old[i];
       }
+      if (ovf) {
+        // The kept statistics are those of the map BEFORE this edit and the unfinished search leaves nothing usable behind:
+        // every cached start plane is dropped and the env is marked stale, so the next step that changes the map recomputes
+        // region count and paths from scratch instead of updating a count that no longer belongs to the map.
+        if (c.lane < n_slots) *(uint4 *)c.hdr(c.lane) = make_uint4(0u, 0u, 0u, 0u);
+        dirty_hdr = (1u << n_slots) - 1u;
+        flags |= ENV_STATS_DIRTY;
+        ovf_any = true;
+        ovf = false;  // (rollout: the later steps of the launch are judged on their own)
+      }
       const double loss = trg.loss(p.cfg, st);
       const double rew = loss - last_loss;
       last_loss = loss;
@@ -1519,7 +1531,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
         if (want_obs) m3_encode_obs<D7>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       }
     }
-    if (ovf && c.lane == 0) atomicOr(p.err, 4);
+    if ((ovf || ovf_any) && c.lane == 0) atomicOr(p.err, 4);
     // ---- write back, once the observe wave has read the old state
     if (HELP && c.lane == 0) m3_st(&mail.exit, 1);
     if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();

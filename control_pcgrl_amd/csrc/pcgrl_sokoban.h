@@ -1183,16 +1183,15 @@ static inline int sokoban_slots_for(int n_levels) {  // one slot per four levels
   const int want = (n_levels + 3) / 4;
   return want < 4 ? 4 : (want > 512 ? 512 : want);
 }
-// min_slots: at least that many slots (pcgrl_stats_for_grids_h grows the pool of a small engine for a large batch)
-static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int envs_per_wave, int min_slots = 0,
-                                       int *n_slots_out = nullptr) {
+constexpr int SK_SLOTS_AT_CREATE = 64;  // pool of an engine whose solver has not been seen running yet (2.9 GB)
+// A pool of n_slots workspace slots (the engine grows it: pcgrl_engine.hip soko_pool_for).
+static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int n_slots, int *n_slots_out = nullptr) {
   SokoPool pool;
-  // A slot = SK_STAGES stage workspaces (~11 MB each at the default solver_power: 46 MB per slot).  One slot per four
-  // envs of the batch, between 4 (a single-env adapter or an RLlib worker's small engine pins 0.18 GB, not 2.9) and 512
-  // (23 GB in all at 2048 envs: the 288 GB of HBM are there to be used); searches beyond the pool wait for a slot.
-  (void)envs_per_wave;
-  pool.n_slots = sokoban_slots_for(p.n_envs);
-  if (min_slots > pool.n_slots) pool.n_slots = min_slots;
+  // A slot = SK_STAGES stage workspaces (~11 MB each at the default solver_power: 46 MB per slot).  Full size: one slot
+  // per four envs of the batch, between 4 (a single-env adapter or an RLlib worker's small engine pins 0.18 GB, not 2.9)
+  // and 512 (23 GB in all at 2048 envs); searches beyond the pool wait for a slot.  pcgrl_create allocates at most
+  // SK_SLOTS_AT_CREATE of them: most workloads (random rollouts) hardly ever meet the solver's precondition.
+  pool.n_slots = n_slots < 1 ? 1 : n_slots;
   if (n_slots_out) *n_slots_out = pool.n_slots;
   pool.max_nodes = 4 * (p.cfg.solver_power > 0 ? p.cfg.solver_power : 1) + 8;
   const size_t vis_off = SK_NODE_BYTES * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);

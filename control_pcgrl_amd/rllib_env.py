@@ -5,9 +5,13 @@ The reference trains with RLlib workers that each hold `num_envs_per_worker` gym
 `register_env('pcgrl', make_env)`); RLlib wraps them in a `VectorEnv` and drives it with
 `vector_reset / reset_at / vector_step / get_sub_environments`.  `PcgrlVectorEnv` is that object for the
 whole worker batch at once: ONE engine, one `pcgrl_step` launch and ONE device->host copy per `vector_step`
-(observations, rewards, dones and stats share a packed buffer).  Every call hands out FRESH numpy arrays: RLlib's
-collectors keep references to the observations they are given and stack them later, so nothing a call returned is ever
-written again.
+(observations, rewards, dones and stats share a packed buffer).  Nothing a call returned is ever written again: RLlib's
+collectors keep references to the observations they are given and stack them later.  The arrays of a call live in a
+pinned host block of their own, which the device->host copy fills directly (no staging copy, no conversion on the host:
+`obs_dtype=np.float32` converts on the device, `obs_dtype=np.uint8` hands out the engine's bytes as they are); the
+block goes back to a free list when the last array over it has been garbage-collected, so a steady-state loop
+allocates nothing.  Small batches (the reference's 20 envs per worker) skip the copy as well: the step kernel writes
+its outputs straight into the pinned block over PCIe (`direct_host_outputs`).
 
     register_env("pcgrl", lambda env_config: PcgrlVectorEnv(env_config, num_envs=env_config["num_envs_per_worker"]))
 
@@ -25,6 +29,8 @@ whole batch with `set_trgs`) and take effect at that env's next reset (:168-178)
 ray is not required: with ray installed the class derives from `ray.rllib.env.vector_env.VectorEnv`, otherwise
 it is a plain object with the same methods (which is how the tests drive it).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -60,9 +66,9 @@ class _SubEnv:
     metrics = _rep_stats
 
     def set_trgs(self, trgs):
-        """ControlWrapper.set_trgs (control_wrappers.py:168-172) for this env: applied at its next reset"""
+        """ControlWrapper.set_trgs (control_wrappers.py:168-172) for this env: queued, and like the reference's
+        _ctrl_trg_queue (:174-178) `metric_trgs` only changes when the env's next reset applies them"""
         self._p.set_trgs(trgs, index=self._i)
-        self.metric_trgs.update(trgs)
 
 
 class _Infos:
@@ -88,14 +94,52 @@ class _Infos:
         return (self[i] for i in range(self._n))
 
 
+class _Lease:
+    """One hand-out of a pinned host block.  numpy arrays made over it (np.asarray(lease) and every view of that) keep
+    the lease alive; when the last of them is gone the block returns to the free list it came from."""
+    __slots__ = ("__array_interface__", "block", "ptr", "_free", "__weakref__")
+
+    def __init__(self, block, free):
+        self.block, self._free, self.ptr = block, free, block.data_ptr()
+        self.__array_interface__ = {"data": (self.ptr, False), "shape": (block.numel(),), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self._free.append(self.block)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+_hip = None
+
+
+def _hip_runtime():
+    """hipMemcpyAsync / hipStreamSynchronize of the runtime torch has loaded (a ctypes call costs ~1 us, the torch
+    wrappers ~10): plumbing of the device->host copy, nothing else."""
+    global _hip
+    if _hip is None:
+        lib = C.CDLL("libamdhip64.so")
+        lib.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        lib.hipMemcpyAsync.restype = C.c_int
+        lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+        lib.hipStreamSynchronize.restype = C.c_int
+        _hip = lib
+    return _hip
+
+
 class PcgrlVectorEnv(_Base):
-    def __init__(self, cfg=None, num_envs=1, device="cuda:0", seeds=None, vec: VecPcgrlEnv = None, obs_dtype=np.float32):
+    DIRECT_MAX_BYTES = 1 << 20  # default: the step kernel writes into host memory itself when a call's outputs are <= 1 MiB
+
+    def __init__(self, cfg=None, num_envs=1, device="cuda:0", seeds=None, vec: VecPcgrlEnv = None, obs_dtype=np.float32,
+                 direct_host_outputs=None):
         self.vec = vec if vec is not None else make_vec_env(cfg, num_envs, device=device, seeds=seeds, auto_reset=False)
         v = self.vec
         assert not v.auto_reset, "PcgrlVectorEnv drives resets itself (RLlib calls reset_at)"
         self.num_envs = v.num_envs
         self.n_ctrl_planes = 2 * len(v.controls)
         self.obs_dtype = np.dtype(obs_dtype if not self.n_ctrl_planes else np.float32)  # (control planes are fractions)
+        if self.obs_dtype not in (np.dtype(np.float32), np.dtype(np.uint8)):
+            raise ValueError("obs_dtype must be float32 (the reference's declared Box dtype) or uint8 (the engine's bytes)")
         shape = v.obs_shape[:-1] + (v.obs_shape[-1] + self.n_ctrl_planes,)
         # wrappers.py:113-123 ToImage: Box(0, max over the stacked spaces) = Box(0, 1) for the one-hot map; the control
         # planes are declared [0, 1] by the reference too (control_wrappers.py:96-104) although metric / range may exceed it
@@ -108,51 +152,82 @@ class PcgrlVectorEnv(_Base):
         if _Base is not object:  # pragma: no cover
             super().__init__(self.observation_space, self.action_space, self.num_envs)
         N, S = self.num_envs, v.n_stats
-        ob = int(np.prod(v.obs_shape))
-        self._ob_shape = v.obs_shape
+        self._out_shape = (N,) + shape
+        ob_out = int(np.prod(shape)) * self.obs_dtype.itemsize  # bytes per env as handed out
 
-        # packed output buffers: [obs N*ob | reward N*4 | stats N*S*4 | done N | ctrl N*2K*4] (16-byte aligned sections),
-        # device + pinned host; one set for vector_step, one for the batched reset
+        # one packed block per call: [obs | reward N*4 | stats N*S*4 | done N | ctrl N*2K*4], 16-byte aligned sections
         def up(x):
             return (x + 15) & ~15
 
-        o_rew = up(N * ob)
-        o_stats = o_rew + up(N * 4)
-        o_done = o_stats + up(N * S * 4)
-        o_ctrl = o_done + up(N)
-        total = o_ctrl + up(N * max(self.n_ctrl_planes, 1) * 4)
-
-        def buffers():
-            dev = torch.zeros(total, dtype=torch.uint8, device=v.device)
-            host = torch.zeros(total, dtype=torch.uint8).pin_memory()
-            h = host.numpy()
-            views = dict(obs=h[0:N * ob].reshape((N,) + v.obs_shape), rew=h[o_rew:o_rew + N * 4].view(np.float32),
-                         stats=h[o_stats:o_stats + N * S * 4].view(np.int32).reshape(N, S), done=h[o_done:o_done + N].view(np.bool_),
-                         ctrl=h[o_ctrl:o_ctrl + N * max(self.n_ctrl_planes, 1) * 4].view(np.float32).reshape(N, -1))
-            base = dev.data_ptr()
-            ptrs = dict(obs=base, rew=base + o_rew, stats=base + o_stats, done=base + o_done, ctrl=base + o_ctrl)
-            return dev, host, views, ptrs
-
-        self._sdev, self._shost, self._s, self._sp = buffers()  # step
-        self._rdev, self._rhost, self._r, self._rp = buffers()  # reset
+        self._o_rew = up(N * ob_out)
+        self._o_stats = self._o_rew + up(N * 4)
+        self._o_done = self._o_stats + up(N * S * 4)
+        self._o_ctrl = self._o_done + up(N)
+        self._total = self._o_ctrl + up(N * max(self.n_ctrl_planes, 1) * 4)
+        self._free = []  # pinned host blocks no array refers to any more
+        self._dev = torch.zeros(self._total, dtype=torch.uint8, device=v.device)
+        base = self._dev.data_ptr()
+        self._dp = dict(obs=base, rew=base + self._o_rew, stats=base + self._o_stats, done=base + self._o_done, ctrl=base + self._o_ctrl)
+        self._convert = self.obs_dtype != np.dtype(np.uint8)
+        if self._convert:  # the engine's uint8 observation -> float32 (+ control planes in front) on the device
+            self._obs_u8 = torch.empty((N,) + v.obs_shape, dtype=torch.uint8, device=v.device)
+            self._obs_out = self._dev[:N * ob_out].view(torch.float32).view(self._out_shape)
+            self._ctrl_dev = self._dev[self._o_ctrl:self._o_ctrl + N * max(self.n_ctrl_planes, 1) * 4].view(torch.float32).view(N, -1)
+            self._engine_obs = self._obs_u8.data_ptr()
+        else:
+            self._engine_obs = self._dp["obs"]
+        if direct_host_outputs is None:
+            direct_host_outputs = self._total <= self.DIRECT_MAX_BYTES
+        self._direct = bool(direct_host_outputs) and not self._convert
+        self._hip = _hip_runtime()
         self._act = torch.zeros((N, v.action_entries), dtype=torch.int32).pin_memory()
-        self._act_dev = torch.zeros((N, v.action_entries), dtype=torch.int32, device=v.device)
+        self._act_np = self._act.numpy()
+        # small batches: the kernel reads the actions from pinned host memory itself (no host->device copy to issue)
+        self._act_dev = self._act if self._direct else torch.zeros((N, v.action_entries), dtype=torch.int32, device=v.device)
         self._stats = np.zeros((N, S), np.int32)  # the envs' current statistics (sub-env accessors)
         self._pending = np.zeros(N, np.bool_)   # finished, waiting for RLlib's reset_at
         self._fresh = np.zeros(N, np.bool_)     # already reset by the batched launch, reset_at only hands the obs out
-        self._reset_obs = None                  # observations of the last batched reset (fresh array per reset)
+        self._reset_obs = None                  # observations of the last batched reset (a block of their own)
         self._iter = np.zeros(N, np.int64)
         self._subs = [_SubEnv(self, i) for i in range(N)]
+        self._queued_trgs = {}  # env index -> targets set since its last reset
 
     # -- helpers -----------------------------------------------------------------------------------
-    def _observations(self, views):
-        """a NEW array [N, H, W, C (+ control planes)] from the pinned staging buffer"""
-        o = views["obs"].astype(self.obs_dtype)
-        if not self.n_ctrl_planes:
-            return o
-        planes = np.broadcast_to(views["ctrl"][:, :self.n_ctrl_planes].reshape((self.num_envs,) + (1,) * (o.ndim - 2) + (-1,)),
-                                 o.shape[:-1] + (self.n_ctrl_planes,))
-        return np.concatenate((planes.astype(self.obs_dtype), o), axis=-1)  # control planes first (:210)
+    def _lease(self):
+        return _Lease(self._free.pop() if self._free else torch.empty(self._total, dtype=torch.uint8).pin_memory(), self._free)
+
+    def _views(self, lease):
+        """numpy views of a call's block (they keep the lease, and so the block, alive)"""
+        h = np.asarray(lease)
+        N, S = self.num_envs, self.vec.n_stats
+        return dict(obs=h[:N * int(np.prod(self._out_shape[1:])) * self.obs_dtype.itemsize].view(self.obs_dtype).reshape(self._out_shape),
+                    rew=h[self._o_rew:self._o_rew + N * 4].view(np.float32),
+                    stats=h[self._o_stats:self._o_stats + N * S * 4].view(np.int32).reshape(N, S),
+                    done=h[self._o_done:self._o_done + N].view(np.bool_))
+
+    def _finish(self, lease, stream):
+        """device-side conversion if any, the call's one device->host copy (unless the kernels wrote into the block
+        themselves), and the wait for it"""
+        if self._convert:
+            K2 = self.n_ctrl_planes
+            if K2:
+                self._obs_out[..., :K2] = self._ctrl_dev[:, :K2].reshape((self.num_envs,) + (1,) * (len(self._out_shape) - 2) + (K2,))
+                self._obs_out[..., K2:] = self._obs_u8  # control planes first (control_wrappers.py:210)
+            else:
+                self._obs_out.copy_(self._obs_u8)
+        if not self._direct:
+            rc = self._hip.hipMemcpyAsync(lease.ptr, self._dev.data_ptr(), self._total, 2, stream)  # 2 = hipMemcpyDeviceToHost
+            if rc:
+                raise RuntimeError(f"hipMemcpyAsync: error {rc}")
+        rc = self._hip.hipStreamSynchronize(stream)
+        if rc:
+            raise RuntimeError(f"hipStreamSynchronize: error {rc}")
+
+    def _out_ptrs(self, lease):
+        if not self._direct:
+            return self._engine_obs, self._dp["rew"], self._dp["stats"], self._dp["done"], self._dp["ctrl"]
+        b = lease.ptr
+        return b, b + self._o_rew, b + self._o_stats, b + self._o_done, b + self._o_ctrl
 
     def stats_dict(self, i):
         return {k: int(x) for k, x in zip(self.vec.stat_keys, self._stats[i])}
@@ -173,24 +248,30 @@ class PcgrlVectorEnv(_Base):
             mask = np.zeros(self.num_envs, np.uint8)
             mask[int(index)] = 1
         self.vec.queue_targets({k: (x if isinstance(x, tuple) else float(x)) for k, x in trgs.items()}, mask=mask)
+        for i in (range(self.num_envs) if index is None else (int(index),)):
+            self._queued_trgs.setdefault(i, {}).update(trgs)
 
     def _masked_reset(self, mask):
-        """one launch for every env in `mask`; results go to the reset staging buffers and, for the masked envs only, into
-        the current statistics"""
+        """one launch for every env in `mask`; the observations go to a block of their own and, for the masked envs only,
+        the statistics into the current ones"""
         v = self.vec
         m = torch.as_tensor(mask.astype(np.uint8), device=v.device)
         L, s = v._L, v._stream()
         from . import _lib
+        lease = self._lease()
+        obs_p, _, stats_p, _, ctrl_p = self._out_ptrs(lease)
         _lib.check(L.pcgrl_reset(v._h, m.data_ptr(), None, None, s), "pcgrl_reset")
-        _lib.check(L.pcgrl_observe(v._h, self._rp["obs"], s), "pcgrl_observe")
-        _lib.check(L.pcgrl_get_state(v._h, None, None, None, self._rp["stats"], None, None, s), "pcgrl_get_state")
+        _lib.check(L.pcgrl_observe(v._h, obs_p, s), "pcgrl_observe")
+        _lib.check(L.pcgrl_get_state(v._h, None, None, None, stats_p, None, None, s), "pcgrl_get_state")
         if self.n_ctrl_planes:
-            _lib.check(L.pcgrl_ctrl_observe(v._h, self._rp["ctrl"], s), "pcgrl_ctrl_observe")
-        self._rhost.copy_(self._rdev, non_blocking=True)
-        torch.cuda.current_stream(v.device).synchronize()
-        self._reset_obs = self._observations(self._r)
-        self._stats[mask] = self._r["stats"][mask]
+            _lib.check(L.pcgrl_ctrl_observe(v._h, ctrl_p, s), "pcgrl_ctrl_observe")
+        self._finish(lease, s)
+        r = self._views(lease)
+        self._reset_obs = r["obs"]
+        self._stats[mask] = r["stats"][mask]
         self._iter[mask] = 0
+        for i in [i for i in self._queued_trgs if mask[i]]:  # the queued targets are the envs' targets from here on
+            self._subs[i].metric_trgs.update(self._queued_trgs.pop(i))
 
     # -- VectorEnv API -----------------------------------------------------------------------------
     def vector_reset(self, *, seeds=None, options=None):
@@ -221,28 +302,29 @@ class PcgrlVectorEnv(_Base):
         v = self.vec
         a = np.asarray(actions, dtype=np.int64).reshape(self.num_envs, v.action_entries)
         hi = v.spec.n_tiles if v.act_window else v.num_actions
-        if (a < 0).any() or (a >= hi).any():
+        if a.min() < 0 or a.max() >= hi:
             raise IndexError("action outside the action space")  # the reference raises IndexError from numpy indexing
-        self._act.numpy()[...] = a
-        self._act_dev.copy_(self._act, non_blocking=True)
-        p = self._sp
+        self._act_np[...] = a
+        s = v._stream()
+        if not self._direct:
+            self._act_dev.copy_(self._act, non_blocking=True)
+        lease = self._lease()
+        obs_p, rew_p, stats_p, done_p, ctrl_p = self._out_ptrs(lease)
         if self.n_ctrl_planes:
-            rc = v._L.pcgrl_step_ex(v._h, self._act_dev.data_ptr(), 0, p["obs"], p["rew"], None, p["done"], p["stats"], p["ctrl"],
-                                    v._stream())
+            rc = v._L.pcgrl_step_ex(v._h, self._act_dev.data_ptr(), 0, obs_p, rew_p, None, done_p, stats_p, ctrl_p, s)
         else:
-            rc = v._L.pcgrl_step(v._h, self._act_dev.data_ptr(), 0, p["obs"], p["rew"], p["done"], p["stats"], v._stream())
+            rc = v._L.pcgrl_step(v._h, self._act_dev.data_ptr(), 0, obs_p, rew_p, done_p, stats_p, s)
         if rc:
             from . import _lib
             _lib.check(rc, "pcgrl_step")
-        self._shost.copy_(self._sdev, non_blocking=True)  # the one device -> host copy of the call
-        torch.cuda.current_stream(v.device).synchronize()
-        obs = self._observations(self._s)
-        self._stats[...] = self._s["stats"]
+        self._finish(lease, s)  # the one device -> host copy of the call
+        r = self._views(lease)
+        self._stats[...] = r["stats"]
         self._iter += 1
-        self._pending |= self._s["done"]
+        self._pending |= r["done"]
         self._fresh[:] = False
-        done = self._s["done"].tolist()
-        return list(obs), self._s["rew"].tolist(), done, list(done), _Infos(self, self._stats.copy(), self._iter.copy())
+        done = r["done"].tolist()
+        return list(r["obs"]), r["rew"].tolist(), done, list(done), _Infos(self, r["stats"], self._iter.copy())
 
     def get_sub_environments(self):
         return self._subs

@@ -251,7 +251,11 @@ int pcgrl_poll_error(pcgrl_handle h);
  *   pcgrl_state_bytes   size of the buffer
  *   pcgrl_export_state  d_buf uint8 [pcgrl_state_bytes]; *maybe_stale_out (host, may be NULL) = 1 when statistics left
  *                       stale by pcgrl_update may be among them -- hand it back to pcgrl_import_state
- *   pcgrl_import_state  into an engine created with the same config and batch size; d_mask uint8 [N] (NULL = all envs)
+ *   pcgrl_import_state  into an engine created with the same config and batch size; d_mask uint8 [N] (NULL = all envs).
+ *                       The image starts with a 256-byte header (magic, fingerprint of every config field + batch size +
+ *                       library version + per-env layout); an image from any other engine is refused with PCGRL_EINVAL
+ *                       before anything is overwritten.  Reading the header waits for `stream` once (the only
+ *                       synchronising call among the state entry points; not to be captured in a HIP graph).
  * The buffer is an opaque image for this library version and config; pcgrl_get_state / pcgrl_set_state remain the
  * portable (maps, positions, counters) form. */
 int64_t pcgrl_state_bytes(pcgrl_handle h);

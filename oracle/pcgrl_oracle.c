@@ -372,15 +372,23 @@ static void get_stats(const orc_config *cfg, const uint8_t *g, int32_t *st, int1
   }
 }
 
-void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out) {
+void orc_stats_for_grids_mt(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out, int32_t threads) {
   int cells = cfg->dims[0] * cfg->dims[1] * (cfg->ndim == 3 ? cfg->dims[2] : 1);
-  int16_t *path = (int16_t *)malloc(sizeof(int16_t) * 3 * (size_t)(cells * 4 + 8));
-  for (int i = 0; i < n; i++) {
-    int32_t st[ORC_MAX_STATS] = {0}, pl = 0;
-    get_stats(cfg, grids + (size_t)i * cells, st, path, &pl);
-    for (int k = 0; k < cfg->n_stats; k++) stats_out[(size_t)i * cfg->n_stats + k] = st[k];
+#pragma omp parallel num_threads(threads < 1 ? 1 : threads)
+  {
+    int16_t *path = (int16_t *)malloc(sizeof(int16_t) * 3 * (size_t)(cells * 4 + 8));
+#pragma omp for schedule(dynamic, 16)
+    for (int i = 0; i < n; i++) {
+      int32_t st[ORC_MAX_STATS] = {0}, pl = 0;
+      get_stats(cfg, grids + (size_t)i * cells, st, path, &pl);
+      for (int k = 0; k < cfg->n_stats; k++) stats_out[(size_t)i * cfg->n_stats + k] = st[k];
+    }
+    free(path);
   }
-  free(path);
+}
+
+void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out) {
+  orc_stats_for_grids_mt(cfg, n, grids, stats_out, 1);
 }
 
 /* control_wrappers.py:318-345 get_loss: sum over static targets of -w * distance(value, target). */
@@ -773,6 +781,7 @@ void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t
 
 void orc_update(orc_engine *e, const int32_t *actions, uint8_t *obs) {
   int64_t osz = orc_obs_size(e);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(e->n_threads)
   for (int i = 0; i < e->n_envs; i++) {
     env_t *v = &e->envs[i];
     (void)rep_update(e, v, actions + (size_t)i * e->n_act);
@@ -782,6 +791,7 @@ void orc_update(orc_engine *e, const int32_t *actions, uint8_t *obs) {
 
 void orc_refresh_stats(orc_engine *e, int32_t *stats) {
   const orc_config *cfg = &e->cfg;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(e->n_threads)
   for (int i = 0; i < e->n_envs; i++) {
     env_t *v = &e->envs[i];
     get_stats(cfg, v->grid, v->stats, v->path_xyz, &v->path_len);

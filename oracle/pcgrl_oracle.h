@@ -95,6 +95,8 @@ void orc_get_ctrl_obs(orc_engine *e, double *out);
 
 /* Stateless Problem.get_stats() on n grids. */
 void orc_stats_for_grids(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out);
+/* the same, OpenMP over maps (bench.py's cpu_baseline leg of the evolution-pattern workloads) */
+void orc_stats_for_grids_mt(const orc_config *cfg, int32_t n, const uint8_t *grids, int32_t *stats_out, int32_t threads);
 
 /* StaticTileRepresentation.static_tiles per env: uint8 [N][(H+2)*(W+2)] (bordered shape, wrappers.py:267) */
 void orc_get_static(orc_engine *e, uint8_t *out);

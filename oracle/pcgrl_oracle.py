@@ -125,6 +125,7 @@ def lib():
         L.orc_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.orc_get_last_episode.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.orc_stats_for_grids.argtypes = [C.POINTER(OrcConfig), C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_stats_for_grids_mt.argtypes = [C.POINTER(OrcConfig), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L.orc_queue_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_get_ctrl_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -311,14 +312,14 @@ class OracleVecEnv:
         return dict(ep_return=ret, ep_len=ln, final_stats=fs, n_episodes=ne)
 
 
-def stats_for_grids(problem, grids, map_shape=None, solver_power=10000):
+def stats_for_grids(problem, grids, map_shape=None, solver_power=10000, threads=1):
     grids = np.ascontiguousarray(grids, dtype=np.uint8)
     if map_shape is None:
         map_shape = grids.shape[1:]
     cfg = make_config(problem, "narrow", map_shape, solver_power=solver_power)
     n = grids.shape[0]
     out = np.empty((n, cfg.n_stats), np.int32)
-    lib().orc_stats_for_grids(C.byref(cfg), n, grids.ctypes.data, out.ctypes.data)
+    lib().orc_stats_for_grids_mt(C.byref(cfg), n, grids.ctypes.data, out.ctypes.data, int(threads))
     return out
 
 

@@ -331,6 +331,15 @@ def test_sokoban_wide_2048_envs_vs_oracle():
     _rollout_vs_oracle("sokoban", "wide", (16, 16), 2048, 400, seed0=77, full_every=131, threads=16, change_percentage=0.2)
 
 
+def test_sokoban_wide_2048_envs_as_benchmarked_vs_oracle():
+    """BASELINE configs[3] EXACTLY as bench.py runs it: 2048 envs, bench.py's seeds, no change budget, the reference's
+    solver_power (10 000, sokoban_prob.py:40), uniform random wide actions, 800 steps across the in-kernel auto-reset
+    (episode = 770 steps): statistics, reward and done of every step against the oracle (sokoban_prob.py:160-180); the
+    solver runs where the random maps after a reset happen to satisfy its precondition (:172-177)."""
+    n_done = _rollout_vs_oracle("sokoban", "wide", (16, 16), 2048, 800, seed0=0x5EED, full_every=131, threads=16)
+    assert n_done == 2048
+
+
 @pytest.mark.parametrize("problem,rep", [("binary", "turtle"), ("binary", "wide"), ("zelda", "narrow"),
                                          ("zelda", "wide"), ("sokoban", "narrow"), ("sokoban", "turtle"),
                                          ("sokoban", "wide")])
@@ -1230,15 +1239,19 @@ def test_rllib_vector_env_adapter_matches_golden(name):
     env.close()
 
 
-def test_rllib_vector_env_adapter_never_rewrites_what_it_returned():
+@pytest.mark.parametrize("obs_dtype,direct", [(np.float32, None), (np.uint8, False), (np.uint8, True)],
+                         ids=["float32", "uint8-copy", "uint8-kernel-writes-host"])
+def test_rllib_vector_env_adapter_never_rewrites_what_it_returned(obs_dtype, direct):
     """RLlib's collectors keep references to the observations / infos a call returned and stack them later: neither the
     next vector_step nor a reset_at (which RLlib calls inside its per-env loop, before it has consumed the other envs'
-    last observations) may change them."""
+    last observations) may change them -- in every hand-out mode (float32 converted on the device, the engine's uint8
+    copied into a pinned block, the kernel writing into the pinned block itself)."""
     from control_pcgrl_amd import PcgrlVectorEnv
     cfg = {"task": {"problem": "binary", "map_shape": [16, 16], "obs_window": [32, 32], "weights": None},
            "representation": "narrow", "change_percentage": 0.02}
     n = 5
-    env = PcgrlVectorEnv(cfg, num_envs=n, seeds=list(range(n)))
+    env = PcgrlVectorEnv(cfg, num_envs=n, seeds=list(range(n)), obs_dtype=obs_dtype, direct_host_outputs=direct)
+    assert env._direct == bool(direct)
     obs0, _ = env.vector_reset()
     keep0 = [o.copy() for o in obs0]
     rng = np.random.default_rng(0)
@@ -1256,7 +1269,46 @@ def test_rllib_vector_env_adapter_never_rewrites_what_it_returned():
     for live, copy, infos, info_copy in kept:
         assert all(np.array_equal(a, b) for a, b in zip(live, copy)), "a later call rewrote a returned observation"
         assert [dict(infos[i]) for i in range(n)] == info_copy, "a later call changed a returned info"
+        assert live[0].dtype == np.dtype(obs_dtype)
+    # ... and once the caller has dropped them, their pinned blocks are reused: a steady-state loop allocates nothing
+    del kept, live, copy, infos, info_copy, obs, obs0, o
+    import gc
+    gc.collect()
+    blocks = len(env._free)
+    assert blocks >= 60
+    for t in range(50):
+        env.vector_step(rng.integers(0, 2, n).tolist())
+    assert len(env._free) == blocks, "blocks of dropped results are recycled, none were added"
     env.close()
+
+
+def test_rllib_vector_env_adapter_hand_out_modes_agree():
+    """the three hand-out modes of PcgrlVectorEnv return the same observations / rewards / dones / infos (2 000 envs, past
+    an episode end with reset_at)"""
+    from control_pcgrl_amd import PcgrlVectorEnv
+    cfg = {"task": {"problem": "zelda", "map_shape": [16, 16], "obs_window": [32, 32], "weights": None},
+           "representation": "turtle", "change_percentage": 0.05}
+    n = 300
+    envs = [PcgrlVectorEnv(cfg, num_envs=n, seeds=list(range(n)), obs_dtype=d, direct_host_outputs=k)
+            for d, k in ((np.float32, None), (np.uint8, False), (np.uint8, True))]
+    first = [e.vector_reset()[0] for e in envs]
+    assert all(np.array_equal(np.stack(first[0]).astype(np.uint8), np.stack(f)) for f in first[1:])
+    rng = np.random.default_rng(3)
+    n_reset = 0
+    for t in range(120):
+        a = rng.integers(0, 12, n)
+        outs = [e.vector_step(a) for e in envs]
+        ref = outs[0]
+        for o in outs[1:]:
+            assert np.array_equal(np.stack(ref[0]).astype(np.uint8), np.stack(o[0])) and ref[1] == o[1] and ref[2] == o[2]
+            assert dict(ref[4][7]) == dict(o[4][7])
+        for i in np.nonzero(ref[2])[0]:
+            rs = [e.reset_at(int(i))[0] for e in envs]
+            assert all(np.array_equal(rs[0].astype(np.uint8), r) for r in rs[1:])
+            n_reset += 1
+    assert n_reset > 0
+    for e in envs:
+        e.close()
 
 
 def test_rllib_vector_env_adapter_controllable_and_rep_wrappers():

@@ -9,8 +9,12 @@ export TMPDIR=/tmp
 cd /tmp
 for W in $WORKLOADS; do
   S=3000; P=1000
-  if [ "$W" = "minecraft_3D_maze-narrow" ]; then S=1500; P=500; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${W}_kt -- python3 $R/bench.py --workload $W --steps $S --warmup 300 --no-cpu-baseline --rollout-launches 20 > $R/gpurun_out/prof_${W}_kt.log 2>&1
+  case "$W" in
+    minecraft_3D_maze-narrow) S=1500; P=500;;
+    binary_big*|zelda_big*|*stats-for-grids) S=1000; P=300;;
+    binary_bigger*|minecraft_3D_maze-narrow-15) S=600; P=200;;
+  esac
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${W}_kt -- python3 $R/bench.py --workload $W --steps $S --warmup 100 --no-cpu-baseline --rollout-launches 20 > $R/gpurun_out/prof_${W}_kt.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${W}_fetch -- python3 $R/bench.py --workload $W --steps $P --warmup 100 --no-cpu-baseline --rollout-steps 0 > $R/gpurun_out/prof_${W}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${W}_write -- python3 $R/bench.py --workload $W --steps $P --warmup 100 --no-cpu-baseline --rollout-steps 0 > $R/gpurun_out/prof_${W}_write.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/prof_${W}_sq -- python3 $R/bench.py --workload $W --steps $P --warmup 100 --no-cpu-baseline --rollout-steps 0 > $R/gpurun_out/prof_${W}_sq.log 2>&1

@@ -19,8 +19,9 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 sys.path.insert(0, ROOT)
-ENVS = {"binary-narrow": 4096, "zelda-turtle": 4096, "sokoban-wide": 2048, "minecraft_3D_maze-narrow": 1024,
-        "zelda-turtle-bfs": 4096, "sokoban-wide-solver": 2048}
+import bench  # noqa: E402
+
+ENVS = {w: v[3] for w, v in bench.WORKLOADS.items()}  # envs per GPU of every bench workload
 
 
 def first(pattern):
@@ -33,13 +34,12 @@ def short(name):
 
 
 def is_m3_step(name):
-    return "m3_kernel<0" in name or "m3_kernel<(pcgrl::M3Mode)0" in name  # (<0>, <0, true>: the 7x7x7 variant)
+    return "m3_kernel<0" in name or "m3_kernel<(pcgrl::M3Mode)0" in name  # (<0, SC>, <0, 0, true>: the 7x7x7 variant)
 
 
 def summarize(w, stats_rows):
-    import bench
     out = {}
-    dom = "m3_kernel" if "3D" in w else "step_kernel"
+    dom = "m3_kernel" if "3D" in w else "stats_for_grids_kernel" if "stats-for-grids" in w else "step_kernel"
     ks = first(f"prof_{w}_kt/**/*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
@@ -52,7 +52,7 @@ def summarize(w, stats_rows):
     kt = first(f"prof_{w}_kt/**/*kernel_trace.csv")
     if kt:
         rows = [r for r in csv.DictReader(open(kt)) if dom in r["Kernel_Name"]
-                and (is_m3_step(r["Kernel_Name"]) or dom == "step_kernel")]
+                and (is_m3_step(r["Kernel_Name"]) or dom != "m3_kernel")]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # (the trace is not always written in time order)
         if len(rows) > 2:
             gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
@@ -65,6 +65,9 @@ def summarize(w, stats_rows):
                 "workgroup": int(r0["Workgroup_Size_X"]), "lds_bytes": int(r0.get("LDS_Block_Size", 0) or 0),
                 "vgpr": int(r0.get("VGPR_Count", 0) or 0), "sgpr": int(r0.get("SGPR_Count", 0) or 0),
                 "scratch_bytes": int(r0.get("Scratch_Size", 0) or 0),
+                # every resource column the trace carries, verbatim (the meaning of VGPR_Count / LDS_Block_Size differs between
+                # rocprofv3 versions: arch VGPRs only, static LDS only -- profiles/<tag>_kernel_resources.txt has the compiler's)
+                "trace_resource_columns": {k: r0[k] for k in r0 if any(t in k for t in ("VGPR", "SGPR", "LDS", "Scratch", "Private", "Group"))},
                 "median_gap_between_launches_ns": statistics.median(gaps),
                 "duration_ns": {"p10": q(0.1), "median": q(0.5), "p90": q(0.9), "p99": q(0.99), "mean": statistics.mean(durs)},
                 "median_start_to_start_ns": statistics.median(periods)}
@@ -80,7 +83,7 @@ def summarize(w, stats_rows):
         for (k, c), v in agg.items():
             counters[k][c] = {"mean_per_launch": statistics.mean(v), "launches": len(v)}
     out["pmc"] = counters
-    step = next((k for k in counters if dom in k and (is_m3_step(k) or dom == "step_kernel")), None)
+    step = next((k for k in counters if dom in k and (is_m3_step(k) or dom != "m3_kernel")), None)
     n = ENVS.get(w, 0)
     if step:
         c = counters[step]
@@ -90,7 +93,7 @@ def summarize(w, stats_rows):
             # step kernel's store pattern): factor 1.00.
             wr = c["WRITE_SIZE"]["mean_per_launch"] * 1024
             rd = c.get("FETCH_SIZE", {"mean_per_launch": 0})["mean_per_launch"] * 1024
-            algo = bench.ALGO_BYTES[w] * n
+            algo = int(bench.ALGO_BYTES[w] * n)
             out["hbm_traffic_per_launch"] = {"write_bytes": wr, "fetch_bytes_raw": rd, "fetch_bytes_x2_correction": 2 * rd,
                                              "traffic_bytes": wr + 2 * rd, "algorithmic_bytes": algo,
                                              "traffic_over_algorithmic": (wr + 2 * rd) / algo}
