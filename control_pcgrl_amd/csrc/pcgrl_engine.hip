@@ -535,6 +535,23 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   // one padded observation row per lane + the OOB row (+ 2 rows per env of the wave with the static_builds plane)
   // (+ 64 bytes per env of the wave: the observe wave's copy of the RNG streams, see step_kernel)
   e->lds_bytes = (size_t)(obs_chunks * 16 + 32) * (65 + (cfg->static_tiles ? 16 : 0)) + 64 * 8;  // (+32: lds_row_stride may add a chunk)
+  {
+    // Cropped windows whose rows are whole 16-byte chunks, off the compile-time 16x16 / 32x32 point, without the static
+    // tiles' extra channel: the general kernels compute the observation chunks from one code byte per cell
+    // (encode_obs_codes) -- per env H rows of W + 20 bytes (rounded to 16) instead of H one-hot rows
+    const int Hc = cfg->dims[0], Wc = cfg->dims[1], OWc = cfg->obs_window[1], Cc = p.n_tiles + 1;
+    const bool fast_cfg = Hc == 16 && Wc == 16 && cfg->obs_window[0] == 32 && OWc == 32;
+    // (only where the one-hot rows are what limits occupancy: at 13 KB per workgroup -- binary 32 x 32 -- the rows are
+    // cheaper: 14.0 vs 15.6 us per launch; at 26 KB -- binary 64 x 64 -- 67 vs 47.5; at 38 KB -- zelda 32 x 32 -- 44 vs 27.6)
+    if (!is3d && cfg->representation != PCGRL_REP_WIDE && !cfg->static_tiles && !fast_cfg && (OWc * Cc) % 16 == 0 &&
+        e->lds_bytes > 20000) {
+      const int rs = (Wc + 8 + 12 + 15) & ~15;
+      const int epw = 64 / lpe;
+      p.obs_codes = rs;
+      e->lds_bytes = (size_t)epw * Hc * rs + rs + (size_t)Cc * 48 + 64 * 8;
+      e->lds_bytes = (e->lds_bytes + 15) & ~(size_t)15;
+    }
+  }
   p.lds_pair_bytes = (int32_t)e->lds_bytes;
   e->cpl = is3d ? (p.n_cells + 63) / 64 : 0;
   const int H = cfg->dims[0], W = cfg->dims[1];

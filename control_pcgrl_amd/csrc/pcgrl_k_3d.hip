@@ -8,7 +8,7 @@ template <int SC>
 static hipError_t launch_3d_sc(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
   switch (id) {
-    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(SC == 0 ? 192 : 128), 0, s, p, cpl); break;  // simulate + observe (+ helper) wave
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())), 0, s, p, cpl); break;  // simulate + observe (+ helper) waves
     case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET, SC>), grid, block, 0, s, p, cpl); break;
     case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE, SC>), grid, block, 0, s, p, cpl); break;
     case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE, SC>), grid, block, 0, s, p, cpl); break;

@@ -1052,6 +1052,32 @@ __device__ inline void store_obs16(void *dst, uint4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
 }
 
+// The env's observation as `total` consecutive 16-byte chunks, lane r of the group taking chunks r, r + LPE, ...: every store
+// instruction covers LPE * 16 contiguous bytes.  Chunk k = chunk k % CH of observation row k / CH, read from the LDS row
+// row_ptr(k / CH).  Four chunks per trip: their LDS reads are issued together (the store is an asm statement with a memory
+// clobber, so nothing moves across it by itself) and the row index comes from one fp32 multiply instead of an integer
+// division (floor((k + 0.5) / CH) is exact in fp32 for k < 2^20).
+template <int LPE, typename RowFn>
+__device__ inline void stream_obs_chunks(const Grp<LPE> &g, uint8_t *base, int total, int CH, RowFn row_ptr) {
+  const float inv_ch = 1.0f / (float)CH;
+  int k = g.row;
+  for (; k + 3 * LPE < total; k += 4 * LPE) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int kk = k + j * LPE;
+      const int i = (int)(((float)kk + 0.5f) * inv_ch), q = kk - i * CH;
+      v[j] = *(const uint4 *)(row_ptr(i) + q * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) store_obs16(base + (size_t)(k + j * LPE) * 16, v[j]);
+  }
+  for (; k < total; k += LPE) {
+    const int i = (int)(((float)k + 0.5f) * inv_ch), q = k - i * CH;
+    store_obs16(base + (size_t)k * 16, *(const uint4 *)(row_ptr(i) + q * 16));
+  }
+}
+
 // Observation rows that are not a multiple of 16 bytes (e.g. the reference's zelda_small task: 22 pixels x 9 channels =
 // 198 bytes): the env's observation is streamed as one byte string of n_rows * RB bytes, byte k taken from the LDS row
 // row_ptr(k / RB) at offset k % RB -- dwords when the env size allows aligned ones, bytes otherwise.  Plain stores.
@@ -1110,6 +1136,111 @@ __device__ inline uint4 oob_chunk_rt(int q) {
   }
 }
 
+// ---- observation chunks from tile codes (general kernels, cropped window; Params::obs_codes) ------------------------------
+// The one-hot rows of encode_obs cost OW * C bytes of LDS per map row (38 KB per workgroup at 32 x 32 zelda, 26 KB at
+// 64 x 64 binary), which leaves a CU with 4-6 workgroups and a launch with two or three rounds of them.  Here a map row is
+// kept as ONE BYTE PER CELL (Cropped's integer map: 1 + tile, 0 = outside the map; wrappers.py:407-437) with 8 zero bytes
+// in front and 12 behind, and every 16-byte chunk of the observation (wrappers.py:232-257: byte = [code == channel]) is computed by
+// the lane that stores it: the 8 codes its bytes can come from (three aligned dwords + two v_alignbyte), then per output
+// dword one v_perm_b32 (which code each byte looks at), one xor with the channel each byte stands for, and a zero-byte
+// test (x + 0x7f7f7f7f has bit 7 of a byte clear iff the byte was 0; codes and channels are < 16).  Which code / channel
+// belongs to a byte depends only on the chunk's phase (16 q) mod C: a 48-byte entry per phase in LDS (selectors,
+// channels, the all-out-of-bounds chunk).  LDS per env: H * (W + 20) bytes -- 2 KB instead of 19 at 32 x 32 zelda.
+__device__ inline uint32_t onehot_bytes(uint32_t x) {  // per byte: 1 if the byte of x is 0, else 0 (bytes < 0x80)
+  return (~(x + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
+}
+// bits x0 .. x0+3 of a row mask (x0 may be negative or beyond the mask: those bits are 0)
+template <typename M>
+__device__ inline uint32_t nibble_at(M v, int x0) {
+  constexpr int BITS = (int)(8 * sizeof(M));
+  if (x0 >= BITS || x0 <= -4) return 0u;
+  return (uint32_t)(x0 >= 0 ? (v >> x0) : (v << (-x0))) & 0xFu;
+}
+__device__ inline uint32_t spread4(uint32_t n) {  // bit i of a nibble -> bit 0 of byte i
+  return (n * 0x204081u) & 0x01010101u;  // (n < 16: the compiler picks v_mul_u32_u24)
+}
+
+template <int PROB, int LPE, typename M>
+__device__ inline void encode_obs_codes(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
+                                        uint8_t *lds, uint8_t *obs_base) {
+  constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB, C = NT + 1, EPW = 64 / LPE;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1], OH = p.cfg.obs_window[0], OW = p.cfg.obs_window[1];
+  const int CH = p.obs_chunks, RS = p.obs_codes;
+  constexpr int PAD = 8;  // zero bytes in front of a code row (a chunk reads 8 codes from window column j0 on)
+  uint8_t *rows = lds + (size_t)(g.lane / LPE) * H * RS;  // this env's code rows
+  uint8_t *zero_row = lds + (size_t)EPW * H * RS;         // what a window row above / below the map reads
+  uint32_t *table = (uint32_t *)(zero_row + RS);          // [C][12]: byte selectors, channels, out-of-bounds chunk
+  // ---- this lane's map row as codes: [8 zeros][1 + tile per cell][>= 12 zeros]
+  if (g.row < H) {
+    const M inmap = W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1));
+    uint8_t *row = rows + g.row * RS;
+    for (int o = 0; o < RS; o += 16) {
+      uint32_t w[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int x0 = o + 4 * t - PAD;  // map column of the dword's first byte
+        uint32_t v = 0;
+        if (x0 > -4 && x0 < W) {
+          v = spread4(nibble_at<M>(inmap, x0));
+#pragma unroll
+          for (int k = 0; k < NB; k++) v += spread4(nibble_at<M>(b[k] & inmap, x0)) << k;
+        }
+        w[t] = v;
+      }
+      *(uint4 *)(row + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  for (int o = g.lane * 16; o < RS; o += 64 * 16) *(uint4 *)(zero_row + o) = make_uint4(0, 0, 0, 0);
+  if (g.lane < C) {  // phase r0 = (first byte of the chunk) mod C
+    const int r0 = g.lane;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t sel = 0, ch = 0, oob = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int k = r0 + 4 * w + t, d = k / C, c = k - d * C;  // byte 4w+t: code d of the eight, channel c
+        sel |= (uint32_t)d << (8 * t);
+        ch |= (uint32_t)c << (8 * t);
+        oob |= (uint32_t)(c == 0) << (8 * t);
+      }
+      table[r0 * 12 + w] = sel;
+      table[r0 * 12 + 4 + w] = ch;
+      table[r0 * 12 + 8 + w] = oob;
+    }
+  }
+  // ---- the env's observation as consecutive 16-byte chunks, lane r of the group taking chunks r, r + LPE, ...
+  const int top = pos[0] - OH / 2, left = pos[1] - OW / 2;
+  const int total = active ? OH * CH : 0;
+  uint8_t *base = obs_base + (size_t)env * OH * OW * C;
+  const float inv_ch = 1.0f / (float)CH;  // floor((k + 0.5) / CH) is exact in fp32 for k < 2^20
+  auto chunk = [&](int k) -> uint4 {
+    const int i = (int)(((float)k + 0.5f) * inv_ch), q = k - i * CH;
+    const int j0 = (q * 16) / C, r0 = q * 16 - j0 * C;  // first window column of the chunk, phase
+    const int m = i + top;
+    const bool valid = (unsigned)m < (unsigned)H;
+    const uint32_t *t = table + r0 * 12;
+    if (__ballot(valid) == 0) return *(const uint4 *)(t + 8);  // every lane is above / below the map
+    // the chunk's 8 codes are map columns x0 .. x0+7 of row m: all zero (the zero row) when the row is above / below the
+    // map or the columns lie wholly left / right of it
+    const int x0 = j0 + left, xb = x0 + PAD;
+    const bool inside = valid && (unsigned)(x0 + 7) < (unsigned)(W + 7);
+    const uint32_t *src = (const uint32_t *)(inside ? rows + m * RS + (xb & ~3) : zero_row);
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(xb & 3));
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)(xb & 3));
+    const uint4 sel = *(const uint4 *)t, ch = *(const uint4 *)(t + 4);
+    return make_uint4(onehot_bytes(__builtin_amdgcn_perm(hi, lo, sel.x) ^ ch.x), onehot_bytes(__builtin_amdgcn_perm(hi, lo, sel.y) ^ ch.y),
+                      onehot_bytes(__builtin_amdgcn_perm(hi, lo, sel.z) ^ ch.z), onehot_bytes(__builtin_amdgcn_perm(hi, lo, sel.w) ^ ch.w));
+  };
+  int k = g.row;
+  for (; k + LPE < total; k += 2 * LPE) {  // two chunks per trip: their LDS reads are in flight together
+    const uint4 v0 = chunk(k), v1 = chunk(k + LPE);
+    store_obs16(base + (size_t)k * 16, v0);
+    store_obs16(base + (size_t)(k + LPE) * 16, v1);
+  }
+  if (k < total) store_obs16(base + (size_t)k * 16, chunk(k));
+}
+
 // FAST: map 16x16 with a 32x32 window (the reference's default obs_window = 2 * map_shape): every map row is
 // visible, every map cell lands inside the window, each lane writes exactly one map row and one all-OOB row,
 // and every loop bound is a compile-time constant.
@@ -1139,11 +1270,8 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
       // store instruction covers LPE * 16 contiguous bytes (whole cache lines; lane-per-row stores left every line to be
       // written piecewise by several instructions, which write-through stores turn into 2 x the HBM write traffic)
       uint8_t *base = obs_base + (size_t)env * H * row_bytes;
-      const int stride = lds_row_stride(row_bytes), total = H * chunks;
-      for (int k = g.row; k < total; k += LPE) {
-        const int i = k / chunks, q = k - i * chunks;
-        store_obs16(base + (size_t)k * 16, *(const uint4 *)(lds + (g.gbase + i) * stride + q * 16));
-      }
+      const int stride = lds_row_stride(row_bytes), gb = g.gbase;
+      stream_obs_chunks(g, base, H * chunks, chunks, [&](int i) -> const uint8_t * { return lds + (gb + i) * stride; });
     }
     return;
   }
@@ -1155,6 +1283,12 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
   // 16-byte chunks (lane r takes chunks r, r+LPE, ...), i.e. 256 contiguous bytes per group per store instruction,
   // picking each chunk from the LDS row of the lane that owns that map row or from the OOB row.
   constexpr int C = NT + 1;
+  if constexpr (!FAST) {
+    if (p.obs_codes > 0) {  // big maps: chunks computed from tile codes, a fraction of the LDS (see encode_obs_codes)
+      encode_obs_codes<PROB, LPE, M>(g, p, env, active, b, pos, lds, obs_base);
+      return;
+    }
+  }
   constexpr int FW = 16, FOW = 32, FOH = 32;
   const int OH = FAST ? FOH : p.cfg.obs_window[0], OW = FAST ? FOW : p.cfg.obs_window[1];
   const int CW = FAST ? FW : W;
@@ -1210,12 +1344,11 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
         return (unsigned)m < (unsigned)H ? lds + (gb + m) * STRIDE : oob_row;
       });
     } else {
-      for (int k = g.row; k < total; k += LPE) {
-        int i = k / CH, q = k - i * CH;
-        int m = i + top;
-        const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
-        store_obs16(base + (size_t)k * 16, *(const uint4 *)src);
-      }
+      const int gb = g.gbase;
+      stream_obs_chunks(g, base, total, CH, [&](int i) -> const uint8_t * {
+        const int m = i + top;
+        return (unsigned)m < (unsigned)H ? lds + (gb + m) * STRIDE : oob_row;
+      });
     }
   }
 }
@@ -1454,15 +1587,11 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
       });
       return;
     }
-    const float inv_ch = 1.0f / (float)CH;  // floor((k + 0.5) / CH) is exact in fp32 for k < 2^20
-    for (int k = g.row; k < total; k += LPE) {
-      const int i = (int)(((float)k + 0.5f) * inv_ch), q = k - i * CH;
+    const int gb = g.gbase;
+    stream_obs_chunks(g, base, total, CH, [&](int i) -> const uint8_t * {
       const int m = i + top;
-      const uint8_t *src = (unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE
-                           : (m == H || m == H + 1) ? xrows + (m - H) * STRIDE
-                                                    : oob_row;
-      store_obs16(base + (size_t)k * 16, *(const uint4 *)(src + q * 16));
-    }
+      return (unsigned)m < (unsigned)H ? lds + (gb + m) * STRIDE : ((m == H || m == H + 1) ? xrows + (m - H) * STRIDE : oob_row);
+    });
   }
 }
 

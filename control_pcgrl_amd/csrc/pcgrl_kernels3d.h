@@ -247,9 +247,13 @@ template <int SC>
 struct M3Env {
   alignas(16) uint32_t rec[M3C<SC>::REC + 4];
 };
+// observe wavefronts of a pcgrl_step workgroup.  Size class 1 keeps 147 KB of LDS per env, i.e. ONE workgroup per CU, and
+// its observation is 108 KB at 15^3: three waves share its chunks (16.7 us per env on one wave).
 template <int SC>
-struct M3ObsLds {  // the observe wave's own copy of the tile and overlay bits + the row masks of its encoder
-  alignas(16) uint32_t bits[2 * M3C<SC>::NW + 2];
+constexpr int m3_observers() { return SC == 0 ? 1 : 3; }
+template <int SC>
+struct M3ObsLds {  // each observe wave's own copy of the tile and overlay bits + the (shared) row masks of the encoder
+  alignas(16) uint32_t bits[m3_observers<SC>()][2 * M3C<SC>::NW + 2];
   uint2 rows[SC == 0 ? 16 * 16 + 1 : 32 * 32 + 1];
 };
 
@@ -1041,13 +1045,14 @@ __device__ inline void m3_encode_obs_cells(const uint32_t *dirt, const uint32_t 
 // W14: the BASELINE window 14 x 14 x 14 with compile-time sizes.
 template <bool W14>
 __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over, const M3Ctx &c, const Params &p, int env, const int *pos,
-                                     bool show_path, uint2 *scratch, int scratch_rows, uint8_t *obs_base = nullptr) {
+                                     bool show_path, uint2 *scratch, int scratch_rows, uint8_t *obs_base = nullptr, int part = 0,
+                                     int nparts = 1) {
   if (p.obs == nullptr) return;
   if (obs_base == nullptr) obs_base = p.obs;
   const int o0 = W14 ? 14 : p.cfg.obs_window[0], o1 = W14 ? 14 : p.cfg.obs_window[1], o2 = W14 ? 14 : p.cfg.obs_window[2];
   const int rows = o0 * o1;
   if (!W14 && (rows + 1 > scratch_rows || o2 > 32 || o2 < 2)) {  // (o2 == 1: a chunk of 4 cells spans 4 rows, pass 2 reads 2)
-    m3_encode_obs_cells(dirt, over, c, p, env, pos, show_path, obs_base);
+    if (part == 0) m3_encode_obs_cells(dirt, over, c, p, env, pos, show_path, obs_base);
     return;
   }
   const int total = rows * o2, chunks = total >> 2;
@@ -1075,7 +1080,10 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
     const uint32_t in = inb ? (uint32_t)xin & omask : 0u;
     scratch[r] = make_uint2(in & (~(uint32_t)db | (uint32_t)ob), in & ((uint32_t)db | (uint32_t)ob));
   }
-  for (int ch = c.lane; ch < chunks; ch += 64) {
+  // (`part` of `nparts`: several observe waves share the chunks -- every wave computes all row masks above, identical
+  // values into the shared scratch, and reads them after its own writes.)  Four chunks per trip: the store is an asm
+  // statement with a memory clobber, so the LDS reads of the next chunk do not move above it by themselves.
+  auto chunk = [&](int ch) -> uint4 {
     const int q0 = ch * 4;
     const int r = (int)(((float)q0 + 0.5f) * inv2), k0 = q0 - r * o2;
     const uint2 ra = scratch[r], rb = scratch[r + 1];
@@ -1083,8 +1091,18 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
     uint32_t w[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) w[t] = 1u << (8 * (((uint32_t)(m0 >> t) & 1u) + 2u * ((uint32_t)(m1 >> t) & 1u)));
-    store_obs16(dst + ch, make_uint4(w[0], w[1], w[2], w[3]));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  const int stride = 64 * nparts;
+  int ch = c.lane + 64 * part;
+  for (; ch + 3 * stride < chunks; ch += 4 * stride) {
+    const uint4 v0 = chunk(ch), v1 = chunk(ch + stride), v2 = chunk(ch + 2 * stride), v3 = chunk(ch + 3 * stride);
+    store_obs16(dst + ch, v0);
+    store_obs16(dst + ch + stride, v1);
+    store_obs16(dst + ch + 2 * stride, v2);
+    store_obs16(dst + ch + 3 * stride, v3);
   }
+  for (; ch < chunks; ch += stride) store_obs16(dst + ch, chunk(ch));
 }
 
 // reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order) into `dirt`.
@@ -1136,11 +1154,29 @@ __device__ inline void m3_advance_pos(const M3Ctx &c, int *pos, int &n_step) {
   n_step++;
 }
 
+// global -> LDS copy of 16-byte words [from, to): B loads per lane are issued before the first of them is stored
+template <int B>
+__device__ inline void m3_copy_batched(uint4 *dst, const uint4 *src, int from, int to, int lane) {
+  for (int base = from; base < to; base += 64 * B) {
+    uint4 r[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const int i = base + lane + 64 * b;
+      r[b] = i < to ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const int i = base + lane + 64 * b;
+      if (i < to) dst[i] = r[b];
+    }
+  }
+}
+
 // D7: the BASELINE map shape 7 x 7 x 7 and observation window 14 x 14 x 14 with compile-time dimensions (the search trip
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
 // HELP (pcgrl_step, size class 0): a third wavefront runs second searches speculatively, see SPECULATION.
 template <int MODE, int SC, bool D7 = false>
-__global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void m3_kernel(Params p, int cpl) {
+__global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())) : 64) void m3_kernel(Params p, int cpl) {
   constexpr int PW = M3C<SC>::PW;
   constexpr bool HELP = MODE == M3_STEP && SC == 0;
   if (MODE == M3_STEP) touch_kernarg(p);  // every line of the argument block in one scalar-memory round trip
@@ -1194,11 +1230,15 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
   }
   if constexpr (MODE == M3_STEP) {
     // ------------------------------------------------------------------------------------------ observe wave
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) {  // (readfirstlane: a scalar branch)
+    constexpr int NOBS = m3_observers<SC>();
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (readfirstlane: scalar branches)
+    if (wave_id >= 1 && wave_id <= NOBS) {
       if (p.obs == nullptr) return;  // (the simulate wave skips the barrier in that case, too)
+      const int part = wave_id - 1;  // this wave's share of the observation's chunks
+      uint32_t *obits = O.bits[part];
       // everything this wave needs of the old state is requested at once; an auto-reset replays the env's RNG streams in
       // both waves, so it takes its copy of them, too
-      for (int i = c.lane; i < 2 * nw; i += 64) O.bits[i] = grec[i];
+      for (int i = c.lane; i < 2 * nw; i += 64) obits[i] = grec[i];
       int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
       int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
       const int action = p.actions[env];
@@ -1206,7 +1246,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
       Pcg rp, rr;
       rp.load(p.rng[env].prob);
       rr.load(p.rng[env].rep);
-      uint32_t *odirt = O.bits, *oover = O.bits + nw;
+      uint32_t *odirt = obits, *oover = obits + nw;
       iteration += upd_only ? 0 : 1;
       bool change = false;
       if (action >= 0 && action < 2) {
@@ -1221,9 +1261,9 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
       if (done && p.auto_reset != 0) {  // first observation of the new episode: no overlay (PcgrlEnv.reset)
         m3_reset_rng(odirt, c, p, cpl, rp, rr);
         pos[0] = pos[1] = pos[2] = 0;
-        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, false, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)));
+        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, false, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)), nullptr, part, NOBS);
       } else {
-        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, true, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)));
+        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, true, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)), nullptr, part, NOBS);
       }
       TRACE_PUT(4, _tr0);
       TRACE_PUT(3, TRACE_NOW());
@@ -1396,7 +1436,20 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 128) : 64) void 
         if (i < c.L.rec_words / 4) ((uint4 *)E.rec)[i] = rch[k];
       }
     } else {
-      for (int i = c.lane; i < c.L.rec_words / 4; i += 64) ((uint4 *)E.rec)[i] = ((const uint4 *)grec)[i];
+      // Size class 1: the record is 49 KB at 15^3, most of it the move table and the cached start planes, which only a step
+      // that CHANGES the map reads (statistics are recomputed only then, pcgrl_env.py:314-323; an auto-reset rebuilds every
+      // table from the new map, but writes the whole record back, so it takes the old one, too).  The tile bits, overlay and
+      // column masks come first, B x 16 bytes per lane in flight per round trip; the rest follows only when it is needed.
+      const int s0 = (c.L.o_slots & ~3) / 4, s1 = c.L.rec_words / 4;
+      m3_copy_batched<4>((uint4 *)E.rec, (const uint4 *)grec, 0, s0, c.lane);
+      bool need_rest = true;
+      if constexpr (MODE == M3_STEP) {
+        const bool ok0 = action0 >= 0 && action0 < 2;
+        const bool ch0 = ok0 && m3_bit(c.dirt, m3_cell(c, pos[2], pos[1], pos[0])) != (action0 != 0);
+        const bool reset0 = p.auto_reset != 0 && p.update_only == 0 && iteration + 1 > p.cfg.max_iterations;
+        need_rest = ch0 || reset0;
+      }
+      if (need_rest) m3_copy_batched<16>((uint4 *)E.rec, (const uint4 *)grec, s0, s1, c.lane);
     }
     M3_MARK(0, 5);  // loads
     const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;

@@ -37,7 +37,8 @@ if three_d:
         NAMES = ["loads until the barrier", "columns + move-table update", "regions", "candidate walk", "overlay", "outputs + write-back", "fresh tables (reset)"]
     else:
       NAMES = ["(count) trips", "(count) queue entries", "(count) searches", "  search loops", "regions", "everything else", "candidate walk incl. search loops"]
-    env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
+    size = int(next((a[7:] for a in sys.argv if a.startswith("--size=")), "7"))  # --size=15: the reference's stock map
+    env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (size, size, size), n, seeds=np.arange(n), auto_reset=True)
 elif soko:
     env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 else:

@@ -25,7 +25,17 @@ from control_pcgrl_amd import VecPcgrlEnv
 three_d = "--3d" in sys.argv
 soko, zelda = "--sokoban" in sys.argv, "--zelda" in sys.argv
 n = 1024 if three_d else (2048 if soko else 4096)
-if soko:
+custom = next((a for a in sys.argv if a.startswith("--cfg=")), None)  # --cfg=problem,rep,envs,dim0,dim1[,dim2]
+epb = 4  # envs per workgroup (16 lanes per env)
+if custom:
+    f = custom[6:].split(",")
+    shape = tuple(int(x) for x in f[3:])
+    n = int(f[2])
+    three_d = len(shape) == 3
+    env = VecPcgrlEnv(f[0], f[1], shape, n, seeds=np.arange(n), auto_reset=True)
+    lpe = 8 if shape[0] <= 8 else 16 if shape[0] <= 16 else 32 if shape[0] <= 32 else 64
+    epb = 64 // lpe
+elif soko:
     env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 elif zelda:
     env = VecPcgrlEnv("zelda", "turtle", (16, 16), n, seeds=np.arange(n), auto_reset=True)
@@ -40,7 +50,7 @@ sp = torch.cuda.current_stream().cuda_stream
 for k in range(500):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
 torch.cuda.synchronize()
-blocks = n if three_d else n // 4
+blocks = n if three_d else n // epb
 rows = []
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(200):
