@@ -371,7 +371,8 @@ def main():
                     if rc:
                         raise RuntimeError(f"pcgrl_rollout rc={rc}")
 
-            run_rollouts(max(1, R // 10))
+            # (warm-up past the first episode end: sokoban sizes its solver workspace the first time the solver is seen running)
+            run_rollouts(max(1, R // 10, (int(env.cfg.max_iterations) + 1) // GR + 2))
             barrier()
             t1 = time.perf_counter()
             run_rollouts(R)

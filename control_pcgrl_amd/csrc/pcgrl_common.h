@@ -129,6 +129,9 @@ struct Params {
   int32_t n_steps;          // steps per launch; actions / reward / done / stats are [n_steps][N]...
   int32_t obs_last_only;    // 0: obs is [n_steps][N][obs_env_bytes]; else only the last step's observation [N][...]
   int64_t obs_env_bytes;    // observation bytes per env
+  // 3-D: plane bits (y * X + x, up to 256 of them) whose x is not 0 / not X - 1: constants of the map shape, filled in by
+  // pcgrl_create (every wave used to rebuild them with Y multi-word range fills: 5 us of a 15^3 step)
+  uint64_t m3_notx0[4], m3_notxl[4];
 };
 
 }  // namespace pcgrl

@@ -530,6 +530,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   const bool is3d = cfg->problem == PCGRL_PROB_MC3DMAZE;
   p.n_cells = cfg->dims[0] * cfg->dims[1] * (is3d ? cfg->dims[2] : 1);
   p.obs_chunks = obs_chunks;
+  if (is3d) m3_edge_masks_host(cfg->dims[1], cfg->dims[2], p.m3_notx0, p.m3_notxl);
   p.ext = (!is3d && (cfg->static_tiles || cfg->act_window[0] > 0)) ? 1 : 0;
   p.n_act = (!is3d && cfg->act_window[0] > 0) ? cfg->act_window[0] * cfg->act_window[1] : 1;
   // one padded observation row per lane + the OOB row (+ 2 rows per env of the wave with the static_builds plane)

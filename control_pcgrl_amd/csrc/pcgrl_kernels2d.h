@@ -1328,14 +1328,24 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     uint8_t *base = obs_base + (size_t)env * OH * RB;
     const int total = OH * CH;
     if constexpr (FAST) {
-      constexpr int FCH = FOW * C / 16;
+      constexpr int FCH = FOW * C / 16, ITERS = FOH * FCH / LPE, BATCH = 4;
+      // (BATCH LDS reads are issued before the first of their stores: the store is an asm statement with a memory clobber,
+      // so without this every chunk pays one dependent LDS round trip)
 #pragma unroll
-      for (int it = 0; it < FOH * FCH / LPE; it++) {
-        int k = it * LPE + g.row;
-        int i = k / FCH, q = k - i * FCH;
-        int m = i + top;
-        const uint8_t *src = ((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16;
-        store_obs16(base + (size_t)k * 16, *(const uint4 *)src);
+      for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+        uint4 v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+          if (it0 + j < ITERS) {
+            const int k = (it0 + j) * LPE + g.row;
+            const int i = k / FCH, q = k - i * FCH;
+            const int m = i + top;
+            v[j] = *(const uint4 *)(((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++)
+          if (it0 + j < ITERS) store_obs16(base + (size_t)((it0 + j) * LPE + g.row) * 16, v[j]);
       }
     } else if (RB & 15) {
       const int gb = g.gbase;

@@ -308,13 +308,22 @@ __device__ inline void pm_set_range(PM<PW> &a, int start, int len) {
 }
 // plane bits whose x is not 0 / not X-1
 template <int PW>
-__device__ inline void m3_edge_masks(const M3Ctx &c, PM<PW> &notx0, PM<PW> &notxl) {
-  notx0 = pm_zero<PW>();
-  notxl = pm_zero<PW>();
-  for (int y = 0; y < c.Y; y++) {
-    pm_set_range(notx0, y * c.X + 1, c.X - 1);
-    pm_set_range(notxl, y * c.X, c.X - 1);
+__device__ inline void m3_edge_masks(const Params &p, PM<PW> &notx0, PM<PW> &notxl) {
+#pragma unroll
+  for (int i = 0; i < PW; i++) {  // constants of the map shape, computed once by pcgrl_create (m3_edge_masks_host)
+    notx0.w[i] = p.m3_notx0[i];
+    notxl.w[i] = p.m3_notxl[i];
   }
+}
+inline void m3_edge_masks_host(int Y, int X, uint64_t notx0[4], uint64_t notxl[4]) {
+  for (int i = 0; i < 4; i++) notx0[i] = notxl[i] = 0;
+  for (int y = 0; y < Y; y++)
+    for (int x = 0; x < X; x++) {
+      const int q = y * X + x;
+      if (q >= 256) continue;
+      if (x != 0) notx0[q >> 6] |= 1ull << (q & 63);
+      if (x != X - 1) notxl[q >> 6] |= 1ull << (q & 63);
+    }
 }
 
 // the 6-neighbourhood of a set of cells (lane = plane)
@@ -798,12 +807,12 @@ __device__ inline bool m3_second_search(M3Work<SC> &W, const M3Ctx &c, int s, in
 
 // body of the helper wave: serve the simulate wave's jobs until it leaves
 template <int SC>
-__device__ inline void m3_helper(M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
+__device__ inline void m3_helper(const Params &p, M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
   uint32_t epoch = 0, trip = 0;
   for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
   PM<PW> notx0, notxl;
-  m3_edge_masks<PW>(c, notx0, notxl);
+  m3_edge_masks<PW>(p, notx0, notxl);
   int seen = 0, rseen = 0;
   while (true) {
     int sq, rq;
@@ -1223,7 +1232,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_obs
     __syncthreads();  // (the waves of a workgroup start together: nobody waits here)
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 2) {
       // ---------------------------------------------------------------------------------------- helper wave
-      m3_helper<SC>(*WH, c, mail PHASE_PASS);
+      m3_helper<SC>(p, *WH, c, mail PHASE_PASS);
       if (p.obs != nullptr) __syncthreads();  // (the closing barrier of the other two waves)
       return;
     }
@@ -1310,7 +1319,7 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_obs
     for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
   };
   PM<PW> notx0, notxl;
-  m3_edge_masks<PW>(c, notx0, notxl);
+  m3_edge_masks<PW>(p, notx0, notxl);
   auto plane_of = [&](const uint32_t *dirt) { return c.lane < c.Z ? m3_plane_air<PW>(dirt, c, c.lane) : pm_zero<PW>(); };
   // statistics of a map the kernel has not seen before: columns, move table, no cached slots
   auto fresh_stats = [&](int32_t *st, bool &ovf) {
@@ -1449,6 +1458,13 @@ __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_obs
         const bool reset0 = p.auto_reset != 0 && p.update_only == 0 && iteration + 1 > p.cfg.max_iterations;
         need_rest = ch0 || reset0;
       }
+#ifdef PCGRL_PHASE_TIMING  // development knob (timing builds only; cfg.solver_power is unused in 3-D): 1 = no second part, 2 = 4 per trip
+      if (p.cfg.solver_power == 1) need_rest = false;
+      if (p.cfg.solver_power == 2 && need_rest) {
+        m3_copy_batched<4>((uint4 *)E.rec, (const uint4 *)grec, s0, s1, c.lane);
+        need_rest = false;
+      }
+#endif
       if (need_rest) m3_copy_batched<16>((uint4 *)E.rec, (const uint4 *)grec, s0, s1, c.lane);
     }
     M3_MARK(0, 5);  // loads

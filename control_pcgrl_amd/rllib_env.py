@@ -129,6 +129,7 @@ def _hip_runtime():
 
 class PcgrlVectorEnv(_Base):
     DIRECT_MAX_BYTES = 1 << 20  # default: the step kernel writes into host memory itself when a call's outputs are <= 1 MiB
+    HOST_CONVERT_MAX_BYTES = 1 << 18  # float32 hand-out: uint8 -> float32 on the host up to this many observation bytes per call
 
     def __init__(self, cfg=None, num_envs=1, device="cuda:0", seeds=None, vec: VecPcgrlEnv = None, obs_dtype=np.float32,
                  direct_host_outputs=None):
@@ -169,7 +170,19 @@ class PcgrlVectorEnv(_Base):
         base = self._dev.data_ptr()
         self._dp = dict(obs=base, rew=base + self._o_rew, stats=base + self._o_stats, done=base + self._o_done, ctrl=base + self._o_ctrl)
         self._convert = self.obs_dtype != np.dtype(np.uint8)
-        if self._convert:  # the engine's uint8 observation -> float32 (+ control planes in front) on the device
+        # small batches (the reference's 20 envs per worker): the kernel writes its uint8 outputs into a pinned staging block
+        # and the float32 arrays are made on the host -- a device-side conversion launch costs more than converting 60 KB
+        self._host_convert = (self._convert and not self.n_ctrl_planes and direct_host_outputs is not False
+                              and N * int(np.prod(v.obs_shape)) <= self.HOST_CONVERT_MAX_BYTES)
+        if self._host_convert:
+            self._o8 = (up(N * int(np.prod(v.obs_shape))), up(N * 4), up(N * S * 4), up(N))  # section sizes of the staging block
+            self._stage = torch.zeros(sum(self._o8), dtype=torch.uint8).pin_memory()
+            sb, sn = self._stage.data_ptr(), self._stage.numpy()
+            o1, o2, o3 = self._o8[0], self._o8[0] + self._o8[1], self._o8[0] + self._o8[1] + self._o8[2]
+            self._stage_ptrs = (sb, sb + o1, sb + o2, sb + o3, 0)
+            self._stage_views = dict(obs=sn[:N * int(np.prod(v.obs_shape))].reshape((N,) + v.obs_shape), rew=sn[o1:o1 + N * 4].view(np.float32),
+                                     stats=sn[o2:o2 + N * S * 4].view(np.int32).reshape(N, S), done=sn[o3:o3 + N].view(np.bool_))
+        if self._convert and not self._host_convert:  # the engine's uint8 observation -> float32 (+ control planes in front) on the device
             self._obs_u8 = torch.empty((N,) + v.obs_shape, dtype=torch.uint8, device=v.device)
             self._obs_out = self._dev[:N * ob_out].view(torch.float32).view(self._out_shape)
             self._ctrl_dev = self._dev[self._o_ctrl:self._o_ctrl + N * max(self.n_ctrl_planes, 1) * 4].view(torch.float32).view(N, -1)
@@ -178,7 +191,7 @@ class PcgrlVectorEnv(_Base):
             self._engine_obs = self._dp["obs"]
         if direct_host_outputs is None:
             direct_host_outputs = self._total <= self.DIRECT_MAX_BYTES
-        self._direct = bool(direct_host_outputs) and not self._convert
+        self._direct = (bool(direct_host_outputs) and not self._convert) or self._host_convert
         self._hip = _hip_runtime()
         self._act = torch.zeros((N, v.action_entries), dtype=torch.int32).pin_memory()
         self._act_np = self._act.numpy()
@@ -208,6 +221,16 @@ class PcgrlVectorEnv(_Base):
     def _finish(self, lease, stream):
         """device-side conversion if any, the call's one device->host copy (unless the kernels wrote into the block
         themselves), and the wait for it"""
+        if self._host_convert:
+            rc = self._hip.hipStreamSynchronize(stream)
+            if rc:
+                raise RuntimeError(f"hipStreamSynchronize: error {rc}")
+            r, sv = self._views(lease), self._stage_views
+            np.copyto(r["obs"], sv["obs"], casting="unsafe")
+            r["rew"][...] = sv["rew"]
+            r["stats"][...] = sv["stats"]
+            r["done"][...] = sv["done"]
+            return
         if self._convert:
             K2 = self.n_ctrl_planes
             if K2:
@@ -224,6 +247,8 @@ class PcgrlVectorEnv(_Base):
             raise RuntimeError(f"hipStreamSynchronize: error {rc}")
 
     def _out_ptrs(self, lease):
+        if self._host_convert:
+            return self._stage_ptrs
         if not self._direct:
             return self._engine_obs, self._dp["rew"], self._dp["stats"], self._dp["done"], self._dp["ctrl"]
         b = lease.ptr

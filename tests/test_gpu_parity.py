@@ -1251,7 +1251,7 @@ def test_rllib_vector_env_adapter_never_rewrites_what_it_returned(obs_dtype, dir
            "representation": "narrow", "change_percentage": 0.02}
     n = 5
     env = PcgrlVectorEnv(cfg, num_envs=n, seeds=list(range(n)), obs_dtype=obs_dtype, direct_host_outputs=direct)
-    assert env._direct == bool(direct)
+    assert env._direct == (bool(direct) or env._host_convert) and env._host_convert == (obs_dtype is np.float32)
     obs0, _ = env.vector_reset()
     keep0 = [o.copy() for o in obs0]
     rng = np.random.default_rng(0)

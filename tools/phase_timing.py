@@ -38,7 +38,8 @@ if three_d:
     else:
       NAMES = ["(count) trips", "(count) queue entries", "(count) searches", "  search loops", "regions", "everything else", "candidate walk incl. search loops"]
     size = int(next((a[7:] for a in sys.argv if a.startswith("--size=")), "7"))  # --size=15: the reference's stock map
-    env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (size, size, size), n, seeds=np.arange(n), auto_reset=True)
+    knob = int(next((a[7:] for a in sys.argv if a.startswith("--knob=")), "10000"))  # development: see PCGRL_PHASE_TIMING in pcgrl_kernels3d.h
+    env = VecPcgrlEnv("minecraft_3D_maze", "narrow", (size, size, size), n, seeds=np.arange(n), auto_reset=True, solver_power=knob)
 elif soko:
     env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 else:
@@ -49,13 +50,18 @@ env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, 256 * 5 if soko else 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
-for k in range(300):
+WARM = int(next((a[7:] for a in sys.argv if a.startswith("--warm=")), "300"))
+for k in range(WARM):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
 blocks = n if three_d else n // 4
 out = np.zeros(8 * blocks, np.uint64)
 env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
+NO_OBS = "--no-obs" in sys.argv  # launches without an observation buffer: no observe waves, no observation stores
 for k in range(iters):
-    env.step_raw(pool[k % 1021].data_ptr(), sp)
+    if NO_OBS:
+        env._L.pcgrl_step(env._h, pool[k % 1021].data_ptr(), 1, None, env._ptrs[1], env._ptrs[2], env._ptrs[3], sp)
+    else:
+        env.step_raw(pool[k % 1021].data_ptr(), sp)
 env._L.pcgrl_debug_counters(env._h, out.ctypes.data, 8 * blocks)
 out = out.reshape(blocks, 8).astype(np.float64).sum(0)
 tot = 0

@@ -47,7 +47,8 @@ env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 pool = torch.randint(0, env.num_actions, (1021, n), generator=g, device="cuda", dtype=torch.int32)
 sp = torch.cuda.current_stream().cuda_stream
-for k in range(500):
+WARM = int(next((a[7:] for a in sys.argv if a.startswith("--warm=")), "500"))
+for k in range(WARM):
     env.step_raw(pool[k % 1021].data_ptr(), sp)
 torch.cuda.synchronize()
 blocks = n if three_d else n // epb
