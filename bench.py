@@ -492,6 +492,7 @@ def main():
         achieved = bytes_per_launch / (elapsed / K) / 1e9          # same clock as `value`
         achieved_ev = bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # HIP events around the K launches
         traffic, traffic_src = profiled_traffic(args.workload, N)
+        k_mean_us = profiled_kernel_mean_us(args.workload, N)
         out = {
             "metric": "env-steps/sec at N envs/GPU (binary 16x16), 1/2/4/8 MI355X",
             "value": value, "unit": "maps/s" if sfg else "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -523,6 +524,10 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "clock": "wall clock of the timed region / steps (the clock of `value`)",
                          "achieved_hip_events": achieved_ev, "frac_hip_events": achieved_ev / HBM_PEAK_GBS,
+                         # from the COMMITTED rocprofv3 --kernel-trace mean of the dominant kernel (profiles/r*_summary.json),
+                         # begin-to-end of the kernel alone: the figure a reader can recompute from profiles/
+                         "kernel_mean_us": k_mean_us,
+                         "kernel_frac": (bytes_per_launch / (k_mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if k_mean_us else None,
                          "avg_launch_us": kernel_ms * 1e3,
                          # context, not a peak: a device fill of the same byte count on the same GPU in the same run
                          "fill_same_bytes": (dict(fill, step_over_fill=(elapsed / K * 1e6) / fill["us"]) if fill else None)},
@@ -671,6 +676,23 @@ def profiled_traffic(workload, n_envs):
                 rec = s.get("hbm_traffic_per_launch")
             if rec is not None:
                 best = (rec["traffic_bytes"], os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)")
+        except Exception:
+            pass
+    return best
+
+
+def profiled_kernel_mean_us(workload, n_envs):
+    """mean begin-to-end duration of the dominant kernel in the newest committed rocprofv3 kernel trace of this workload at its
+    default batch (profiles/r*_summary.json), or None"""
+    import glob
+    best = None
+    if n_envs != WORKLOADS[workload][3]:
+        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(f))["workloads"].get(workload, {}).get("dominant_kernel_launch")
+            if d:
+                best = d["duration_ns"]["mean"] / 1e3
         except Exception:
             pass
     return best

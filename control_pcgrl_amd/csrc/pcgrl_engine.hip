@@ -464,6 +464,9 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
     p.sk_helpers = force == 2 ? 3 : 0;
     return;
   }
+  // (a workgroup per env only pays while the launch is short of wavefronts: at 32 768 envs it is 32 768 workgroups of eight
+  // waves and the step launch goes from 10 to 74 us)
+  if (h->p.n_envs > 8192) return;
   const int32_t seen = *(volatile int32_t *)h->seen_host;
   if (seen != h->seen_last) {
     h->seen_last = seen;
@@ -542,6 +545,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     // (encode_obs_codes) -- per env H rows of W + 20 bytes (rounded to 16) instead of H one-hot rows
     const int Hc = cfg->dims[0], Wc = cfg->dims[1], OWc = cfg->obs_window[1], Cc = p.n_tiles + 1;
     const bool fast_cfg = Hc == 16 && Wc == 16 && cfg->obs_window[0] == 32 && OWc == 32;
+    p.obs16 = (!is3d && fast_cfg) ? 1 : 0;
     // (only where the one-hot rows are what limits occupancy: at 13 KB per workgroup -- binary 32 x 32 -- the rows are
     // cheaper: 14.0 vs 15.6 us per launch; at 26 KB -- binary 64 x 64 -- 67 vs 47.5; at 38 KB -- zelda 32 x 32 -- 44 vs 27.6)
     if (!is3d && cfg->representation != PCGRL_REP_WIDE && !cfg->static_tiles && !fast_cfg && (OWc * Cc) % 16 == 0 &&

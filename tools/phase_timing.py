@@ -43,12 +43,17 @@ if three_d:
 elif soko:
     env = VecPcgrlEnv("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=True)
 else:
-    env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+    # --static / --patch: the representation wrappers (general kernels); --general: the general kernel on the plain config
+    # (statistics left stale by one pcgrl_update keep Params::no_fast set)
+    kw = dict(static_prob=0.3, n_static_walls=3) if "--static" in sys.argv else dict(act_window=[3, 3]) if "--patch" in sys.argv else {}
+    env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True, **kw)
 if soko:
     NAMES = ["loads+barrier", "action+state", "stats refresh", "loss + outputs", "auto-reset block", "-", "state write-back"]
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
-pool = torch.randint(0, 256 * 5 if soko else 2, (1021, n), generator=g, device="cuda", dtype=torch.int32)
+pool = torch.randint(0, 256 * 5 if soko else 2, (1021, n * env.action_entries), generator=g, device="cuda", dtype=torch.int32)
+if "--general" in sys.argv:
+    env.update(pool[0])
 sp = torch.cuda.current_stream().cuda_stream
 WARM = int(next((a[7:] for a in sys.argv if a.startswith("--warm=")), "300"))
 for k in range(WARM):

@@ -32,7 +32,8 @@ if custom:
     shape = tuple(int(x) for x in f[3:])
     n = int(f[2])
     three_d = len(shape) == 3
-    env = VecPcgrlEnv(f[0], f[1], shape, n, seeds=np.arange(n), auto_reset=True)
+    kw = dict(static_prob=0.3, n_static_walls=3) if "--static" in sys.argv else dict(act_window=[3, 3]) if "--patch" in sys.argv else {}
+    env = VecPcgrlEnv(f[0], f[1], shape, n, seeds=np.arange(n), auto_reset=True, **kw)
     lpe = 8 if shape[0] <= 8 else 16 if shape[0] <= 16 else 32 if shape[0] <= 32 else 64
     epb = 64 // lpe
 elif soko:
@@ -45,7 +46,9 @@ else:
     env = VecPcgrlEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset="--no-reset" not in sys.argv)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
-pool = torch.randint(0, env.num_actions, (1021, n), generator=g, device="cuda", dtype=torch.int32)
+pool = torch.randint(0, env.num_actions, (1021, n * env.action_entries), generator=g, device="cuda", dtype=torch.int32)
+if "--general" in sys.argv:  # statistics left stale by one pcgrl_update keep the general kernels in use (Params::no_fast)
+    env.update(pool[0])
 sp = torch.cuda.current_stream().cuda_stream
 WARM = int(next((a[7:] for a in sys.argv if a.startswith("--warm=")), "500"))
 for k in range(WARM):
