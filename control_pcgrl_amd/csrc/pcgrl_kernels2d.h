@@ -580,7 +580,7 @@ __device__ __attribute__((always_inline)) inline void touch_kernarg(const Params
                "s"(kw[208 < sizeof(Params) / 4 ? 208 : 0]));
 }
 
-template <int LPE, typename M>
+template <int LPE, typename M, bool HUGE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player, M crate, M target,
                               int &dist_win, int &sol_len);
 // helper wavefronts of the solver (pcgrl_sokoban.h): kernels launched with Params::sk_helpers carry three of them per
@@ -648,7 +648,8 @@ __device__ inline int regions_update(const Grp<LPE> &g, M x, M w_old, M w_new, i
 }
 
 // regions_known >= 0: the caller already has the region count (incremental update in the step kernel)
-template <int PROB, int LPE, typename M>
+// SK_HUGE (sokoban): also the search for levels with more than 128 crate / target pairs (false in the 16x16 kernels)
+template <int PROB, int LPE, typename M, bool SK_HUGE = true>
 __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, M colmask, int32_t *st,
                                      int regions_known = -1) {
   if constexpr (PROB == PCGRL_PROB_BINARY) {
@@ -719,7 +720,7 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     int sol_len = 0;
     bool need = active && n_player == 1 && n_crate == n_target && n_crate > 0 && regions == 1;
     if (__ballot(need) != 0) {
-      sokoban_solve<LPE, M>(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
+      sokoban_solve<LPE, M, SK_HUGE>(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
     }
     st[0] = n_player;
     st[1] = n_crate;
@@ -1655,7 +1656,7 @@ __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, 
         regions_known = one ? r : -1;
       }
     }
-    compute_stats<PROB, LPE, M>(g, p, e, full, b, colmask, ns, regions_known);
+    compute_stats<PROB, LPE, M, !FAST>(g, p, e, full, b, colmask, ns, regions_known);
     if (full) {
 #pragma unroll
       for (int k = 0; k < NS; k++) st[k] = ns[k];
@@ -1936,7 +1937,7 @@ void step_kernel(Params p) {
     if (do_reset && g.row == 0) latch_episode<NS>(p, e, S, ep_return, iteration, st);
     reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/true, ext ? &X : nullptr);
     int32_t ns[NS];
-    compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
+    compute_stats<PROB, LPE, M, !FAST>(g, p, e, do_reset, b, colmask, ns);
     if (do_reset) {
 #pragma unroll
       for (int k = 0; k < NS; k++) st[k] = ns[k];
@@ -2111,7 +2112,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         }
         reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, true, ext ? &X : nullptr, &rp, &rr);
         int32_t ns[NS];
-        compute_stats<PROB, LPE, M>(g, p, e, do_reset, b, colmask, ns);
+        compute_stats<PROB, LPE, M, !FAST>(g, p, e, do_reset, b, colmask, ns);
         if (do_reset) {
 #pragma unroll
           for (int i = 0; i < NS; i++) st[i] = ns[i];

@@ -64,7 +64,11 @@ namespace pcgrl {
   } while (0)
 #endif
 
-constexpr int SK_MAXC = 128;     // crates (= targets) the device solver supports (a 16x16 map holds at most 127 pairs + player)
+constexpr int SK_MAXC = 128;     // crates (= targets) of a level the wave-cooperative solver keeps in two registers per lane, and
+                                 // the crate-list area of a node in a stage workspace (a 16x16 map holds at most 127 pairs + player)
+constexpr int SK_NH_HUGE = 8;    // levels with more pairs (maps of >= 258 cells can have them): 8 registers per lane, up to
+constexpr int SK_MAXC_HUGE = 64 * SK_NH_HUGE;  // 512 pairs; their node crate lists spread over the crate areas of the slot's
+                                 // four stage workspaces (sk_crate_ptr), the stages run one after the other on the simulate wave
 constexpr int SK_MAXDIM = 64;    // bordered level side (H+2, W+2 <= 64: one lane / one mask bit per row and per column)
 constexpr int SK_VCAP = 1 << 15; // visited table entries (>= 2 x iterations per stage), 16 bytes each, in groups of 8
 constexpr int SK_VGROUPS = SK_VCAP / 8;  // a group = one 128-byte line: a probe reads it with one load (lane l < 8: entry l)
@@ -75,8 +79,8 @@ constexpr uint32_t SK_NOCRATE = 0xFFFFu;
 struct SokoLevel {  // LDS, one per workgroup (one solve at a time per simulate wave)
   int32_t w, h, ncr, ntg;
   uint64_t solid[SK_MAXDIM + 2], dead[SK_MAXDIM + 2], tgt[SK_MAXDIM + 2];
-  uint16_t root[SK_MAXC];     // crates of the level in row-major order: x | y << 8 (engine.py:170-188)
-  uint16_t target[SK_MAXC];   // targets, same encoding
+  uint16_t root[SK_MAXC_HUGE];     // crates of the level in row-major order: x | y << 8 (engine.py:170-188)
+  uint16_t target[SK_MAXC_HUGE];   // targets, same encoding
 };
 // The workspace pointers carry their address space (global / LDS): pointers read from memory are generic otherwise and
 // every access becomes a flat_load that counts on both the vector-memory and the LDS counter.
@@ -157,6 +161,8 @@ struct SokoCtx {
   uint32_t SK_GLOBAL *q;       // [max_nodes] BFS queue (node) / A* heap (key << 16 | node)
   int32_t n_nodes, max_nodes, ncr;
   int32_t cstride;  // crate-list stride of this level in uint16: ncr rounded up to 4 (compact records stay in the L2)
+  int32_t npr;      // levels with more than SK_MAXC pairs: node crate lists per stage workspace's crate area (else unused)
+  size_t region_stride;  // ... and the distance between those areas (one stage workspace)
   uint32_t epoch;
   int lane;
   int stage;  // which quarter of the slot this context is bound to
@@ -188,64 +194,170 @@ __device__ inline uint32_t sk_wave_xor(uint32_t v) {
          (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-// The crate list of one node, spread over the wave: lane k holds crate k in c0 and (BIG: levels with more than 64
-// crates) crate k + 64 in c1.
-template <bool BIG>
+// where node n's crate list lives
+template <int NH>
+__device__ inline uint16_t SK_GLOBAL *sk_crate_ptr(const SokoCtx &c, int n) {
+  if constexpr (NH > 2) {  // list n % npr of the crate area of stage workspace n / npr (4 * npr >= max_nodes: cstride <= 512)
+    const int r = n / c.npr, i = n - r * c.npr;
+    return (uint16_t SK_GLOBAL *)((uint8_t SK_GLOBAL *)c.crates + (size_t)r * c.region_stride) + (size_t)i * c.cstride;
+  } else {
+    return c.crates + (size_t)n * c.cstride;
+  }
+}
+
+// The crate list of one node, spread over the wave: lane k holds crate k in c0, (NH >= 2: levels with more than 64 crates)
+// crate k + 64 in c1 and (NH > 2: more than 128, the whole-slot search) crate k + 64 j in cx[j - 2].
+template <int NH>
 struct SkCrates {
+  static constexpr int NX = NH > 2 ? NH - 2 : 1;
   uint32_t c0, c1;  // x | y << 8, SK_NOCRATE beyond the list
+  uint32_t cx[NX];
+  __device__ inline void clear() {
+    c0 = c1 = SK_NOCRATE;
+#pragma unroll
+    for (int j = 0; j < NX; j++) cx[j] = SK_NOCRATE;
+  }
   __device__ inline void load(const SokoCtx &c, int n) {
-    const uint16_t SK_GLOBAL *src = c.crates + (size_t)n * c.cstride;
+    const uint16_t SK_GLOBAL *src = sk_crate_ptr<NH>(c, n);
     c0 = c.lane < c.ncr ? src[c.lane] : SK_NOCRATE;
-    c1 = (BIG && c.lane + 64 < c.ncr) ? src[c.lane + 64] : SK_NOCRATE;
+    c1 = ((NH >= 2) && c.lane + 64 < c.ncr) ? src[c.lane + 64] : SK_NOCRATE;
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) cx[j] = c.lane + 64 * (j + 2) < c.ncr ? src[c.lane + 64 * (j + 2)] : SK_NOCRATE;
+    }
+  }
+  __device__ inline void load_level(const SokoCtx &c, const uint16_t *list) {  // the level's root list (LDS)
+    c0 = c.lane < c.ncr ? list[c.lane] : SK_NOCRATE;
+    c1 = ((NH >= 2) && c.lane + 64 < c.ncr) ? list[c.lane + 64] : SK_NOCRATE;
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) cx[j] = c.lane + 64 * (j + 2) < c.ncr ? list[c.lane + 64 * (j + 2)] : SK_NOCRATE;
+    }
   }
   __device__ inline void store(const SokoCtx &c, int n) const {
-    uint16_t SK_GLOBAL *dst = c.crates + (size_t)n * c.cstride;
+    uint16_t SK_GLOBAL *dst = sk_crate_ptr<NH>(c, n);
     if (c.lane < c.ncr) dst[c.lane] = (uint16_t)c0;
-    if (BIG && c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
+    if ((NH >= 2) && c.lane + 64 < c.ncr) dst[c.lane + 64] = (uint16_t)c1;
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++)
+        if (c.lane + 64 * (j + 2) < c.ncr) dst[c.lane + 64 * (j + 2)] = (uint16_t)cx[j];
+    }
+  }
+  // crate `moved` of the list takes the cell np
+  __device__ inline void move(const SokoCtx &c, int moved, uint32_t np) {
+    if (NH < 2 || moved < 64) c0 = c.lane == moved ? np : c0;
+    else if (NH == 2 || moved < 128) c1 = c.lane == moved - 64 ? np : c1;
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) cx[j] = (c.lane == moved - 64 * (j + 2)) ? np : cx[j];
+    }
+  }
+  // crate k of the list, broadcast
+  __device__ inline uint32_t get(int k) const {
+    if (NH < 2 || k < 64) return (uint32_t)__builtin_amdgcn_readlane((int)c0, k & 63);
+    if (NH == 2 || k < 128) return (uint32_t)__builtin_amdgcn_readlane((int)c1, (k - 64) & 63);
+    uint32_t v = SK_NOCRATE;
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++)
+        if ((k >> 6) == j + 2) v = (uint32_t)__builtin_amdgcn_readlane((int)cx[j], k & 63);
+    }
+    return v;
   }
   // index of the crate standing at (x, y), -1 if none (engine.py:263-267)
   __device__ inline int at(int x, int y) const {
     const uint32_t key = (uint32_t)x | ((uint32_t)y << 8);
     const uint64_t b0 = __ballot(c0 == key);
-    if (!BIG) return b0 ? __builtin_ctzll(b0) : -1;
+    if (NH < 2) return b0 ? __builtin_ctzll(b0) : -1;
     const uint64_t b1 = __ballot(c1 == key);
+    if constexpr (NH > 2) {
+      if (b0 == 0 && b1 == 0) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+          const uint64_t bj = __ballot(cx[j] == key);
+          if (bj) return 64 * (j + 2) + __builtin_ctzll(bj);
+        }
+        return -1;
+      }
+    }
     return b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : -1);
   }
   // number of crates whose cell has its bit set in `rows`
   __device__ inline int count_on(const uint64_t *rows) const {
     const bool h0 = c0 != SK_NOCRATE && sk_bit(rows, c0 & 255, c0 >> 8);
     int n = __popcll(__ballot(h0));
-    if (BIG) {
+    if (NH >= 2) {
       const bool h1 = c1 != SK_NOCRATE && sk_bit(rows, c1 & 255, c1 >> 8);
       n += __popcll(__ballot(h1));
     }
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        const bool hj = cx[j] != SK_NOCRATE && sk_bit(rows, cx[j] & 255, cx[j] >> 8);
+        n += __popcll(__ballot(hj));
+      }
+    }
     return n;
   }
-  __device__ inline bool same(const SkCrates &o) const { return __ballot(c0 != o.c0 || (BIG && c1 != o.c1)) == 0; }
+  __device__ inline bool same(const SkCrates &o) const {
+    bool d = c0 != o.c0 || ((NH >= 2) && c1 != o.c1);
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) d = d || cx[j] != o.cx[j];
+    }
+    return __ballot(d) == 0;
+  }
 };
 
-template <bool BIG>
-__device__ inline bool sk_free_cell(const SokoCtx &c, const SkCrates<BIG> &cr, int x, int y) {  // checkMovableLocation :269-270
+template <int NH>
+__device__ inline bool sk_free_cell(const SokoCtx &c, const SkCrates<NH> &cr, int x, int y) {  // checkMovableLocation :269-270
   if (x < 0 || y < 0 || x > c.lv->w - 1 || y > c.lv->h - 1) return false;
   return !sk_bit(c.lv->solid, x, y) && cr.at(x, y) < 0;
 }
 
 // engine.py:282-296 getHeuristic: crates in list order greedily take the nearest remaining target (first minimum in
 // list order).  Lane t holds targets t and t + 64; per crate: broadcast its cell, one distance per lane, wave arg-min.
-template <bool BIG>
-__device__ __attribute__((always_inline)) inline int sk_heuristic(const SokoCtx &c, const SkCrates<BIG> &cr) {
+template <int NH>
+__device__ __attribute__((always_inline)) inline int sk_heuristic(const SokoCtx &c, const SkCrates<NH> &cr) {
   const int nt = c.lv->ntg;
+  if constexpr (NH > 2) {  // the same with target indices beyond 255: key = distance << 12 | target index
+    uint32_t tg[NH];
+    bool used[NH];
+#pragma unroll
+    for (int j = 0; j < NH; j++) {
+      tg[j] = c.lane + 64 * j < nt ? c.lv->target[c.lane + 64 * j] : SK_NOCRATE;
+      used[j] = tg[j] == SK_NOCRATE;
+    }
+    int distance = 0;
+    for (int k = 0; k < c.ncr; k++) {
+      const uint32_t ck = cr.get(k);
+      const int cx = ck & 255, cy = ck >> 8;
+      uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < NH; j++) {
+        const uint32_t dj = used[j] ? 0xFFFFu : (uint32_t)(abs(cx - (int)(tg[j] & 255)) + abs(cy - (int)(tg[j] >> 8)));
+        key = min(key, (dj << 12) | (uint32_t)(c.lane + 64 * j));
+      }
+      const uint32_t best = sk_wave_min(key);
+      distance += (int)(best >> 12);
+      const int t = best & 0xFFF;
+#pragma unroll
+      for (int j = 0; j < NH; j++) used[j] = used[j] || t == c.lane + 64 * j;
+    }
+    return distance;
+  }
   const uint32_t t0 = c.lane < nt ? c.lv->target[c.lane] : SK_NOCRATE;
-  const uint32_t t1 = (BIG && c.lane + 64 < nt) ? c.lv->target[c.lane + 64] : SK_NOCRATE;
+  const uint32_t t1 = ((NH >= 2) && c.lane + 64 < nt) ? c.lv->target[c.lane + 64] : SK_NOCRATE;
   bool u0 = t0 == SK_NOCRATE, u1 = t1 == SK_NOCRATE;  // "used" (absent targets never match)
   int distance = 0;
   for (int k = 0; k < c.ncr; k++) {
-    const uint32_t ck = (!BIG || k < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, k & 63)
+    const uint32_t ck = (NH < 2 || k < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)cr.c0, k & 63)
                                          : (uint32_t)__builtin_amdgcn_readlane((int)cr.c1, k - 64);
     const int cx = ck & 255, cy = ck >> 8;
     const uint32_t d0 = u0 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t0 & 255)) + abs(cy - (int)(t0 >> 8)));
     uint32_t key = (d0 << 8) | (uint32_t)c.lane;
-    if (BIG) {
+    if (NH >= 2) {
       const uint32_t d1 = u1 ? 0xFFFFu : (uint32_t)(abs(cx - (int)(t1 & 255)) + abs(cy - (int)(t1 >> 8)));
       key = min(key, (d1 << 8) | (uint32_t)(c.lane + 64));
     }
@@ -332,8 +444,8 @@ struct SkKey {
     return (int)((h ^ (h >> 13)) & (uint32_t)(SK_VGROUPS - 1));
   }
 };
-template <bool BIG>
-__device__ __attribute__((always_inline)) inline SkKey sk_key(const SokoCtx &c, int px, int py, const SkCrates<BIG> &cr) {
+template <int NH>
+__device__ __attribute__((always_inline)) inline SkKey sk_key(const SokoCtx &c, int px, int py, const SkCrates<NH> &cr) {
   SkKey k;
   const uint32_t xy = (uint32_t)px | ((uint32_t)py << 8);
   k.exact = c.ncr <= 5;
@@ -349,11 +461,20 @@ __device__ __attribute__((always_inline)) inline SkKey sk_key(const SokoCtx &c, 
     a ^= a >> 15;
     uint32_t b = (cr.c0 ^ (0x7F4A7C15u + 0x632BE5ABu * (uint32_t)c.lane)) * 0xC2B2AE35u;
     b ^= b >> 13;
-    if (BIG) {
+    if (NH >= 2) {
       uint32_t a1 = (cr.c1 + 0x9E3779B9u * (uint32_t)(c.lane + 65)) * 0xC2B2AE35u;
       a ^= a1 ^ (a1 >> 13);
       uint32_t b1 = (cr.c1 ^ (0x1B873593u + 0x632BE5ABu * (uint32_t)(c.lane + 64))) * 0x85EBCA6Bu;
       b ^= b1 ^ (b1 >> 15);
+    }
+    if constexpr (NH > 2) {
+#pragma unroll
+      for (int j = 0; j < SkCrates<NH>::NX; j++) {
+        uint32_t aj = (cr.cx[j] + 0x9E3779B9u * (uint32_t)(c.lane + 64 * (j + 2) + 1)) * 0xC2B2AE35u;
+        a ^= aj ^ (aj >> 13);
+        uint32_t bj = (cr.cx[j] ^ (0x1B873593u + 0x632BE5ABu * (uint32_t)(c.lane + 64 * (j + 2)))) * 0x85EBCA6Bu;
+        b ^= bj ^ (bj >> 15);
+      }
     }
     k.k1 = sk_wave_xor(a);
     k.k2 = sk_wave_xor(b);
@@ -366,8 +487,8 @@ __device__ __attribute__((always_inline)) inline SkKey sk_key(const SokoCtx &c, 
 // group of 8 entries with one load; a full group overflows into the next.
 // `pre` / `have_pre`: the first group of the probe, already requested by the caller (the A* stage asks for it before its
 // heap pop, so the memory round trip runs under the pop instead of after it).
-template <bool BIG>
-__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, const SkKey &key, const SkCrates<BIG> &cr,
+template <int NH>
+__device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(SokoCtx &c, int n, const SkKey &key, const SkCrates<NH> &cr,
                                                                                sk_u32x4 pre = sk_u32x4{0u, 0u, 0u, 0u}, bool have_pre = false) {
   int grp = key.group();
   while (true) {
@@ -387,7 +508,7 @@ __device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(So
         const int j = __builtin_ctz(cand);
         cand &= cand - 1u;
         const int m = (int)((uint32_t)__builtin_amdgcn_readlane((int)e.x, j) & 0x1FFFFu) - 1;
-        SkCrates<BIG> o;
+        SkCrates<NH> o;
         o.load(c, m);
         if (cr.same(o)) return true;
       }
@@ -524,7 +645,7 @@ __device__ __attribute__((always_inline)) inline void sk_heappush(SokoCtx &c, in
 }
 
 // `cancel` (helper-wave mode): the stage gives up as soon as *cancel < my_stage (its result is not needed).
-template <bool BIG>
+template <int NH>
 __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
                                 bool *exhausted = nullptr, const int32_t *cancel = nullptr, int my_stage = 0) {
   uint32_t *epoch_word = &pool.epochs[slot * SK_STAGES + c.stage];
@@ -562,8 +683,8 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
   bool pre_valid = false;
   int pre_cur = 0;
   SokoNode pre_nd;
-  SkCrates<BIG> pre_cr;
-  pre_cr.c0 = pre_cr.c1 = SK_NOCRATE;
+  SkCrates<NH> pre_cr;
+  pre_cr.clear();
   pre_nd.parent = pre_nd.depth = pre_nd.h = pre_nd.px = pre_nd.py = 0;
   SK_T_DECL();
   while (iters < max_iter && head < tail) {
@@ -596,7 +717,7 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
     }
     SK_T_MARK(0);  // pop
     SokoNode nd;
-    SkCrates<BIG> cr;
+    SkCrates<NH> cr;
     if (had_pre) {
       nd = pre_nd;
       cr = pre_cr;
@@ -637,7 +758,7 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
         const int nx = px + DX[d], ny = py + DY[d];
         if (nx < 0 || ny < 0 || nx > c.lv->w - 1 || ny > c.lv->h - 1 || sk_bit(c.lv->solid, nx, ny)) continue;
         const int moved = cr.at(nx, ny);
-        SkCrates<BIG> ch = cr;
+        SkCrates<NH> ch = cr;
         int h = nd.h;  // the heuristic depends on the crates only
         if (moved >= 0) {
           const int bx = nx + DX[d], by = ny + DY[d];
@@ -646,8 +767,7 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
           const int ndead = n_dead - (sk_bit(c.lv->dead, nx, ny) ? 1 : 0) + (sk_bit(c.lv->dead, bx, by) ? 1 : 0);
           if (ndead > 0) continue;
           const uint32_t np = (uint32_t)bx | ((uint32_t)by << 8);
-          if (!BIG || moved < 64) ch.c0 = c.lane == moved ? np : ch.c0;
-          else ch.c1 = c.lane == moved - 64 ? np : ch.c1;
+          ch.move(c, moved, np);
           h = sk_heuristic(c, ch);
         }
         if (c.n_nodes >= c.max_nodes) {  // cannot happen (<= 1 + 4 * iterations nodes per stage); reported if it does
@@ -691,6 +811,8 @@ __device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int s
   c.nodes = (sk_u32x4 SK_GLOBAL *)b;
   b += SK_NODE_BYTES * (size_t)c.max_nodes;
   c.crates = (uint16_t SK_GLOBAL *)b;
+  c.region_stride = pool.stage_bytes;
+  c.npr = c.cstride > 0 ? (int)(((size_t)c.max_nodes * SK_MAXC) / (size_t)c.cstride) : c.max_nodes;
   b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
   c.vis = (sk_u32x4 SK_GLOBAL *)b;
   b += SK_VIS_BYTES;
@@ -698,11 +820,10 @@ __device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int s
 }
 
 // node 0 of the bound workspace = the level's root state (crates in c.lv->root)
-template <bool BIG>
+template <int NH>
 __device__ inline int sk_root(SokoCtx &c, int px, int py) {
-  SkCrates<BIG> root;
-  root.c0 = c.lane < c.ncr ? c.lv->root[c.lane] : SK_NOCRATE;
-  root.c1 = (BIG && c.lane + 64 < c.ncr) ? c.lv->root[c.lane + 64] : SK_NOCRATE;
+  SkCrates<NH> root;
+  root.load_level(c, c.lv->root);
   root.store(c, 0);
   const int h0 = sk_heuristic(c, root);
   if (c.lane == 0) {
@@ -786,11 +907,11 @@ __device__ __attribute__((always_inline)) inline bool sk_stage_heap(SokoCtx &c, 
 }
 
 // expander wave: one node of the search bound to c (AStarAgent.getSolution's loop body without the heap, engine.py:104-119)
-template <bool BIG>
+template <int NH>
 __device__ __attribute__((always_inline)) inline void sk_expand(SokoCtx &c, SokoPipe &pp, int cur, int b2, int &best, int &best_h, int &best_depth) {
   const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
   SokoNode nd = SokoNode::unpack(c.nodes[cur]);
-  SkCrates<BIG> cr;
+  SkCrates<NH> cr;
   cr.load(c, cur);
   nd.depth = sk_u(nd.depth);
   nd.h = sk_u(nd.h);
@@ -817,7 +938,7 @@ __device__ __attribute__((always_inline)) inline void sk_expand(SokoCtx &c, Soko
       const int nx = px + DX[d], ny = py + DY[d];
       if (nx < 0 || ny < 0 || nx > c.lv->w - 1 || ny > c.lv->h - 1 || sk_bit(c.lv->solid, nx, ny)) continue;
       const int moved = cr.at(nx, ny);
-      SkCrates<BIG> ch = cr;
+      SkCrates<NH> ch = cr;
       int h = nd.h;  // the heuristic depends on the crates only
       if (moved >= 0) {
         const int bx = nx + DX[d], by = ny + DY[d];
@@ -826,8 +947,7 @@ __device__ __attribute__((always_inline)) inline void sk_expand(SokoCtx &c, Soko
         const int ndead = n_dead - (sk_bit(c.lv->dead, nx, ny) ? 1 : 0) + (sk_bit(c.lv->dead, bx, by) ? 1 : 0);
         if (ndead > 0) continue;
         const uint32_t np = (uint32_t)bx | ((uint32_t)by << 8);
-        if (!BIG || moved < 64) ch.c0 = c.lane == moved ? np : ch.c0;
-        else ch.c1 = c.lane == moved - 64 ? np : ch.c1;
+        ch.move(c, moved, np);
         h = sk_heuristic(c, ch);
       }
       if (c.n_nodes >= c.max_nodes) {  // cannot happen (<= 1 + 4 * iterations nodes per stage); reported if it does
@@ -901,7 +1021,7 @@ __device__ __attribute__((always_inline)) inline void sokoban_expander(const Par
       c.n_nodes = 1;
       best = -1;
       best_h = best_depth = 0;
-      const int h0 = c.ncr > 64 ? sk_root<true>(c, px, py) : sk_root<false>(c, px, py);
+      const int h0 = c.ncr > 64 ? sk_root<2>(c, px, py) : sk_root<1>(c, px, py);
       if (c.lane == 0) pp.res = sk_u32x4{0u, 0u, (uint32_t)h0, 0u};
     } else if (cur == SK_JOB_END) {
       if (c.lane == 0) {
@@ -911,8 +1031,8 @@ __device__ __attribute__((always_inline)) inline void sokoban_expander(const Par
       c.pool_full = false;
     } else {
       c.n_nodes = sk_u(c.n_nodes);
-      if (c.ncr > 64) sk_expand<true>(c, pp, cur, b2, best, best_h, best_depth);
-      else sk_expand<false>(c, pp, cur, b2, best, best_h, best_depth);
+      if (c.ncr > 64) sk_expand<2>(c, pp, cur, b2, best, best_h, best_depth);
+      else sk_expand<1>(c, pp, cur, b2, best, best_h, best_depth);
       best = sk_u(best);
       best_h = sk_u(best_h);
       best_depth = sk_u(best_depth);
@@ -925,10 +1045,10 @@ __device__ __attribute__((always_inline)) inline void sokoban_expander(const Par
 }
 
 // The reference's cascade (sokoban_prob.py:99-148), all four stages on the calling wave (stage workspace 0).
-template <bool BIG>
+template <int NH>
 __device__ __attribute__((always_inline)) inline bool sk_cascade(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
   sk_bind(c, pool, slot, 0);
-  sk_root<BIG>(c, px, py);
+  sk_root<NH>(c, px, py);
   // If the BFS stage expands the whole reachable state space without finding a win, no stage can win, each A*
   // stage would expand exactly the same set of states (pushes = 1 + sum of children over unique states, whatever
   // the order) and end with bestNode.h = min h over that set -- which the BFS stage already holds.  Skipping the
@@ -937,14 +1057,14 @@ __device__ __attribute__((always_inline)) inline bool sk_cascade(SokoCtx &c, con
   for (int st = 0; st < SK_STAGES && !won && !exhausted; st++)  // (one call site: the stage is inlined once)
   {
     bool ex = false;
-    won = sk_stage<BIG>(c, pool, slot, st == 0 ? -1 : 3 - st, power, h, depth, &ex);
+    won = sk_stage<NH>(c, pool, slot, st == 0 ? -1 : 3 - st, power, h, depth, &ex);
     exhausted = st == 0 && ex;  // (only the BFS stage's flag ends the cascade, see above)
   }
   return won;
 }
 
 // The same with helper waves: this wave runs the BFS stage, helper k (1..3) the A* stage with balance (3 - k) / 2.
-template <bool BIG>
+template <int NH>
 __device__ __attribute__((always_inline)) inline bool sk_cascade_helped(SokoCtx &c, const SokoPool &pool, int slot, int power, int px, int py, int &h, int &depth) {
   SokoMail &m = sk_shared().mail;
   int seq = 0;
@@ -960,9 +1080,9 @@ __device__ __attribute__((always_inline)) inline bool sk_cascade_helped(SokoCtx 
   }
   seq = __builtin_amdgcn_readfirstlane(seq);
   sk_bind(c, pool, slot, 0);
-  sk_root<BIG>(c, px, py);
+  sk_root<NH>(c, px, py);
   bool exhausted = false;
-  bool won = sk_stage<BIG>(c, pool, slot, -1, power, h, depth, &exhausted);
+  bool won = sk_stage<NH>(c, pool, slot, -1, power, h, depth, &exhausted);
   if (won || exhausted) {
     if (c.lane == 0) sk_st(&m.cancel_after, 0);
   } else {
@@ -1059,7 +1179,9 @@ __device__ inline void sokoban_helpers_release() {
 // Called by every lane of the wave in uniform control flow; `need` is uniform per group.  Groups that need the
 // solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
 // and never waits for a slot while holding one.
-template <int LPE, typename M>
+// HUGE: the kernel also carries the search for levels with more than SK_MAXC pairs (every kernel except the compile-time
+// 16x16 ones, whose maps hold at most 127 pairs)
+template <int LPE, typename M, bool HUGE>
 __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player,
                                                         M crate, M target, int &dist_win, int &sol_len) {
   (void)env;
@@ -1131,17 +1253,18 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
       const uint64_t below = (1ull << g.lane) - 1ull;
       if ((cr >> g.lane) & 1ull) {
         const int k = ncr + __popcll(cr & below);
-        if (k < SK_MAXC) s_level.root[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
+        if (k < (HUGE ? SK_MAXC_HUGE : SK_MAXC)) s_level.root[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
       }
       if ((tg >> g.lane) & 1ull) {
         const int k = ntg + __popcll(tg & below);
-        if (k < SK_MAXC) s_level.target[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
+        if (k < (HUGE ? SK_MAXC_HUGE : SK_MAXC)) s_level.target[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
       }
       ncr += __popcll(cr);
       ntg += __popcll(tg);
     }
     int dw = dist_win, sl = sol_len;
-    if (ncr > SK_MAXC || ntg > SK_MAXC || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {
+    constexpr int MAXC = HUGE ? SK_MAXC_HUGE : SK_MAXC;
+    if (ncr > MAXC || ntg > MAXC || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {
       if (g.lane == 0) atomicOr(p.err, 2);  // beyond the device solver's limits: reported by pcgrl_poll_error
     } else {
       c.ncr = ncr;
@@ -1153,12 +1276,17 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
       sk_init_deadlocks(c);
       bool won;
       int h = 0, depth = 0;
-      if (p.sk_helpers != 0) {
-        if (ncr > 64) won = sk_cascade_helped<true>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
-        else won = sk_cascade_helped<false>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+      if (ncr > SK_MAXC) {
+        // more pairs than two registers per lane hold: this wave alone, stage after stage, eight registers per lane (the
+        // helper waves, if any, get no job and keep waiting)
+        if constexpr (HUGE) won = sk_cascade<SK_NH_HUGE>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+        else won = false;
+      } else if (p.sk_helpers != 0) {
+        if (ncr > 64) won = sk_cascade_helped<2>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+        else won = sk_cascade_helped<1>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
       } else {
-        if (ncr > 64) won = sk_cascade<true>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
-        else won = sk_cascade<false>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+        if (ncr > 64) won = sk_cascade<2>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
+        else won = sk_cascade<1>(c, pool, slot, p.cfg.solver_power, px, py, h, depth);
       }
       if (won) {
         dw = 0;

@@ -1047,6 +1047,47 @@ def gen_stats_sokoban_solver_wide():
     np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver_wide.npz"), stat_keys=np.array(STAT_KEYS["sokoban"]), **out)
 
 
+def gen_stats_sokoban_solver_huge():
+    """levels with MORE THAN 128 crate / target pairs (maps of >= 258 cells can hold them; the reference runs its solver on
+    any number, sokoban_prob.py:172-177): one player, k = 129 .. 300 pairs, a single region, on 23 x 23, 24 x 21 and 32 x 32
+    maps -- packed levels (the player can hardly move: the searches run dry), open ones (every stage runs to its iteration
+    limit; `solver_power` lowered to keep the reference's Python solver within minutes) and levels whose first pushes win
+    nothing.  Stored with the solver_power each was answered with."""
+    rng = np.random.default_rng(35)
+    E, S, P, C, T = range(5)
+    grids, stats, powers, shapes = [], [], [], []
+    for shape, k, n_solid, power in (((23, 23), 129, 0, 250), ((23, 23), 200, 6, 400), ((23, 23), 262, 0, 10000), ((24, 21), 140, 10, 250),
+                                     ((24, 21), 250, 0, 10000), ((32, 32), 300, 20, 150), ((32, 32), 505, 0, 10000), ((17, 16), 130, 0, 300)):
+        core = _problem("sokoban", shape)
+        core._prob._solver_power = power
+        while True:
+            g = np.full(shape, E, np.uint8)
+            cells = rng.permutation(shape[0] * shape[1])
+            order = [P] + [C] * k + [T] * k + [S] * n_solid
+            if len(order) > len(cells):
+                raise ValueError((shape, k))
+            for c_, t in zip(cells, order):
+                g[c_ // shape[1], c_ % shape[1]] = t
+            st = _get_stats(core, "sokoban", g) if True else None
+            if st[3] == 1:  # one region: the solver ran
+                break
+        assert st[0] == 1 and st[1] == k and st[2] == k and st[4] != shape[0] * shape[1] * (shape[0] + shape[1]) or st[5] > 0, st
+        pad = np.full((32, 32), 255, np.uint8)
+        pad[:shape[0], :shape[1]] = g
+        grids.append(pad)
+        stats.append(st)
+        powers.append(power)
+        shapes.append(shape)
+        print("stats_sokoban_solver_huge", shape, "pairs", k, "power", power, "stats", st.tolist(), flush=True)
+    np.savez_compressed(os.path.join(OUT, "stats_sokoban_solver_huge.npz"), grids=np.array(grids), stats=np.array(stats, np.int32),
+                        solver_power=np.array(powers, np.int32), shapes=np.array(shapes, np.int32), stat_keys=np.array(STAT_KEYS["sokoban"]))
+
+
+if __name__ == "__main__" and "sokohuge" in sys.argv[1:]:
+    gen_stats_sokoban_solver_huge()
+    sys.exit(0)
+
+
 if __name__ == "__main__" and "sokowide" in sys.argv[1:]:
     gen_stats_sokoban_solver_wide()
     sys.exit(0)

@@ -1399,6 +1399,36 @@ def test_golden_sokoban_solver_other_shapes_known_answers():
             env.check_errors()
 
 
+def test_golden_sokoban_solver_more_than_128_pairs():
+    """levels with 129 .. 505 crate / target pairs against the reference's answers: more pairs than two registers per lane
+    hold, searched with eight (SK_NH_HUGE) on the simulate wave alone, through stats_for_grids (helper waves present) and
+    through a reset with injected maps (step-path kernels)"""
+    z = np.load(os.path.join(GOLDEN, "stats_sokoban_solver_huge.npz"))
+    for g, want, power, shape in zip(z["grids"], z["stats"], z["solver_power"], z["shapes"]):
+        h, w = int(shape[0]), int(shape[1])
+        grid = np.ascontiguousarray(g[:h, :w])
+        env = _vec("sokoban", "narrow", (h, w), 3, auto_reset=False, solver_power=int(power))
+        got = env.stats_for_grids(torch.as_tensor(grid[None])).cpu().numpy()
+        assert np.array_equal(got[0], want), f"{h}x{w} power {int(power)}: got {got[0].tolist()} want {want.tolist()}"
+        env.reset(init_grids=torch.as_tensor(np.repeat(grid[None], 3, 0)))
+        st = env.get_state().stats.cpu().numpy()
+        assert np.array_equal(st, np.repeat(want[None], 3, 0)), f"{h}x{w} through pcgrl_reset: {st.tolist()}"
+        env.check_errors()  # nothing was refused
+
+
+def test_fuzz_cases_with_more_than_128_pairs_replay():
+    """the two cases the round-3 fuzzer reported as REFUSED (random 24 x 21 / 23 x 23 maps that met the solver's
+    precondition with more than 128 pairs) replay green against the oracle"""
+    import json
+    import fuzz_parity as fz
+    for line in ('{"problem": "sokoban", "kw": {"obs_window": [42, 28], "solver_power": 50}, "rep": "turtle", "shape": [24, 21], "n_envs": 809, "steps": 54, "bias": false, "mode": "mixed", "auto_reset": true, "seed": 480642379}',
+                 '{"problem": "sokoban", "kw": {"change_percentage": 0.001, "solver_power": 500}, "rep": "wide", "shape": [23, 23], "n_envs": 68, "steps": 123, "bias": false, "mode": "adapter", "auto_reset": true, "seed_kind": "huge", "seed": 656225453}'):
+        c = json.loads(line)
+        seed = c.pop("seed")
+        run = {"adapter": fz.run_adapter_case, "gym": fz.run_gym_case}.get(c.get("mode"), fz.run_case)
+        assert run(c, seed) >= 0
+
+
 def test_loss_integer_and_float64_forms_agree():
     """get_loss has an integer form (all static targets integral: every stock problem) and the float64 form; a
     non-integral target on a zero-weighted statistic switches an engine to the float64 form without changing any reward."""
@@ -1577,6 +1607,7 @@ def test_fuzz_sweep_fixed_seed():
     import fuzz_parity
     failures = fuzz_parity.sweep(250, 20261002, verbose=False, stop_on_fail=False)
     assert not failures, failures[:3]
+    assert not fuzz_parity.sweep.refused, fuzz_parity.sweep.refused[:3]  # nothing the generator draws is refused at run time
 
 
 def test_injected_maps_with_action_patch_ignore_init_pos():
