@@ -75,9 +75,14 @@ NOTES = {
     "binary-narrow-static": "static tiles (p ≤ 0.3, 3 walls), general kernel",
     "binary-narrow-patch3x3": "3×3 action patch, general kernel",
     "sokoban-wide-solver": "solver-active, see below",
+    "binary_big-narrow": "the reference's `binary_big` task (32², window 64²; `configs/task/binary_big.yaml:5-6`): one-hot rows in LDS (13 KB per workgroup)",
+    "binary_bigger-narrow": "`binary_bigger` (64², window 128²; `binary_bigger.yaml:5-6`): 64-bit row masks, observation chunks from tile codes; the launch ends with the env whose path search is longest",
+    "zelda_big-turtle": "`zelda_big` (32², window 64²; `zelda_big.yaml:5-6`): observation chunks from tile codes (§4.1)",
+    "minecraft_3D_maze-narrow-15": "the reference's stock 3-D map (`configs/config.py:153-157`), two whole episodes: one workgroup per CU (147 KB of LDS), three observe waves",
 }
-rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac | same-size fill µs | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|---|"]
-for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
+rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac (wall / kernel mean) | same-size fill µs (step ÷ fill) | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|---|"]
+for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle",
+          "minecraft_3D_maze-narrow-15", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
     if w not in lines:
         continue
     l = lines[w]
@@ -85,11 +90,12 @@ for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-na
     ks = f"{k['mean'] / 1e3:.2f} / {k['median'] / 1e3:.2f}" if k else "–"
     ro = l.get("open_loop_rollout")
     cb = l.get("cpu_baseline")
-    rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {ks} | {l['roofline']['frac']:.3f} | "
-                + (f"{l['roofline']['fill_same_bytes']['us']:.2f}" if l['roofline'].get('fill_same_bytes') else "–") + " | "
+    kf = (l['roofline']['algorithmic_bytes_per_launch'] / (k['mean'] * 1e-9) / 8e12) if k else None
+    rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {ks} | {l['roofline']['frac']:.3f}" + (f" / {kf:.3f}" if kf else "") + " | "
+                + (f"{l['roofline']['fill_same_bytes']['us']:.2f} ({l['roofline']['fill_same_bytes']['step_over_fill']:.2f} ×)" if l['roofline'].get('fill_same_bytes') else "–") + " | "
                 + (f"{ro['us_per_step']:.2f}" if ro else "–") + " | " + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + f" | {NOTES.get(w, '')} |")
 extra = []
-for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow"):
+for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle", "minecraft_3D_maze-narrow-15"):
     s_ = summ["workloads"].get(w, {})
     if "hbm_traffic_per_launch" in s_ and "lds" in s_:
         extra.append(f"{w}: traffic {s_['hbm_traffic_per_launch']['traffic_bytes'] / 1e6:.1f} MB / launch = {s_['hbm_traffic_per_launch']['traffic_over_algorithmic']:.2f} × algorithmic, "
@@ -104,12 +110,56 @@ if sa:
                      f"{100 * sa['solver_active']['envs_with_solver_result_at_end']:.0f} % of the envs with a solver result at the end, "
                      f"{100 * sa['solver_active']['envs_solved_at_end']:.0f} % solved); CPU oracle: {sci(cb.get('value', 0))} on {cb.get('cores', '?')} threads.")
 
-blocks = {"HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active}
+# saturation sweeps: the BASELINE batch x1 / x4 / x16
+sweep_rows = ["| workload | envs/GPU | env-steps/s | µs per step launch | roofline frac | same-size fill µs (step ÷ fill) |", "|---|---|---|---|---|---|"]
+for w, sizes in (("binary-narrow", ("", "-65536")), ("zelda-turtle", ("", "-16384", "-65536")), ("sokoban-wide", ("", "-8192", "-32768")),
+                 ("minecraft_3D_maze-narrow", ("", "-4096", "-16384"))):
+    for sfx in sizes:
+        l = lines.get(w + sfx)
+        if not l:
+            continue
+        f_ = l["roofline"].get("fill_same_bytes")
+        sweep_rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {l['roofline']['frac']:.3f} | "
+                          + (f"{f_['us']:.2f} ({f_['step_over_fill']:.2f} ×)" if f_ else "–") + " |")
+sweep_table = "\n".join(sweep_rows)
+
+# evolution-driver pattern
+evo_rows = ["| workload | units per launch | throughput | µs per launch | roofline frac | CPU oracle (threads) |", "|---|---|---|---|---|---|"]
+for w, what in (("binary-narrow-evo", "4096 envs: `pcgrl_update` (+ observation) per step, `pcgrl_refresh_stats` every 256 steps"),
+                ("binary-stats-for-grids", "65 536 maps per `pcgrl_stats_for_grids_h` launch"), ("zelda-stats-for-grids", "65 536 maps per launch")):
+    l = lines.get(w)
+    if not l:
+        continue
+    cb = l.get("cpu_baseline") or {}
+    evo_rows.append(f"| {w}: {what} | {l['config']['envs_per_gpu']} | {sci(l['value'])} {l['unit']} | {l['ms_per_step'] * 1e3:.2f} | {l['roofline']['frac']:.3f} | "
+                    + (f"{sci(cb['value'])} {cb.get('unit', '')} ({cb['cores']})" if cb else "–") + " |")
+evo_table = "\n".join(evo_rows)
+
+# RLlib-shaped adapter
+ad = (lines.get("binary-narrow") or {}).get("rllib_adapter")
+base = None
+try:
+    base = {r["envs"]: r for r in json.load(open(os.path.join(ROOT, "profiles", "r04_rllib_adapter_r3_baseline.json")))["rows"]}
+except Exception:
+    pass
+ad_rows = ["| envs | hand-out | env-steps/s | host µs per `vector_step` | device→host bytes per call | vs the round-3 adapter (float32) |", "|---|---|---|---|---|---|"]
+if ad:
+    for r in ad["rows"]:
+        b0 = base.get(r["envs"]) if base else None
+        mode = r["obs_dtype"] + (", kernel writes pinned host memory" if r["kernel_writes_host_memory"] else ", one copy")
+        ad_rows.append(f"| {r['envs']} | {mode} | {sci(r['env_steps_per_s'])} | {r['host_us_per_vector_step']:.1f} | {r['d2h_bytes_per_call']} | "
+                       + (f"{r['env_steps_per_s'] / b0['env_steps_per_s']:.2f} × ({sci(b0['env_steps_per_s'])})" if b0 else "–") + " |")
+adapter_table = "\n".join(ad_rows)
+
+blocks = {"HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active,
+          "SWEEP_TABLE": sweep_table, "EVO_TABLE": evo_table, "ADAPTER_TABLE": adapter_table}
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 for name, text in blocks.items():
     inline = name in ("DRIVER20", "SOLVER_ACTIVE")
     new = f"<!-- {name} -->{'' if inline else chr(10)}{text}{'' if inline else chr(10)}<!-- /{name} -->"
+    if f"<!-- {name} -->" not in s and f"@@{name}@@" not in s:
+        continue
     if f"@@{name}@@" in s:
         s = s.replace(f"@@{name}@@", new)
     else:
@@ -117,5 +167,8 @@ for name, text in blocks.items():
 open(p, "w").write(s)
 print(headline)
 print(workload_table)
+print(sweep_table)
+print(evo_table)
+print(adapter_table)
 print(driver20)
 print(solver_active)
