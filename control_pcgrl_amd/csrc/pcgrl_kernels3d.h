@@ -1185,7 +1185,10 @@ __device__ inline void m3_copy_batched(uint4 *dst, const uint4 *src, int from, i
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
 // HELP (pcgrl_step, size class 0): a third wavefront runs second searches speculatively, see SPECULATION.
 template <int MODE, int SC, bool D7 = false>
-__global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())) : 64) void m3_kernel(Params p, int cpl) {
+// (size class 0 step kernel: 129 VGPRs would mean 3 waves per SIMD = 4 workgroups per CU where the LDS allows 5; the
+// second launch bound asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
+__global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
+void m3_kernel(Params p, int cpl) {
   constexpr int PW = M3C<SC>::PW;
   constexpr bool HELP = MODE == M3_STEP && SC == 0;
   if (MODE == M3_STEP) touch_kernarg(p);  // every line of the argument block in one scalar-memory round trip
