@@ -1086,6 +1086,33 @@ def test_state_dict_round_trip_continues_bit_exactly(problem, rep, shape, xkw):
     other.check_errors()
 
 
+def test_state_image_from_another_config_is_refused():
+    """pcgrl_import_state checks the image's header: an image of the same byte size from an engine with other weights, another
+    change budget or another problem of the same layout (none of which change pcgrl_state_bytes) is refused before anything
+    is overwritten; a corrupted header is refused as well"""
+    n = 32
+    a = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True)
+    a.reset()
+    a.step(torch.zeros(n, dtype=torch.int32, device=a.device))
+    sd = a.state_dict()
+    before = a.get_state().grids.clone()
+    for kw in (dict(weights={"regions": 2.0, "path-length": 1.0}), dict(change_percentage=0.5), dict(max_board_scans=2)):
+        b = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), auto_reset=True, **kw)
+        b.reset()
+        keep = b.get_state().grids.clone()
+        assert b._L.pcgrl_state_bytes(b._h) == a._L.pcgrl_state_bytes(a._h)
+        with pytest.raises(ValueError, match="another config"):
+            b.load_state_dict(sd)
+        assert torch.equal(b.get_state().grids, keep), "a refused image must not touch the engine"
+    bad = dict(sd, blob=sd["blob"].clone())
+    bad["blob"][0] ^= 0xFF
+    with pytest.raises(ValueError, match="magic"):
+        a.load_state_dict(bad)
+    a.load_state_dict(sd)  # the right image still imports
+    assert torch.equal(a.get_state().grids, before)
+    a.check_errors()
+
+
 def test_stats_for_grids_any_batch_size_and_async():
     """Problem.get_stats through an existing engine's scratch: the number of maps is independent of the engine's batch."""
     z = np.load(os.path.join(GOLDEN, "stats_sokoban.npz"))
@@ -1325,8 +1352,12 @@ def test_rllib_vector_env_adapter_controllable_and_rep_wrappers():
     assert env.observation_space.shape == (32, 32, 3 + K2) and float(np.max(env.observation_space.high)) == 1.0
     n, t = int(z["steps_per_episode"]), 0
     for ep in range(len(z["reset_at"])):
-        env.get_sub_environments()[0].set_trgs({k: float(v) for k, v in zip(controls, z["reset_trg"][ep])})
+        sub = env.get_sub_environments()[0]
+        trgs_before = dict(sub.metric_trgs)
+        sub.set_trgs({k: float(v) for k, v in zip(controls, z["reset_trg"][ep])})
+        assert sub.metric_trgs == trgs_before, "queued targets are not the env's targets before its next reset (control_wrappers.py:174-178)"
         obs = env.vector_reset()[0] if ep == 0 else [env.reset_at(0)[0], env.reset_at(1)[0]]
+        assert all(sub.metric_trgs[k] == float(v) for k, v in zip(controls, z["reset_trg"][ep]))
         assert obs[0].shape == (32, 32, 3 + K2) and np.all(obs[0][..., :K2] == obs[0][0, 0, :K2])
         assert np.allclose(obs[0][3, 4, :K2], z["reset_ctrl"][ep], rtol=1e-6, atol=1e-7)
         assert zlib.crc32(obs[0][..., K2:].astype(np.uint8).tobytes()) == int(z["reset_obs_crc"][ep])
