@@ -552,7 +552,10 @@ def main():
         if rollout is not None:
             out["open_loop_rollout"] = rollout
         if args.rllib_adapter > 0 or (args.rllib_adapter < 0 and args.workload == "binary-narrow" and args.envs == 0):
-            out["rllib_adapter"] = rllib_adapter_bench(problem, rep, shape, dev)
+            try:  # (a secondary figure must never cost the run its line)
+                out["rllib_adapter"] = rllib_adapter_bench(problem, rep, shape, dev)
+            except Exception as exc:  # noqa: BLE001
+                out["rllib_adapter"] = {"error": repr(exc)}
         if not args.no_cpu_baseline:  # rank 0 only, also with N > 1 ranks (the others wait at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT,
                                                mode="evo" if evo else "sfg" if sfg else "step", maps=sfg_host if sfg else None)
