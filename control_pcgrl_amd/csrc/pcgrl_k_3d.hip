@@ -27,11 +27,20 @@ hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s
   const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7 && p.cfg.obs_window[0] == 14 &&
                   p.cfg.obs_window[1] == 14 && p.cfg.obs_window[2] == 14;
   if (d7 && id == K_STEP) {
-    hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, true>), grid, dim3(192), 0, s, p, cpl);
+    hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7>), grid, dim3(192), 0, s, p, cpl);
     return hipGetLastError();
   }
   if (d7 && id == K_ROLLOUT) {
-    hipLaunchKernelGGL((m3_kernel<M3_ROLLOUT, 0, true>), grid, block, 0, s, p, cpl);
+    hipLaunchKernelGGL((m3_kernel<M3_ROLLOUT, 0, 7>), grid, block, 0, s, p, cpl);
+    return hipGetLastError();
+  }
+  // the reference's stock map (configs/config.py:153-157) with its 30^3 window: the same with compile-time dimensions (the
+  // size class 1 kernels keep ~100 wave-uniform values alive and spill scalar registers into vector lanes: constant strides
+  // and bounds take a third of the step kernel's instructions away)
+  const bool d15 = p.cfg.dims[0] == 15 && p.cfg.dims[1] == 15 && p.cfg.dims[2] == 15 && p.cfg.obs_window[0] == 30 &&
+                   p.cfg.obs_window[1] == 30 && p.cfg.obs_window[2] == 30;
+  if (d15 && id == K_STEP) {
+    hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 15>), grid, dim3(64 * (1 + m3_observers<1>())), 0, s, p, cpl);
     return hipGetLastError();
   }
   if (m3_size_class(p.cfg.dims[0], p.cfg.dims[1], p.cfg.dims[2]) == 0) return launch_3d_sc<0>(id, p, cpl, s);

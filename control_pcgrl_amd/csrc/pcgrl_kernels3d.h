@@ -259,6 +259,9 @@ struct M3ObsLds {  // each observe wave's own copy of the tile and overlay bits 
 
 struct M3Ctx {
   int lane, Z, Y, X, YX, n_cells;
+#ifdef PCGRL_PHASE_TIMING
+  int knob;  // development (timing builds): cfg.solver_power, see m3_update_moves
+#endif
   M3Lay L;
   // views into the env's record in LDS
   uint32_t *dirt, *over, *slots;
@@ -279,7 +282,7 @@ __device__ inline int m3_below(uint64_t mask) {
 
 // (Y*X)-bit AIR mask of plane z from the flat bit string.  Words past the string are whatever follows it in the record:
 // the plane mask removes them.
-template <int PW>
+template <int PW, bool INVERT = true>
 __device__ inline PM<PW> m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int z) {
   PM<PW> r;
   const int b0 = z * c.YX;
@@ -291,10 +294,13 @@ __device__ inline PM<PW> m3_plane_air(const uint32_t *dirt, const M3Ctx &c, int 
     if (s) v |= (uint64_t)dirt[w + 2] << (64 - s);
     const int left = c.YX - 64 * k;  // plane bits in this word and beyond
     const uint64_t pm = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
-    r.w[k] = ~v & pm;
+    r.w[k] = (INVERT ? ~v : v) & pm;
   }
   return r;
 }
+// plane z of any per-cell bit string as it is (set bits, not AIR = clear bits)
+template <int PW>
+__device__ inline PM<PW> m3_plane_bits(const uint32_t *bits, const M3Ctx &c, int z) { return m3_plane_air<PW, false>(bits, c, z); }
 
 // bits [start, start + len) of a plane mask, len < 64
 template <int PW>
@@ -470,6 +476,9 @@ __device__ inline uint32_t m3_update_moves(const M3Ctx &c, int ex, int ey, int e
   chg_cell = cell;
   if (chg) c.mv[cell * 4 + d] = (int16_t)nw_;
   uint32_t dropped = 0;
+#ifdef PCGRL_PHASE_TIMING
+  if (c.knob == 3) return 0u;  // development: time without the slot-drop test (results are wrong)
+#endif
   if (M3_BALLOT(chg) != 0) {
     // (all reads first: one LDS round trip for the whole loop)
     constexpr int MAXS = 14;
@@ -983,19 +992,19 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
   // path tile (x,y,z) is drawn at array index [x][y][z]
   for (int i = c.lane; i < c.L.nw; i += 64) c.over[i] = 0;
   if (best_slot >= 0) {
+    // Lane z holds plane z of the path as a bit mask, so "no path tile directly below" (remove_stacked_path_tiles) is one
+    // shift between lanes; what is left -- a handful of tiles per plane -- is drawn bit by bit, every lane its own plane.
+    // (Round 3 walked all Z heights of every column: 60 dependent LDS reads per lane at 15^3, 4 us of a changing step.)
     const uint32_t *pathm = c.spath(best_slot);
-#pragma unroll
-    for (int k = 0; k < PW; k++) {
-      const int q = 64 * k + c.lane, y = q / c.X, x = q - y * c.X;  // this lane's column (q < YX)
-      // tiles of the column as a bit mask over z, then "no path tile directly below"
-      uint32_t colp = 0;
-      for (int z = 0; z < c.Z; z++) colp |= (q < c.YX && m3_bit(pathm, z * c.YX + q)) ? 1u << z : 0u;
-      uint32_t keep = colp & ~(colp << 1);
-      if (x >= c.Z) keep = 0;
-      while (keep) {
-        const int z = __builtin_ctz(keep);
-        keep &= keep - 1u;
-        if (z < c.X) {
+    const PM<PW> P = c.lane < c.Z ? m3_plane_bits<PW>(pathm, c, c.lane) : pm_zero<PW>();
+    PM<PW> keep = P & ~pm_up(P);  // (lane z - 1's plane; zero into lane 0)
+    const int z = c.lane;
+    while (M3_BALLOT(pm_any(keep)) != 0) {
+      if (pm_any(keep)) {
+        const int q = pm_ctz(keep);
+        keep = keep & ~pm_lowest(keep);
+        const int y = q / c.X, x = q - y * c.X;
+        if (x < c.Z && z < c.X) {
           const int oi = (x * c.Y + y) * c.X + z;
           atomicOr(&c.over[oi >> 5], 1u << (oi & 31));
         }
@@ -1051,16 +1060,16 @@ __device__ inline void m3_encode_obs_cells(const uint32_t *dirt, const uint32_t 
 // Pass 1: per window row (i, j) two o2-bit masks -- bit k = low / high bit of the channel of cell (i, j, k) -- into
 // `scratch` (o0 * o1 + 1 entries).  Pass 2: every 16-byte chunk (4 cells, possibly across a row end) picks its bits from
 // the masks of two consecutive rows; chunk ch = lane + 64 * t, so a store instruction covers 1 KiB of consecutive bytes.
-// W14: the BASELINE window 14 x 14 x 14 with compile-time sizes.
-template <bool W14>
+// WIN: a cubic window with compile-time sizes (14: BASELINE's, 30: the reference's stock map's), 0: run-time sizes.
+template <int WIN>
 __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over, const M3Ctx &c, const Params &p, int env, const int *pos,
                                      bool show_path, uint2 *scratch, int scratch_rows, uint8_t *obs_base = nullptr, int part = 0,
                                      int nparts = 1) {
   if (p.obs == nullptr) return;
   if (obs_base == nullptr) obs_base = p.obs;
-  const int o0 = W14 ? 14 : p.cfg.obs_window[0], o1 = W14 ? 14 : p.cfg.obs_window[1], o2 = W14 ? 14 : p.cfg.obs_window[2];
+  const int o0 = WIN ? WIN : p.cfg.obs_window[0], o1 = WIN ? WIN : p.cfg.obs_window[1], o2 = WIN ? WIN : p.cfg.obs_window[2];
   const int rows = o0 * o1;
-  if (!W14 && (rows + 1 > scratch_rows || o2 > 32 || o2 < 2)) {  // (o2 == 1: a chunk of 4 cells spans 4 rows, pass 2 reads 2)
+  if (!WIN && (rows + 1 > scratch_rows || o2 > 32 || o2 < 2)) {  // (o2 == 1: a chunk of 4 cells spans 4 rows, pass 2 reads 2)
     if (part == 0) m3_encode_obs_cells(dirt, over, c, p, env, pos, show_path, obs_base);
     return;
   }
@@ -1181,10 +1190,11 @@ __device__ inline void m3_copy_batched(uint4 *dst, const uint4 *src, int from, i
   }
 }
 
-// D7: the BASELINE map shape 7 x 7 x 7 and observation window 14 x 14 x 14 with compile-time dimensions (the search trip
+// DIM: a cubic map DIM^3 with its 2 DIM window as compile-time dimensions -- 7: BASELINE's shape, 15: the reference's stock
+// map (configs/config.py:153-157); 0: run-time dimensions (the search trip
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
 // HELP (pcgrl_step, size class 0): a third wavefront runs second searches speculatively, see SPECULATION.
-template <int MODE, int SC, bool D7 = false>
+template <int MODE, int SC, int DIM = 0>
 // (size class 0 step kernel: 129 VGPRs would mean 3 waves per SIMD = 4 workgroups per CU where the LDS allows 5; the
 // second launch bound asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
 __global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
@@ -1203,12 +1213,15 @@ void m3_kernel(Params p, int cpl) {
   __shared__ M3ObsLds<SC> O;
   M3Ctx c;
   c.lane = (int)__lane_id();
-  c.Z = D7 ? 7 : p.cfg.dims[0];
-  c.Y = D7 ? 7 : p.cfg.dims[1];
-  c.X = D7 ? 7 : p.cfg.dims[2];
-  if (D7) cpl = 6;  // ceil(343 / 64)
+  c.Z = DIM ? DIM : p.cfg.dims[0];
+  c.Y = DIM ? DIM : p.cfg.dims[1];
+  c.X = DIM ? DIM : p.cfg.dims[2];
+  if (DIM) cpl = (DIM * DIM * DIM + 63) / 64;
   c.YX = c.Y * c.X;
   c.n_cells = c.Z * c.YX;
+#ifdef PCGRL_PHASE_TIMING
+  c.knob = p.cfg.solver_power;
+#endif
   c.L = m3_layout(c.Z, c.Y, c.X);
   c.dirt = E.rec;
   c.over = E.rec + c.L.o_over;
@@ -1273,9 +1286,9 @@ void m3_kernel(Params p, int cpl) {
       if (done && p.auto_reset != 0) {  // first observation of the new episode: no overlay (PcgrlEnv.reset)
         m3_reset_rng(odirt, c, p, cpl, rp, rr);
         pos[0] = pos[1] = pos[2] = 0;
-        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, false, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)), nullptr, part, NOBS);
+        m3_encode_obs<2 * DIM>(odirt, oover, c, p, env, pos, false, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)), nullptr, part, NOBS);
       } else {
-        m3_encode_obs<D7>(odirt, oover, c, p, env, pos, true, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)), nullptr, part, NOBS);
+        m3_encode_obs<2 * DIM>(odirt, oover, c, p, env, pos, true, O.rows, (int)(sizeof(O.rows) / sizeof(uint2)), nullptr, part, NOBS);
       }
       TRACE_PUT(4, _tr0);
       TRACE_PUT(3, TRACE_NOW());
@@ -1504,6 +1517,9 @@ void m3_kernel(Params p, int cpl) {
           edited = true;
           dirty_hdr |= m3_update_moves(c, ex, ey, ez, mv_chg, mv_cell);
         }
+#ifdef PCGRL_M3_PHASES
+        M3_MARK(6, 5);  // (development: edit + move-table update, apart from the position arithmetic below)
+#endif
         m3_advance_pos(c, pos, n_step);
       } else if (c.lane == 0) {
         atomicOr(p.err, 1);
@@ -1520,7 +1536,7 @@ void m3_kernel(Params p, int cpl) {
       // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
       // the previous stats update on the already edited map
       M3_MARK(1, 5);  // action + move-table update
-      if (!do_reset && want_obs) m3_encode_obs<D7>(c.dirt, c.over, c, p, env, pos, true, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
+      if (!do_reset && want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, true, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       M3_MARK(1, 5);  // observation (rollout mode)
       if (change) {
         const PM<PW> air = plane_of(c.dirt);
@@ -1600,7 +1616,7 @@ void m3_kernel(Params p, int cpl) {
         ep_return = 0.0;
         trg.load(p, env, true);
         last_loss = trg.loss(p.cfg, st);
-        if (want_obs) m3_encode_obs<D7>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
+        if (want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       }
     }
     if ((ovf || ovf_any) && c.lane == 0) atomicOr(p.err, 4);
