@@ -248,9 +248,9 @@ struct M3Env {
   alignas(16) uint32_t rec[M3C<SC>::REC + 4];
 };
 // observe wavefronts of a pcgrl_step workgroup.  Size class 1 keeps 147 KB of LDS per env, i.e. ONE workgroup per CU, and
-// its observation is 108 KB at 15^3: three waves share its chunks (16.7 us per env on one wave).
+// its observation is 108 KB at 15^3: four waves share it, a contiguous quarter each (16.7 us per env on one wave).
 template <int SC>
-constexpr int m3_observers() { return SC == 0 ? 1 : 3; }
+constexpr int m3_observers() { return SC == 0 ? 1 : 4; }
 template <int SC>
 struct M3ObsLds {  // each observe wave's own copy of the tile and overlay bits + the (shared) row masks of the encoder
   alignas(16) uint32_t bits[m3_observers<SC>()][2 * M3C<SC>::NW + 2];
@@ -1078,7 +1078,12 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
   const int t0 = pos[0] - o0 / 2, t1 = pos[1] - o1 / 2, t2 = pos[2] - o2 / 2;
   const uint32_t xmask = (1u << c.X) - 1u, omask = o2 >= 32 ? 0xFFFFFFFFu : (1u << o2) - 1u;
   const float inv1 = 1.0f / (float)o1, inv2 = 1.0f / (float)o2;
-  for (int r = c.lane; r <= rows; r += 64) {
+  // `part` of `nparts`: several observe waves share the observation, each a contiguous range of chunks -- and only the row
+  // masks that range reads (its rows and the one after), so the waves need nothing from each other
+  const int ch_lo = (int)((long long)chunks * part / nparts), ch_hi = (int)((long long)chunks * (part + 1) / nparts);
+  const int r_lo = nparts > 1 ? (ch_lo * 4) / o2 : 0;
+  const int r_hi = nparts > 1 ? min(rows, (ch_hi * 4 - 1) / o2 + 1) : rows;
+  for (int r = r_lo + c.lane; r <= r_hi; r += 64) {
     const int i = (int)(((float)r + 0.5f) * inv1), j = r - i * o1;  // (exact in fp32 for these sizes)
     const int a = t0 + i, b = t1 + j;
     const bool inb = (r < rows) & ((unsigned)a < (unsigned)c.Z) & ((unsigned)b < (unsigned)c.Y);
@@ -1098,9 +1103,8 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
     const uint32_t in = inb ? (uint32_t)xin & omask : 0u;
     scratch[r] = make_uint2(in & (~(uint32_t)db | (uint32_t)ob), in & ((uint32_t)db | (uint32_t)ob));
   }
-  // (`part` of `nparts`: several observe waves share the chunks -- every wave computes all row masks above, identical
-  // values into the shared scratch, and reads them after its own writes.)  Four chunks per trip: the store is an asm
-  // statement with a memory clobber, so the LDS reads of the next chunk do not move above it by themselves.
+  // Four chunks per trip: the store is an asm statement with a memory clobber, so the LDS reads of the next chunk do not
+  // move above it by themselves.  (Row masks shared by two waves' ranges are written by both: identical values.)
   auto chunk = [&](int ch) -> uint4 {
     const int q0 = ch * 4;
     const int r = (int)(((float)q0 + 0.5f) * inv2), k0 = q0 - r * o2;
@@ -1111,16 +1115,16 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
     for (int t = 0; t < 4; t++) w[t] = 1u << (8 * (((uint32_t)(m0 >> t) & 1u) + 2u * ((uint32_t)(m1 >> t) & 1u)));
     return make_uint4(w[0], w[1], w[2], w[3]);
   };
-  const int stride = 64 * nparts;
-  int ch = c.lane + 64 * part;
-  for (; ch + 3 * stride < chunks; ch += 4 * stride) {
+  const int stride = 64;
+  int ch = ch_lo + c.lane;
+  for (; ch + 3 * stride < ch_hi; ch += 4 * stride) {
     const uint4 v0 = chunk(ch), v1 = chunk(ch + stride), v2 = chunk(ch + 2 * stride), v3 = chunk(ch + 3 * stride);
     store_obs16(dst + ch, v0);
     store_obs16(dst + ch + stride, v1);
     store_obs16(dst + ch + 2 * stride, v2);
     store_obs16(dst + ch + 3 * stride, v3);
   }
-  for (; ch < chunks; ch += stride) store_obs16(dst + ch, chunk(ch));
+  for (; ch < ch_hi; ch += stride) store_obs16(dst + ch, chunk(ch));
 }
 
 // reset from the env's RNG streams (envs/pcgrl_env.py:158-188; probabilities, then the map in (z,y,x) order) into `dirt`.
