@@ -858,14 +858,11 @@ struct ExtRow {
     has32 = xs[1];
     val32 = xs[2];
     prot = ok ? xp[0] : M(0);
-    // (the lagging planes are read whether or not they are in use -- flags bit 0 -- so that their loads do not wait for the
-    // flags word: one memory round trip for the whole wrapper state instead of two)
+    // (the lagging planes are read whether or not they are in use -- flags bit 0 -- and NOT masked here: a test of the flags
+    // word right behind the loads would make everything the kernel loads after them wait for it, i.e. a second memory
+    // round trip.  Every reader tests the flag itself: rep_update_ext, store.)
 #pragma unroll
     for (int k = 0; k < NB; k++) stale[k] = ok ? xp[(size_t)(1 + k) * p.cfg.dims[0]] : M(0);
-    if (!(flags & 1u)) {
-#pragma unroll
-      for (int k = 0; k < NB; k++) stale[k] = M(0);
-    }
   }
   __device__ inline void store(const Params &p, int env, int row, bool ok, bool lead, bool planes) const {
     if (planes && ok) {
