@@ -226,3 +226,28 @@ def test_fuzzer_draws_only_configurations_the_engine_validates():
         if rc == 0:  # (a GPU is present after all)
             L.pcgrl_destroy(h)
     assert refused < 40
+
+
+def test_bench_workload_tables_are_consistent():
+    """every bench workload has its algorithmic bytes (action + map read / 1 B write + uint8 one-hot window +
+    reward / done / stats / pos) and they follow from the shapes; the launcher's GPU count needs no GPU runtime"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.ALGO_BYTES) == set(bench.WORKLOADS)
+    n_stats = {"binary": 2, "zelda": 7, "sokoban": 7, "minecraft_3D_maze": 3}
+    n_tiles = {"binary": 2, "zelda": 8, "sokoban": 5, "minecraft_3D_maze": 2}
+    for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow",
+              "zelda_big-turtle", "minecraft_3D_maze-narrow-15"):
+        problem, rep, shape, _ = bench.WORKLOADS[w][:4]
+        cells = int(np.prod(shape))
+        if rep == "wide":
+            obs, pos = cells * n_tiles[problem], 0
+        elif len(shape) == 3:
+            obs, pos = int(np.prod([2 * s for s in shape])) * 4, 3  # out of bounds, AIR, DIRT, path overlay
+        else:
+            obs, pos = int(np.prod([2 * s for s in shape])) * (n_tiles[problem] + 1), 2
+        assert bench.ALGO_BYTES[w] == 4 + cells + 1 + obs + 4 + 1 + 4 * n_stats[problem] + pos, w
+    n = bench.gpus_without_runtime()
+    assert n is None or (isinstance(n, int) and n >= 0)
