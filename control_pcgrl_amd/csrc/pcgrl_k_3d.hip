@@ -8,7 +8,7 @@ template <int SC>
 static hipError_t launch_3d_sc(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
   switch (id) {
-    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())), 0, s, p, cpl); break;  // simulate + observe (+ helper) waves
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(64 * (2 + m3_observers<SC>())), 0, s, p, cpl); break;  // simulate + observe + helper waves
     case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET, SC>), grid, block, 0, s, p, cpl); break;
     case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE, SC>), grid, block, 0, s, p, cpl); break;
     case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE, SC>), grid, block, 0, s, p, cpl); break;
@@ -40,7 +40,7 @@ hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s
   const bool d15 = p.cfg.dims[0] == 15 && p.cfg.dims[1] == 15 && p.cfg.dims[2] == 15 && p.cfg.obs_window[0] == 30 &&
                    p.cfg.obs_window[1] == 30 && p.cfg.obs_window[2] == 30;
   if (d15 && id == K_STEP) {
-    hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 15>), grid, dim3(64 * (1 + m3_observers<1>())), 0, s, p, cpl);
+    hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 15>), grid, dim3(64 * (2 + m3_observers<1>())), 0, s, p, cpl);
     return hipGetLastError();
   }
   if (m3_size_class(p.cfg.dims[0], p.cfg.dims[1], p.cfg.dims[2]) == 0) return launch_3d_sc<0>(id, p, cpl, s);

@@ -815,11 +815,15 @@ __device__ inline bool m3_second_search(M3Work<SC> &W, const M3Ctx &c, int s, in
 }
 
 // body of the helper wave: serve the simulate wave's jobs until it leaves
-template <int SC>
+// SEARCH: the wave also runs speculative second searches in its own workspace W (size class 0); otherwise it only counts
+// regions (size class 1: there is no LDS for a second workspace) and W is not touched.
+template <int SC, bool SEARCH>
 __device__ inline void m3_helper(const Params &p, M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
   uint32_t epoch = 0, trip = 0;
-  for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
+  if constexpr (SEARCH) {
+    for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
+  }
   PM<PW> notx0, notxl;
   m3_edge_masks<PW>(p, notx0, notxl);
   int seen = 0, rseen = 0;
@@ -859,6 +863,7 @@ __device__ inline void m3_helper(const Params &p, M3Work<SC> &W, const M3Ctx &c,
       continue;
     }
     seen = sq;
+    if constexpr (!SEARCH) continue;  // (never posted without a workspace)
     const int root = __builtin_amdgcn_readfirstlane(m3_ld(&m.root)), s = __builtin_amdgcn_readfirstlane(m3_ld(&m.slot));
     for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
     int far2 = 0, max_dist = 0, n_jump = 0;
@@ -1197,20 +1202,21 @@ __device__ inline void m3_copy_batched(uint4 *dst, const uint4 *src, int from, i
 // DIM: a cubic map DIM^3 with its 2 DIM window as compile-time dimensions -- 7: BASELINE's shape, 15: the reference's stock
 // map (configs/config.py:153-157); 0: run-time dimensions (the search trip
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
-// HELP (pcgrl_step, size class 0): a third wavefront runs second searches speculatively, see SPECULATION.
+// HELP (pcgrl_step): one more wavefront counts the regions while the simulate wave searches and, in size class 0 (HELP_S),
+// runs second searches speculatively, see SPECULATION.  Waves of a step workgroup: 0 simulate, 1 .. NOBS observe, then helper.
 template <int MODE, int SC, int DIM = 0>
 // (size class 0 step kernel: 129 VGPRs would mean 3 waves per SIMD = 4 workgroups per CU where the LDS allows 5; the
 // second launch bound asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
-__global__ __launch_bounds__(MODE == M3_STEP ? (SC == 0 ? 192 : 64 * (1 + m3_observers<SC>())) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
+__global__ __launch_bounds__(MODE == M3_STEP ? 64 * (2 + m3_observers<SC>()) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
 void m3_kernel(Params p, int cpl) {
   constexpr int PW = M3C<SC>::PW;
-  constexpr bool HELP = MODE == M3_STEP && SC == 0;
+  constexpr bool HELP = MODE == M3_STEP, HELP_S = HELP && SC == 0;
   if (MODE == M3_STEP) touch_kernarg(p);  // every line of the argument block in one scalar-memory round trip
   __shared__ M3Env<SC> E;
   __shared__ M3Work<SC> W;
   __shared__ M3Mail mail;
   M3Work<SC> *WH = nullptr;  // the helper wave's workspace
-  if constexpr (HELP) {
+  if constexpr (HELP_S) {
     __shared__ M3Work<SC> wh_;
     WH = &wh_;
   }
@@ -1250,9 +1256,9 @@ void m3_kernel(Params p, int cpl) {
       mail.exit = 0;
     }
     __syncthreads();  // (the waves of a workgroup start together: nobody waits here)
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 2) {
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1 + m3_observers<SC>()) {
       // ---------------------------------------------------------------------------------------- helper wave
-      m3_helper<SC>(p, *WH, c, mail PHASE_PASS);
+      m3_helper<SC, HELP_S>(p, HELP_S ? *WH : W, c, mail PHASE_PASS);  // (regions only: W is not touched)
       if (p.obs != nullptr) __syncthreads();  // (the closing barrier of the other two waves)
       return;
     }
@@ -1570,7 +1576,7 @@ void m3_kernel(Params p, int cpl) {
         }
         flags &= ~ENV_STATS_DIRTY;
         M3_MARK(2, 4);  // regions
-        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP ? &mail : nullptr PHASE_PASS);
+        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP_S ? &mail : nullptr PHASE_PASS);
         over_dirty = true;
         if constexpr (HELP) {
           while (__builtin_amdgcn_readfirstlane(m3_ld(&mail.rdone)) != rjob) __builtin_amdgcn_s_sleep(1);
