@@ -347,6 +347,17 @@ def test_other_pairs_vs_oracle(problem, rep):
     _rollout_vs_oracle(problem, rep, (16, 16), 203, 300, full_every=37)
 
 
+@pytest.mark.parametrize("problem,rep,shape,kw", [
+    ("sokoban", "narrow", (32, 32), {}), ("zelda", "narrow", (24, 24), {}), ("binary", "turtle", (64, 64), {}),
+    ("zelda", "turtle", (40, 48), {}), ("binary", "narrow", (64, 64), dict(act_window=[3, 3])),
+    ("sokoban", "turtle", (24, 40), dict(obs_window=(48, 80)))])
+def test_tile_code_observation_configs_vs_oracle(problem, rep, shape, kw):
+    """configurations whose one-hot rows would take more than 20 KB of LDS per workgroup: the general kernels compute the
+    observation chunks from per-cell tile codes (encode_obs_codes) -- 6 / 9 / 3 channels, 32- and 64-bit row masks, windows
+    that hang over every edge of the map, an action patch -- every observation against the oracle"""
+    _rollout_vs_oracle(problem, rep, shape, 61, 260, full_every=1, **kw)
+
+
 @pytest.mark.parametrize("shape", [(8, 8), (5, 7), (12, 16), (16, 32), (32, 32), (20, 24), (64, 32), (40, 16)])
 def test_other_map_shapes_vs_oracle(shape):
     """ragged / non-square / maximum sizes: lanes-per-env 8, 16, 32, 64; rows beyond H idle."""
