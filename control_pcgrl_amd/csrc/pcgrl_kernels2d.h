@@ -1552,26 +1552,30 @@ __device__ inline void build_obs_row_static(uint8_t *row, const Params &p, int C
 
 // the same for two tile types: C = 4, so a pixel is one dword (byte 0 out of bounds, byte 1 + tile, byte 3 static) and
 // the row is assembled in registers, four pixels per 16-byte LDS store
+// pixels j0 .. j0+3 of bordered row r (one 16-byte chunk)
+template <typename M>
+__device__ inline uint4 obs_chunk_static4(const Params &p, int r, int left, int j0, M tiles, M prot_above) {
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  const bool maprow = r < H, srow = r <= H + 1, ring_row = r == 0 || r == H + 1;
+  uint32_t w[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int q = left + j0 + t;
+    const bool inmap = maprow && (unsigned)q < (unsigned)W;
+    const uint32_t tile = (uint32_t)((tiles >> (inmap ? q : 0)) & M(1));
+    uint32_t v = inmap ? (0x100u << (8 * tile)) : 1u;
+    if (srow && (unsigned)q <= (unsigned)(W + 1)) {
+      const bool ring = ring_row || q == 0 || q == W + 1;
+      v |= (ring ? 1u : (uint32_t)((prot_above >> (ring ? 0 : q - 1)) & M(1))) << 24;
+    }
+    w[t] = v;
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
 template <typename M>
 __device__ inline void build_obs_row_static4(uint8_t *row, const Params &p, int r, int left, M tiles, M prot_above) {
-  const int H = p.cfg.dims[0], W = p.cfg.dims[1], OW = p.cfg.obs_window[1];
-  const bool maprow = r < H, srow = r <= H + 1, ring_row = r == 0 || r == H + 1;
-  for (int j0 = 0; j0 < OW; j0 += 4) {
-    uint32_t w[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int q = left + j0 + t;
-      const bool inmap = maprow && (unsigned)q < (unsigned)W;
-      const uint32_t tile = (uint32_t)((tiles >> (inmap ? q : 0)) & M(1));
-      uint32_t v = inmap ? (0x100u << (8 * tile)) : 1u;
-      if (srow && (unsigned)q <= (unsigned)(W + 1)) {
-        const bool ring = ring_row || q == 0 || q == W + 1;
-        v |= (ring ? 1u : (uint32_t)((prot_above >> (ring ? 0 : q - 1)) & M(1))) << 24;
-      }
-      w[t] = v;
-    }
-    *(uint4 *)(row + j0 * 4) = make_uint4(w[0], w[1], w[2], w[3]);
-  }
+  const int OW = p.cfg.obs_window[1];
+  for (int j0 = 0; j0 < OW; j0 += 4) *(uint4 *)(row + j0 * 4) = obs_chunk_static4<M>(p, r, left, j0, tiles, prot_above);
 }
 
 template <int PROB, int LPE, typename M>
@@ -1597,11 +1601,13 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
   for (int k = 0; k < NB; k++) none[k] = M(0);
   if constexpr (NT == 2) {
     if (g.row < H) build_obs_row_static4<M>(lds + g.lane * STRIDE, p, g.row, left, b[0], above);
-    // second pass, different lanes at once: the two bordered rows below the map (rows 0, 1 of the group) and, on one lane
-    // of the wave, the all-out-of-bounds row
-    const bool xr = g.row < 2, ob = g.lane == 2;
-    if (xr || ob)
-      build_obs_row_static4<M>(xr ? xrows + g.row * STRIDE : oob_row, p, xr ? H + g.row : H + 2, xr ? left : 0, M(0), xr ? last : M(0));
+    // the two bordered rows below the map, chunk by chunk over the lanes of the group (2 * CH chunks: one or two per lane
+    // instead of a whole row on two lanes), and the all-out-of-bounds row (every pixel = byte 0 set) over the wave's lanes
+    for (int k = g.row; k < 2 * CH; k += LPE) {
+      const int xr = k >= CH ? 1 : 0, j0 = (k - xr * CH) * 4;
+      *(uint4 *)(xrows + xr * STRIDE + j0 * 4) = obs_chunk_static4<M>(p, H + xr, left, j0, M(0), last);
+    }
+    for (int k = g.lane; k < CH; k += 64) *(uint4 *)(oob_row + k * 16) = make_uint4(1u, 1u, 1u, 1u);
   } else {
     if (g.row < H) build_obs_row_static<NB, M>(lds + g.lane * STRIDE, p, C, g.row, left, b, above);
     if (g.row < 2) build_obs_row_static<NB, M>(xrows + g.row * STRIDE, p, C, H + g.row, left, none, last);
