@@ -251,3 +251,31 @@ def test_bench_workload_tables_are_consistent():
         assert bench.ALGO_BYTES[w] == 4 + cells + 1 + obs + 4 + 1 + 4 * n_stats[problem] + pos, w
     n = bench.gpus_without_runtime()
     assert n is None or (isinstance(n, int) and n >= 0)
+
+
+def test_adapter_lease_returns_its_block_when_the_last_array_is_gone():
+    """PcgrlVectorEnv hands out numpy arrays over pinned blocks: a block may only come back to the free list when the last
+    array (view, or view of a view) over it has been garbage-collected -- the mechanism, on a plain CPU tensor"""
+    import gc
+    torch = pytest.importorskip("torch")
+    from control_pcgrl_amd.rllib_env import _Lease
+    free = []
+    block = torch.arange(64, dtype=torch.uint8)
+    lease = _Lease(block, free)
+    h = np.asarray(lease)
+    assert h.shape == (64,) and h[5] == 5 and not h.flags.owndata
+    obs = h[:32].reshape(2, 4, 4)
+    rows = list(obs)           # what vector_step returns: one view per env
+    rew = h[32:48].view(np.float32)
+    del lease, h, obs
+    gc.collect()
+    assert free == [], "views are alive: the block is still lent"
+    keep = rows[1][2:]         # a view of a view keeps it, too
+    del rows, rew
+    gc.collect()
+    assert free == []
+    block[16 + 8 + 0] = 200     # (the memory really is the block's)
+    assert keep[0, 0] == 200
+    del keep
+    gc.collect()
+    assert len(free) == 1 and free[0] is block
