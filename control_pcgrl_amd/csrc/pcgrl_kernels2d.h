@@ -1742,7 +1742,7 @@ template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
 #define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
 #endif
 __global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 512 : 128 * PAIRS,
-                             (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? 6 : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : 1)))
+                             (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? 6 : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : ((FAST && PROB == PCGRL_PROB_SOKOBAN && !CTRL) ? 4 : 1))))
 void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
