@@ -202,8 +202,9 @@ int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls,
  * d_grids uint8 [n][cells] -> d_stats int32 [n][n_stats].  Asynchronous on `stream`.
  *   pcgrl_stats_for_grids_h  uses the scratch (error word, sokoban solver workspace) of an existing engine of the same
  *                            problem and map shape; n is independent of the engine's batch size; device-side errors
- *                            (a level beyond the solver's limits) are reported by pcgrl_poll_error(h).  sokoban: the
- *                            solver's workspace pool is sized for the engine's own envs (one 46 MB slot per four); the
+ *                            (a level beyond the solver's limits: more than 512 crate / target pairs) are reported by
+ *                            pcgrl_poll_error(h).  sokoban: the solver's workspace pool is sized for the engine's own
+ *                            envs (one 46 MB slot per four; at most 64 slots until the solver has been seen running); the
  *                            first call whose n is much larger grows it once, synchronously (one slot per four maps,
  *                            at most 256 = 11.8 GB at solver_power 10000) -- not to be captured in a HIP graph
  *   pcgrl_stats_for_grids    handle-less: keeps one hidden scratch engine per (problem, map shape, solver_power, device),
