@@ -52,6 +52,7 @@ ALGO_BYTES = {"binary-narrow": 4 + 257 + 32 * 32 * 3 + (4 + 1 + 8 + 2),
               "binary_big-narrow": 4 + (32 * 32 + 1) + 64 * 64 * 3 + (4 + 1 + 8 + 2),
               "binary_bigger-narrow": 4 + (64 * 64 + 1) + 128 * 128 * 3 + (4 + 1 + 8 + 2),
               "zelda_big-turtle": 4 + (32 * 32 + 1) + 64 * 64 * 9 + (4 + 1 + 28 + 2),
+              "zelda_bigger-turtle": 4 + (64 * 64 + 1) + 128 * 128 * 9 + (4 + 1 + 28 + 2),  # configs/task/zelda_bigger.yaml:5-6
               "minecraft_3D_maze-narrow-15": 4 + (15 ** 3 + 1) + 30 ** 3 * 4 + (4 + 1 + 12 + 3),
               # evolution driver's call pattern (evo/evolve.py:1083-1120): n_cells x rep.update (+ observation), then one
               # get_stats; per update: action + map read / 1 B write + observation + pos; the statistics pass adds
@@ -69,7 +70,7 @@ WORKLOADS = {"binary-narrow": ("binary", "narrow", (16, 16), 4096), "zelda-turtl
              "zelda-turtle-bfs": ("zelda", "turtle", (16, 16), 4096),
              "sokoban-wide-solver": ("sokoban", "wide", (16, 16), 2048),
              "binary_big-narrow": ("binary", "narrow", (32, 32), 4096), "binary_bigger-narrow": ("binary", "narrow", (64, 64), 4096),
-             "zelda_big-turtle": ("zelda", "turtle", (32, 32), 4096),
+             "zelda_big-turtle": ("zelda", "turtle", (32, 32), 4096), "zelda_bigger-turtle": ("zelda", "turtle", (64, 64), 4096),
              "minecraft_3D_maze-narrow-15": ("minecraft_3D_maze", "narrow", (15, 15, 15), 1024),
              "binary-narrow-evo": ("binary", "narrow", (16, 16), 4096),
              "binary-stats-for-grids": ("binary", "narrow", (16, 16), 65536),

@@ -239,7 +239,7 @@ def test_bench_workload_tables_are_consistent():
     n_stats = {"binary": 2, "zelda": 7, "sokoban": 7, "minecraft_3D_maze": 3}
     n_tiles = {"binary": 2, "zelda": 8, "sokoban": 5, "minecraft_3D_maze": 2}
     for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow",
-              "zelda_big-turtle", "minecraft_3D_maze-narrow-15"):
+              "zelda_big-turtle", "zelda_bigger-turtle", "minecraft_3D_maze-narrow-15"):
         problem, rep, shape, _ = bench.WORKLOADS[w][:4]
         cells = int(np.prod(shape))
         if rep == "wide":

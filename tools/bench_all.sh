@@ -19,7 +19,7 @@ if [ "$WHAT" = "base" ] || [ "$WHAT" = "all" ]; then
 fi
 if [ "$WHAT" = "stock" ] || [ "$WHAT" = "all" ]; then
   # the reference's stock task configs off 16x16 and the evolution driver's call pattern
-  for W in binary_big-narrow binary_bigger-narrow zelda_big-turtle minecraft_3D_maze-narrow-15 binary-narrow-evo binary-stats-for-grids zelda-stats-for-grids; do
+  for W in binary_big-narrow binary_bigger-narrow zelda_big-turtle zelda_bigger-turtle minecraft_3D_maze-narrow-15 binary-narrow-evo binary-stats-for-grids zelda-stats-for-grids; do
     python bench.py --workload $W --cpu-seconds 8 > $O/bench_${T}_$W.log 2>&1
   done
 fi

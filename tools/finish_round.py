@@ -78,11 +78,12 @@ NOTES = {
     "binary_big-narrow": "the reference's `binary_big` task (32², window 64²; `configs/task/binary_big.yaml:5-6`): one-hot rows in LDS (13 KB per workgroup)",
     "binary_bigger-narrow": "`binary_bigger` (64², window 128²; `binary_bigger.yaml:5-6`): 64-bit row masks, observation chunks from tile codes; the launch ends with the env whose path search is longest",
     "zelda_big-turtle": "`zelda_big` (32², window 64²; `zelda_big.yaml:5-6`): observation chunks from tile codes (§4.1)",
+    "zelda_bigger-turtle": "`zelda_bigger` (64², window 128²; `zelda_bigger.yaml:5-6`): 621 MB of observations per launch, 64-bit row masks, chunks from tile codes",
     "minecraft_3D_maze-narrow-15": "the reference's stock 3-D map (`configs/config.py:153-157`), two whole episodes: one workgroup per CU (147 KB of LDS), three observe waves",
 }
 rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac (wall / kernel mean) | same-size fill µs (step ÷ fill) | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|---|"]
 for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle",
-          "minecraft_3D_maze-narrow-15", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
+          "zelda_bigger-turtle", "minecraft_3D_maze-narrow-15", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
     if w not in lines:
         continue
     l = lines[w]
