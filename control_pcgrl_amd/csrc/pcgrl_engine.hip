@@ -485,7 +485,7 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
 extern "C" {
 
 const char *pcgrl_last_error(void) { return g_err.c_str(); }
-const char *pcgrl_version(void) { return "pcgrl_amd 0.1 (gfx950)"; }
+const char *pcgrl_version(void) { return "pcgrl_amd 0.2 (gfx950)"; }
 
 int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_handle *out) {
   if (!cfg || !out || n_envs < 1) return fail(PCGRL_EINVAL, "pcgrl_create: bad arguments");
