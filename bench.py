@@ -149,6 +149,13 @@ def main():
                     help="1 / 0: time PcgrlVectorEnv.vector_step (the RLlib VectorEnv call shape, host arrays out) as the secondary "
                          "object `rllib_adapter`; default: on for the headline workload")
     ap.add_argument("--rollout-launches", type=int, default=200, help="timed pcgrl_rollout launches of the secondary figure")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: initialise a world-size-1 'nccl' (RCCL) process group and close the timed region through the "
+                         "N > 1 exchange (device all-reduce + device->host copy), so that a 1-GPU box executes the multi-GPU code path")
+    ap.add_argument("--closed-loop-steps", type=int, default=-1,
+                    help="steps of the secondary figure `closed_loop_device_actions` (a HIP graph of [pcgrl_sample_actions -> pcgrl_step] "
+                         "pairs: an action drawn on the device at every step, SURVEY 8(d)'s literal protocol); 0 = skip; default max(steps, 2000)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +171,21 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (it launches its own ranks) "
                  f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
+
+    # N > 1: every rank keeps to its own slice of the host cores (launch threads, the runtime's helpers and RCCL's proxy do not
+    # migrate onto another rank's cores); set before anything touches the GPU.  Rank 0 widens its mask again for `cpu_baseline`.
+    all_cores = None
+    pinned = None
+    try:
+        all_cores = sorted(os.sched_getaffinity(0))
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        if world > 1 and not args.no_pin and lw > 1 and len(all_cores) >= 2 * lw:
+            per = len(all_cores) // lw
+            pinned = all_cores[lr * per:(lr + 1) * per]
+            os.sched_setaffinity(0, pinned)
+    except (AttributeError, OSError):
+        pinned = None
 
     import numpy as np
     import torch
@@ -200,12 +222,19 @@ def main():
         sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    use_coll = world > 1 or args.force_collective  # the N > 1 exchange path (also with ONE rank under --force-collective)
+    if use_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     problem, rep, shape, default_envs = WORKLOADS[args.workload][:4]
@@ -296,7 +325,12 @@ def main():
     # coprime with the narrow scan period (256 cells), so every cell keeps receiving fresh random actions.
     # Short runs (the driver's --steps 20 --warmup 5): one graph of all K steps, uploaded to the device ahead of time
     # (hipGraphUpload: no launch), so that the timed region is a single replay; the W warm-up steps are eager launches.
+    # Short runs, second form (round 5): a graph of gcd(W, K) steps replayed W / G times untimed and K / G times timed -- the
+    # timed replays are then not the exec's first launch (that first launch costs ~60 us, a third of a 20-step region).
+    import math
     G_short = K if 2 <= K <= 125 else 0
+    if G_short and W >= 2 and math.gcd(W, K) >= 2:
+        G_short = math.gcd(W, K)
     G = args.graph_steps if args.graph_steps >= 0 else ((125 if K >= 250 else G_short) if inject is None else 0)
     if evo or sfg:
         G = 0
@@ -317,9 +351,7 @@ def main():
                             raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
             stream.wait_stream(side)
             try:  # (best effort: the first replay of a graph that was never launched is otherwise slower)
-                import ctypes
-                ctypes.CDLL("libamdhip64.so").hipGraphUpload(ctypes.c_void_p(graph.raw_cuda_graph_exec()),
-                                                             ctypes.c_void_p(stream.cuda_stream))
+                env._L.pcgrl_graph_upload(graph.raw_cuda_graph_exec(), stream.cuda_stream)
                 torch.cuda.synchronize(dev)
             except Exception:  # noqa: BLE001
                 pass
@@ -398,7 +430,7 @@ def main():
         """the path's only exchange: one pcgrl_reduce_episodes launch; world == 1: the kernel writes its 3 + n_stats
         doubles straight into pinned host memory (no copy); world > 1: one small all-reduce over RCCL, then one
         device -> host copy.  Ends with the device synchronised."""
-        if world == 1:
+        if not use_coll:
             rc = env._L.pcgrl_reduce_episodes(env._h, ep_host.data_ptr(), 1, sptr)
             if rc:
                 raise RuntimeError(f"pcgrl_reduce_episodes rc={rc}")
@@ -424,6 +456,80 @@ def main():
             after.record(stream)
         ep_host.copy_(ep_dev, non_blocking=True)
         torch.cuda.synchronize(dev)
+
+    def measure_closed_loop():
+        """Secondary figure: SURVEY 8(d)'s protocol taken literally (profile_env.py:134-139: an action sampled at every step).
+        One HIP graph of Gc [pcgrl_sample_actions -> pcgrl_step] pairs -- the sampler is one more kernel per step whose output
+        the step launch depends on -- replayed to cover Kc steps; HIP events on the launch stream.  Never `value`."""
+        Kc = args.closed_loop_steps if args.closed_loop_steps >= 0 else max(K, 2000)
+        if Kc <= 0 or inject is not None or evo or sfg:
+            return None
+        Gc = min(125, Kc)
+        act_buf = torch.empty((N, env.action_entries), dtype=torch.int32, device=dev)
+        try:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    cap = torch.cuda.current_stream(dev).cuda_stream
+                    for _ in range(Gc):
+                        rc = env._L.pcgrl_sample_actions(env._h, act_buf.data_ptr(), 1234 + rank, cap)
+                        rc = rc or step_raw(act_buf.data_ptr(), cap)
+                        if rc:
+                            raise RuntimeError(f"closed loop (capture) rc={rc}")
+            stream.wait_stream(side)
+        except Exception as exc:  # noqa: BLE001
+            torch.cuda.synchronize(dev)
+            return {"error": repr(exc)}
+        reps = max(1, Kc // Gc)
+        for _ in range(max(1, reps // 10)):
+            g.replay()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(reps):
+            g.replay()
+        e1.record(stream)
+        barrier()
+        el, _ = max_over_ranks(time.perf_counter() - t1)
+        env.check_errors()
+        us_ev = e0.elapsed_time(e1) / (reps * Gc) * 1e3
+        us = el / (reps * Gc) * 1e6
+        del g
+        return {"value": total_envs * reps * Gc / el, "unit": "env-steps/s", "steps": reps * Gc, "us_per_step": us,
+                "us_per_step_hip_events": us_ev, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "launch": f"HIP graph of {Gc} [pcgrl_sample_actions -> pcgrl_step] pairs per replay",
+                "note": "an action drawn on the device at every step (counter-based generator, draw counter in device memory: fresh "
+                        "actions at every replay); two dependent kernels per step; measured after the timed region"}
+
+    def measure_first_replay():
+        """Round 4's short-run protocol, kept as a detail: ONE graph of all K steps, uploaded but never launched before the
+        clock starts.  Returns ms per step of that first replay (+ the closing synchronise), or None."""
+        if not (2 <= K <= 125) or inject is not None or evo or sfg or graph is None or G == K:
+            return None
+        try:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    cap = torch.cuda.current_stream(dev).cuda_stream
+                    for k in range(K):
+                        if step_raw(base + (k % POOL) * stride, cap):
+                            raise RuntimeError("capture")
+            stream.wait_stream(side)
+            env._L.pcgrl_graph_upload(g.raw_cuda_graph_exec(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            g.replay()
+            done_ev.record(stream)
+            done_ev.synchronize()
+            return (time.perf_counter() - t1) / K * 1e3
+        except Exception:  # noqa: BLE001
+            torch.cuda.synchronize(dev)
+            return None
 
     def measure_fill():
         """What a write-only kernel reaches at this launch size: a device fill of exactly the launch's algorithmic byte
@@ -482,6 +588,9 @@ def main():
     _, per_rank_eps = max_over_ranks(float(local_eps.item()))
     _, per_rank_kernel_ms = max_over_ranks(kernel_ms)
     _, per_rank_exchange_ms = max_over_ranks(exchange_ms)
+    first_replay_ms = measure_first_replay()
+    _, per_rank_first = max_over_ranks(first_replay_ms if first_replay_ms is not None else float("nan"))
+    closed = measure_closed_loop()
     h = ep_host.tolist()
     n_ep = max(h[2], 1.0)
     ep = {"episodes": h[2], "mean_return": h[0] / n_ep, "mean_length": h[1] / n_ep,
@@ -539,7 +648,21 @@ def main():
         # one line as  min(launch_ms_per_step at N = 1) / max(launch_ms_per_step)  and the exchange's share
         out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "ms_per_step": [t / K * 1e3 for t in per_rank_elapsed],
                            "launch_ms_per_step": per_rank_kernel_ms, "exchange_ms": per_rank_exchange_ms,
-                           "episodes": per_rank_eps, "collective": "none" if world == 1 else f"{backend} all-reduce of {3 + env.n_stats} doubles"}
+                           "episodes": per_rank_eps,
+                           "collective": "none" if not use_coll else f"{backend} all-reduce of {3 + env.n_stats} doubles"
+                                         + (" (world size 1: --force-collective)" if world == 1 else ""),
+                           "cores": "all" if pinned is None else f"{len(pinned)} per rank (sched_setaffinity by LOCAL_RANK)"}
+        if first_replay_ms is not None:  # round 4's protocol for short runs, for comparison (never `value`)
+            out["per_rank"]["first_replay_of_one_graph_ms_per_step"] = per_rank_first
+        # what the timed region consists of on the slowest rank: K launches (HIP events) + the closing exchange
+        # (pcgrl_reduce_episodes launch, N > 1: the all-reduce, which also absorbs rank skew, + the device->host copy) + host latency
+        out["timed_region"] = {"wall_ms": elapsed * 1e3, "launches_ms": max(per_rank_kernel_ms) * K,
+                               "exchange_ms": max(per_rank_exchange_ms), "exchange_share_of_wall": max(per_rank_exchange_ms) / (elapsed * 1e3),
+                               "protocol": (f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and W % G == 0 and K % G == 0
+                                            else f"replays of a HIP graph of {G} steps (+ {K % G} eager launches)" if graph is not None
+                                            else "eager launches")}
+        if closed is not None:
+            out["closed_loop_device_actions"] = closed
         if solver_active:
             st = env.get_state().stats
             out["solver_active"] = {"reinject_every": REINJECT, "solver_power": int(env.cfg.solver_power),
@@ -552,18 +675,28 @@ def main():
                                  "envs_with_one_player_at_end": (st[:, 0] == 1).float().mean().item()}
         if rollout is not None:
             out["open_loop_rollout"] = rollout
+    if use_coll:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # The CPU baseline runs on rank 0 AFTER the process group is gone: the other ranks have left (none of them sits in a
+        # barrier, spinning, while the OpenMP threads are timed) and rank 0 may use every host core again.
         if args.rllib_adapter > 0 or (args.rllib_adapter < 0 and args.workload == "binary-narrow" and args.envs == 0):
             try:  # (a secondary figure must never cost the run its line)
                 out["rllib_adapter"] = rllib_adapter_bench(problem, rep, shape, dev)
             except Exception as exc:  # noqa: BLE001
                 out["rllib_adapter"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline:  # rank 0 only, also with N > 1 ranks (the others wait at the closing barrier)
+        if not args.no_cpu_baseline:
+            if pinned is not None:
+                try:
+                    os.sched_setaffinity(0, all_cores)
+                except OSError:
+                    pass
+            if world > 1:
+                time.sleep(1.0)  # (the other ranks tear down their runtimes)
             out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT,
                                                mode="evo" if evo else "sfg" if sfg else "step", maps=sfg_host if sfg else None)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def gpus_without_runtime():
@@ -788,10 +921,11 @@ def cpu_baseline(problem, rep, shape, n_envs, target_s, wkw=None, bfs_active=Fal
     elif bfs_active:
         acts = np.array(BFS_ACTIONS, np.int32)[rng.integers(0, len(BFS_ACTIONS), size=(64, n_envs))]
     # pick the thread count that this box actually rewards (short calibration), then time the sample
-    cands = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)})
+    # (>= 2 s per candidate: shorter calibrations picked 8 threads for one workload where every other picked 16)
+    cands = sorted({avail, max(1, avail // 2), min(avail, 32)})
     best_threads, best_rate = 1, 0.0
     for th in cands:
-        r, _, _ = rate(th, 0.6)
+        r, _, _ = rate(th, 2.0)
         if r > best_rate:
             best_threads, best_rate = th, r
     value, steps, dt = rate(best_threads, target_s)

@@ -74,6 +74,13 @@ SYMBOLS = {
     "pcgrl_get_rng_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_set_rng_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_poll_error": (C.c_int, [C.c_void_p]),
+    "pcgrl_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pcgrl_num_actions": (C.c_int32, [C.c_void_p]),
+    "pcgrl_reserve_solver_pool": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "pcgrl_solver_pool_slots": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pcgrl_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pcgrl_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "pcgrl_graph_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pcgrl_debug_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "pcgrl_last_error": (C.c_char_p, []),
     "pcgrl_version": (C.c_char_p, []),

@@ -36,6 +36,7 @@ static int fail(int code, const std::string &msg) {
 
 namespace pcgrl {
 struct RedScratch;
+struct SampleState;
 }
 struct pcgrl_engine {
   Params p;
@@ -46,15 +47,24 @@ struct pcgrl_engine {
   int32_t *seen_host = nullptr;  // sokoban: host-mapped counter of device solver runs
   int soko_slots = 0;            // sokoban: workspace slots of the current pool (p.soko)
   int32_t seen_last = 0, spread_left = 0;
+  bool soko_lazy = true;         // grow the solver pool by itself the first time the solver has been seen running
+  bool soko_grow_failed = false; // the last growth attempt failed (message in soko_grow_msg): not retried by itself
+  std::string soko_grow_msg;
+  uint8_t *hdr_host = nullptr;   // pinned: the 256-byte header of pcgrl_export_state images (rebuilt by pcgrl_set_static)
   bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
   int obs_ndim = 0;
   int32_t obs_shape[4] = {0, 0, 0, 0};
   RedScratch *red = nullptr;  // pcgrl_reduce_episodes block partials
+  SampleState *sample = nullptr;  // pcgrl_sample_actions: draw counter + ticket
   std::vector<void *> allocs;
   // the persistent per-env arrays (pointer, bytes per env): what pcgrl_export_state / pcgrl_import_state carry
   std::vector<std::pair<void *, size_t>> state_arrays;
 };
+
+extern "C" {
+static void state_header_build(pcgrl_engine *h);
+}
 
 // ---------------------------------------------------------------------------------------------- RNG seeding (host)
 // numpy.random.SeedSequence(seed).generate_state(4, uint64) -> PCG64 state/inc (numpy/random/bit_generator.pyx,
@@ -384,6 +394,37 @@ __global__ __launch_bounds__(1024) void reduce_episodes_small_kernel(Params p, d
   }
 }
 
+// pcgrl_sample_actions: action_space.sample() for every env.  Counter-based (entry i of draw c under seed s is a pure
+// function of (s, c, i)); the draw counter lives in device memory and is advanced by the last block to finish, after every
+// block has read it, so a launch captured in a HIP graph draws new actions at every replay.
+struct SampleState {
+  unsigned long long counter;
+  unsigned int ticket;
+};
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void sample_actions_kernel(int32_t *out, int32_t n, uint32_t n_actions, uint64_t seed, SampleState *st) {
+  __shared__ unsigned long long c_sh;
+  if (threadIdx.x == 0) c_sh = __hip_atomic_load(&st->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const uint64_t c = c_sh;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const uint64_t r = mix64(mix64(seed + c * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)i * 0xd1b54a32d192ed03ull + 0x8cb92ba72f3d8dd7ull));
+    out[i] = (int32_t)__umul64hi(r, (uint64_t)n_actions);  // floor(r * n / 2^64): bias < n / 2^64
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1u) {  // every block has read the counter before its ticket
+      st->ticket = 0;
+      __hip_atomic_store(&st->counter, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // pcgrl_get_rng_state / pcgrl_set_rng_state: [N][10] = rep state hi, lo, inc hi, lo; prob state hi, lo, inc hi, lo;
 // representation-wrapper flags | has32 << 32, val32
 __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, const uint64_t *in) {
@@ -432,23 +473,33 @@ __global__ __launch_bounds__(256) void masked_rows_copy_kernel(uint32_t *dst, co
 // beyond the pool wait for a slot: speed, not results).  Synchronous (hipMalloc + a device synchronise), once per engine,
 // never while `stream` is being captured; launches issued earlier (or frozen in a HIP graph) keep using the pool they were
 // issued with, which stays allocated until pcgrl_destroy.
-static void soko_pool_for(pcgrl_engine *h, Params &p, int want, hipStream_t stream) {
-  if (!h->p.soko || h->soko_slots >= want) return;
+static int soko_pool_for(pcgrl_engine *h, Params &p, int want, hipStream_t stream, bool lazy = true) {
+  if (!h->p.soko || h->soko_slots >= want) return PCGRL_OK;
+  if (lazy && (!h->soko_lazy || h->soko_grow_failed)) return PCGRL_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream != nullptr && (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {
     (void)hipGetLastError();
-    return;
+    return lazy ? PCGRL_OK : fail(PCGRL_EINVAL, "solver pool: `stream` is being captured (hipMalloc is not capturable)");
   }
   Params grown = h->p;
   int got = 0;
-  if (sokoban_alloc(grown, h->allocs, want, &got) == hipSuccess) {
+  const hipError_t e = sokoban_alloc(grown, h->allocs, want, &got);
+  if (e == hipSuccess) {
     h->p.soko = grown.soko;
     p.soko = grown.soko;
     h->soko_slots = got;
-  } else {
-    (void)hipGetLastError();
-    h->soko_slots = want;  // (out of memory: the engine keeps the pool it has and does not try again)
+    h->soko_grow_failed = false;
+    h->soko_grow_msg.clear();
+    return PCGRL_OK;
   }
+  (void)hipGetLastError();
+  // (out of memory: sokoban_alloc handed back what it had taken; the engine keeps the pool it has -- searches beyond it wait
+  // for a slot: speed, not results -- and does not try again by itself; pcgrl_solver_pool_slots reports it,
+  // pcgrl_reserve_solver_pool retries on request)
+  h->soko_grow_failed = true;
+  h->soko_grow_msg = std::string("solver pool: growing from ") + std::to_string(h->soko_slots) + " to " + std::to_string(want) +
+                     " slots failed: " + hipGetErrorString(e);
+  return lazy ? PCGRL_OK : fail(PCGRL_EHIP, h->soko_grow_msg);
 }
 
 static void soko_pool_lazy(pcgrl_engine *h, Params &p, hipStream_t stream) {
@@ -485,7 +536,7 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
 extern "C" {
 
 const char *pcgrl_last_error(void) { return g_err.c_str(); }
-const char *pcgrl_version(void) { return "pcgrl_amd 0.2 (gfx950)"; }
+const char *pcgrl_version(void) { return "pcgrl_amd 0.3 (gfx950)"; }
 
 int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_handle *out) {
   if (!cfg || !out || n_envs < 1) return fail(PCGRL_EINVAL, "pcgrl_create: bad arguments");
@@ -584,6 +635,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
   CREATE_CHK(dalloc((void **)&p.rng, (size_t)n_envs * sizeof(RngState)));
   CREATE_CHK(dalloc((void **)&e->red, sizeof(RedScratch)));
+  CREATE_CHK(dalloc((void **)&e->sample, sizeof(SampleState)));
   // [0..3] error flags; from int 64 on: per-workgroup phase-timing accumulators (PCGRL_PHASE_TIMING builds)
   CREATE_CHK(dalloc((void **)&p.err, sizeof(int32_t) * 64 + sizeof(uint64_t) * 8 * (size_t)(n_envs + 64)));
   std::vector<JumpEntry> jt = is3d ? make_jump_table(64, e->cpl, p.n_cells) : make_jump_table(H, W);
@@ -638,6 +690,14 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
       e->state_arrays.push_back({p.trg_flag, sizeof(int32_t)});
     }
   }
+  {
+    const hipError_t he = hipHostMalloc((void **)&e->hdr_host, 256, hipHostMallocDefault);
+    if (he != hipSuccess) {
+      pcgrl_destroy(e);
+      return fail(PCGRL_EHIP, std::string("hipHostMalloc (state header): ") + hipGetErrorString(he));
+    }
+    state_header_build(e);
+  }
   *out = e;
   // default seeding: env i gets seed i (callers normally call pcgrl_seed)
   std::vector<uint64_t> seeds(n_envs);
@@ -649,6 +709,7 @@ void pcgrl_destroy(pcgrl_handle h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   if (h->seen_host) (void)hipHostFree(h->seen_host);
+  if (h->hdr_host) (void)hipHostFree(h->hdr_host);
   for (void *a : h->allocs) (void)hipFree(a);
   delete h;
 }
@@ -845,6 +906,7 @@ int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls,
   if (static_prob >= 0.0) h->p.cfg.static_prob = static_prob;
   if (n_static_walls >= 0) h->p.cfg.n_static_walls = n_static_walls;
   h->p.cfg.static_eval = eval_mode ? 1 : 0;
+  state_header_build(h);
   return PCGRL_OK;
 }
 
@@ -999,13 +1061,18 @@ static size_t state_section(size_t bytes) { return (bytes + 255) & ~(size_t)255;
 // header does not match the importing engine (another config -- even one with the same byte size, e.g. other weights or
 // targets --, another batch size, another per-env layout / library version) instead of importing it silently.
 struct StateHeader {
-  uint64_t magic;        // "PCGRLST1"
-  uint64_t fingerprint;  // FNV-1a over the config fields, n_envs, the library version string and every array's bytes per env
+  uint64_t magic;        // "PCGRLST2"
+  uint64_t fingerprint;  // FNV-1a over the create-time config fields, n_envs, the library version string and every array's bytes per env
   int32_t n_envs, n_arrays;
   uint64_t total_bytes;
+  // the three static-tile parameters pcgrl_set_static changes at run time (the reference's set_static_prob /
+  // set_n_static_walls / set_eval_mode, reps/wrappers.py:256-263): state, not identity -- a full import applies them
+  double static_prob;
+  int32_t n_static_walls, static_eval;
 };
-static constexpr uint64_t STATE_MAGIC = 0x3154534c52474350ull;  // "PCGRLST1", little endian
+static constexpr uint64_t STATE_MAGIC = 0x3254534c52474350ull;  // "PCGRLST2", little endian
 static constexpr size_t STATE_HDR_BYTES = 256;
+static_assert(sizeof(StateHeader) <= STATE_HDR_BYTES, "state header section");
 
 static uint64_t state_fingerprint(pcgrl_handle h) {
   uint64_t x = 1469598103934665603ull;
@@ -1016,7 +1083,7 @@ static uint64_t state_fingerprint(pcgrl_handle h) {
 #define MIX(f) mix(&c.f, sizeof(c.f))
   MIX(problem); MIX(representation); MIX(ndim); MIX(dims); MIX(obs_window); MIX(max_iterations); MIX(max_changes); MIX(n_stats);
   MIX(has_trg); MIX(weights); MIX(trg_lo); MIX(trg_hi); MIX(solver_power); MIX(n_ctrl); MIX(ctrl_idx); MIX(ctrl_range);
-  MIX(act_window); MIX(static_tiles); MIX(n_static_walls); MIX(static_eval); MIX(static_prob);
+  MIX(act_window); MIX(static_tiles);  // (not static_prob / n_static_walls / static_eval: pcgrl_set_static moves them)
 #undef MIX
   const int32_t n = h->p.n_envs;
   mix(&n, sizeof(n));
@@ -1024,6 +1091,23 @@ static uint64_t state_fingerprint(pcgrl_handle h) {
   mix(v, strlen(v));
   for (auto &a : h->state_arrays) mix(&a.second, sizeof(a.second));
   return x;
+}
+
+// The header lives in pinned host memory owned by the engine: pcgrl_export_state copies it from there, so a captured export
+// keeps a pointer that stays valid and every replay writes the header of the engine's CURRENT static-tile parameters.
+static void state_header_build(pcgrl_handle h) {
+  if (!h->hdr_host) return;
+  StateHeader hdr{};
+  hdr.magic = STATE_MAGIC;
+  hdr.fingerprint = state_fingerprint(h);
+  hdr.n_envs = h->p.n_envs;
+  hdr.n_arrays = (int32_t)h->state_arrays.size();
+  hdr.total_bytes = (uint64_t)pcgrl_state_bytes(h);
+  hdr.static_prob = h->p.cfg.static_prob;
+  hdr.n_static_walls = h->p.cfg.n_static_walls;
+  hdr.static_eval = h->p.cfg.static_eval;
+  memset(h->hdr_host, 0, STATE_HDR_BYTES);
+  memcpy(h->hdr_host, &hdr, sizeof(hdr));
 }
 
 int64_t pcgrl_state_bytes(pcgrl_handle h) {
@@ -1036,11 +1120,8 @@ int64_t pcgrl_state_bytes(pcgrl_handle h) {
 int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out, void *stream) {
   if (!h || !d_buf) return fail(PCGRL_EINVAL, "pcgrl_export_state: bad arguments");
   ON_DEVICE(h->device);
-  uint8_t hdr_bytes[STATE_HDR_BYTES] = {0};
-  StateHeader hdr{STATE_MAGIC, state_fingerprint(h), h->p.n_envs, (int32_t)h->state_arrays.size(), (uint64_t)pcgrl_state_bytes(h)};
-  memcpy(hdr_bytes, &hdr, sizeof(hdr));
-  // (pageable source: the runtime stages it before the call returns, so the stack buffer may go away)
-  HIPCHK(hipMemcpyAsync(d_buf, hdr_bytes, STATE_HDR_BYTES, hipMemcpyHostToDevice, (hipStream_t)stream));
+  // (pinned, engine-owned source: capturable, and no stack frame for the runtime to read later)
+  HIPCHK(hipMemcpyAsync(d_buf, h->hdr_host, STATE_HDR_BYTES, hipMemcpyHostToDevice, (hipStream_t)stream));
   size_t off = STATE_HDR_BYTES;
   for (auto &a : h->state_arrays) {
     const size_t bytes = a.second * (size_t)h->p.n_envs;
@@ -1062,6 +1143,16 @@ int pcgrl_import_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_b
   if (hdr.n_envs != h->p.n_envs || hdr.n_arrays != (int32_t)h->state_arrays.size() || hdr.total_bytes != (uint64_t)pcgrl_state_bytes(h) ||
       hdr.fingerprint != state_fingerprint(h))
     return fail(PCGRL_EINVAL, "pcgrl_import_state: the image was exported by an engine with another config, batch size or library version");
+  if (d_mask == nullptr && h->p.cfg.static_tiles) {
+    // the exporter's run-time static-tile parameters (a curriculum's set_static_prob, evaluation mode) come with the image;
+    // a masked import leaves the engine-wide parameters as they are
+    if (!(hdr.static_prob >= 0.0 && hdr.static_prob <= 1.0) || hdr.n_static_walls < 0)
+      return fail(PCGRL_EINVAL, "pcgrl_import_state: corrupt static-tile parameters in the image header");
+    h->p.cfg.static_prob = hdr.static_prob;
+    h->p.cfg.n_static_walls = hdr.n_static_walls;
+    h->p.cfg.static_eval = hdr.static_eval ? 1 : 0;
+    state_header_build(h);
+  }
   size_t off = STATE_HDR_BYTES;
   for (auto &a : h->state_arrays) {
     const size_t bytes = a.second * (size_t)h->p.n_envs;
@@ -1095,6 +1186,66 @@ int pcgrl_set_rng_state(pcgrl_handle h, const uint8_t *d_mask, const uint64_t *d
   p.mask = d_mask;
   hipLaunchKernelGGL(rng_state_kernel, dim3((p.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, (uint64_t *)nullptr, d_in);
   HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+static int32_t num_actions_of(const pcgrl_engine *h) {
+  const pcgrl_config &c = h->p.cfg;
+  if (c.act_window[0] > 0) return h->p.n_tiles;  // MultiDiscrete([n_tiles] * prod(act_window)), reps/wrappers.py:475-478
+  switch (c.representation) {
+    case PCGRL_REP_NARROW: return h->p.n_tiles;      // narrow_rep.py: Discrete(n_tiles)
+    case PCGRL_REP_TURTLE: return h->p.n_tiles + 4;  // turtle_rep.py: 4 moves + n_tiles (A6)
+    default: return h->p.n_cells * h->p.n_tiles;     // wide: ActionMap's flat (cell, tile) index (A7)
+  }
+}
+
+int32_t pcgrl_num_actions(pcgrl_handle h) { return h ? num_actions_of(h) : -1; }
+
+int pcgrl_sample_actions(pcgrl_handle h, int32_t *d_actions, uint64_t seed, void *stream) {
+  if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_sample_actions: bad arguments");
+  ON_DEVICE(h->device);
+  const int32_t n = h->p.n_envs * h->p.n_act;
+  hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_actions, n,
+                     (uint32_t)num_actions_of(h), seed, h->sample);
+  HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_reserve_solver_pool(pcgrl_handle h, int32_t n_slots, int32_t allow_lazy_growth) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_reserve_solver_pool: null handle");
+  if (!h->p.soko) return fail(PCGRL_EINVAL, "pcgrl_reserve_solver_pool: the engine has no device solver (sokoban only)");
+  ON_DEVICE(h->device);
+  h->soko_lazy = allow_lazy_growth != 0;
+  const int full = sokoban_slots_for(h->p.n_envs);
+  const int want = n_slots < 0 ? h->soko_slots : (n_slots == 0 ? full : std::min((int)n_slots, 512));
+  Params scratch = h->p;
+  return soko_pool_for(h, scratch, want, nullptr, /*lazy=*/false);
+}
+
+int32_t pcgrl_solver_pool_slots(pcgrl_handle h, int32_t *full_size_out, int32_t *grow_failed_out) {
+  if (!h || !h->p.soko) return 0;
+  if (full_size_out) *full_size_out = sokoban_slots_for(h->p.n_envs);
+  if (grow_failed_out) *grow_failed_out = h->soko_grow_failed ? 1 : 0;
+  if (h->soko_grow_failed) g_err = h->soko_grow_msg;
+  return h->soko_slots;
+}
+
+// Host utilities for a foreign-language host (ctypes): the HIP runtime THIS library is linked against -- the one that owns
+// the handles the caller passes -- instead of a second dlopen of libamdhip64 by name.
+int pcgrl_copy_to_host(void *dst_host, const void *d_src, int64_t bytes, void *stream) {
+  if (!dst_host || !d_src || bytes < 0) return fail(PCGRL_EINVAL, "pcgrl_copy_to_host: bad arguments");
+  HIPCHK(hipMemcpyAsync(dst_host, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_stream_synchronize(void *stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return PCGRL_OK;
+}
+
+int pcgrl_graph_upload(void *graph_exec, void *stream) {
+  if (!graph_exec) return fail(PCGRL_EINVAL, "pcgrl_graph_upload: null graph");
+  HIPCHK(hipGraphUpload((hipGraphExec_t)graph_exec, (hipStream_t)stream));
   return PCGRL_OK;
 }
 

@@ -1328,24 +1328,28 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, i
   const size_t n_ws = (size_t)pool.n_slots * SK_STAGES;
   hipError_t e;
   void *base = nullptr, *locks = nullptr, *epochs = nullptr, *dpool = nullptr;
-  if ((e = hipMalloc(&base, pool.stage_bytes * n_ws)) != hipSuccess) return e;
-  allocs.push_back(base);
+  // (all or nothing: a failure part-way hands back what this call allocated instead of leaving tens of GB pinned in `allocs`)
+  auto undo = [&](hipError_t err) {
+    (void)hipDeviceSynchronize();
+    for (void *q : {dpool, epochs, locks, base})
+      if (q) (void)hipFree(q);
+    return err;
+  };
+  if ((e = hipMalloc(&base, pool.stage_bytes * n_ws)) != hipSuccess) return undo(e);
   // only the visited tables need a defined start (entries carry the epoch of the stage that wrote them; 0 = empty)
   for (size_t s = 0; s < n_ws; s++)
-    if ((e = hipMemsetAsync((uint8_t *)base + s * pool.stage_bytes + vis_off, 0, SK_VIS_BYTES, 0)) != hipSuccess) return e;
-  if ((e = hipMalloc(&locks, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
-  allocs.push_back(locks);
-  if ((e = hipMemset(locks, 0, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return e;
-  if ((e = hipMalloc(&epochs, sizeof(uint32_t) * n_ws)) != hipSuccess) return e;
-  allocs.push_back(epochs);
-  if ((e = hipMemset(epochs, 0, sizeof(uint32_t) * n_ws)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync((uint8_t *)base + s * pool.stage_bytes + vis_off, 0, SK_VIS_BYTES, 0)) != hipSuccess) return undo(e);
+  if ((e = hipMalloc(&locks, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return undo(e);
+  if ((e = hipMemset(locks, 0, sizeof(int32_t) * pool.n_slots)) != hipSuccess) return undo(e);
+  if ((e = hipMalloc(&epochs, sizeof(uint32_t) * n_ws)) != hipSuccess) return undo(e);
+  if ((e = hipMemset(epochs, 0, sizeof(uint32_t) * n_ws)) != hipSuccess) return undo(e);
   pool.base = (uint8_t *)base;
   pool.locks = (int32_t *)locks;
   pool.epochs = (uint32_t *)epochs;
-  if ((e = hipMalloc(&dpool, sizeof(SokoPool))) != hipSuccess) return e;
-  allocs.push_back(dpool);
-  if ((e = hipMemcpy(dpool, &pool, sizeof(pool), hipMemcpyHostToDevice)) != hipSuccess) return e;
-  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+  if ((e = hipMalloc(&dpool, sizeof(SokoPool))) != hipSuccess) return undo(e);
+  if ((e = hipMemcpy(dpool, &pool, sizeof(pool), hipMemcpyHostToDevice)) != hipSuccess) return undo(e);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return undo(e);
+  for (void *q : {base, locks, epochs, dpool}) allocs.push_back(q);
   p.soko = dpool;
   return hipSuccess;
 }

@@ -34,6 +34,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from . import _lib
 from .envs import Box, Discrete, MultiDiscrete
 from .vec_env import VecPcgrlEnv, make_vec_env
 
@@ -110,21 +111,11 @@ class _Lease:
             pass
 
 
-_hip = None
-
-
 def _hip_runtime():
-    """hipMemcpyAsync / hipStreamSynchronize of the runtime torch has loaded (a ctypes call costs ~1 us, the torch
-    wrappers ~10): plumbing of the device->host copy, nothing else."""
-    global _hip
-    if _hip is None:
-        lib = C.CDLL("libamdhip64.so")
-        lib.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-        lib.hipMemcpyAsync.restype = C.c_int
-        lib.hipStreamSynchronize.argtypes = [C.c_void_p]
-        lib.hipStreamSynchronize.restype = C.c_int
-        _hip = lib
-    return _hip
+    """Device->host copy and stream wait of the HIP runtime libpcgrl_amd.so itself is linked against -- the one that owns
+    the stream handles torch hands over (pcgrl_copy_to_host / pcgrl_stream_synchronize; a ctypes call costs ~1 us, the
+    torch wrappers ~10).  Never a dlopen of libamdhip64 by name: that could load a second runtime."""
+    return _lib.lib()
 
 
 class PcgrlVectorEnv(_Base):
@@ -222,9 +213,9 @@ class PcgrlVectorEnv(_Base):
         """device-side conversion if any, the call's one device->host copy (unless the kernels wrote into the block
         themselves), and the wait for it"""
         if self._host_convert:
-            rc = self._hip.hipStreamSynchronize(stream)
+            rc = self._hip.pcgrl_stream_synchronize(stream)
             if rc:
-                raise RuntimeError(f"hipStreamSynchronize: error {rc}")
+                _lib.check(rc, "pcgrl_stream_synchronize")
             r, sv = self._views(lease), self._stage_views
             np.copyto(r["obs"], sv["obs"], casting="unsafe")
             r["rew"][...] = sv["rew"]
@@ -239,12 +230,12 @@ class PcgrlVectorEnv(_Base):
             else:
                 self._obs_out.copy_(self._obs_u8)
         if not self._direct:
-            rc = self._hip.hipMemcpyAsync(lease.ptr, self._dev.data_ptr(), self._total, 2, stream)  # 2 = hipMemcpyDeviceToHost
+            rc = self._hip.pcgrl_copy_to_host(lease.ptr, self._dev.data_ptr(), self._total, stream)
             if rc:
-                raise RuntimeError(f"hipMemcpyAsync: error {rc}")
-        rc = self._hip.hipStreamSynchronize(stream)
+                _lib.check(rc, "pcgrl_copy_to_host")
+        rc = self._hip.pcgrl_stream_synchronize(stream)
         if rc:
-            raise RuntimeError(f"hipStreamSynchronize: error {rc}")
+            _lib.check(rc, "pcgrl_stream_synchronize")
 
     def _out_ptrs(self, lease):
         if self._host_convert:

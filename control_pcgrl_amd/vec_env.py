@@ -252,6 +252,30 @@ class VecPcgrlEnv:
         self.queue_targets(trgs, mask=mask)
         return trgs
 
+    def sample_actions(self, seed=0, out=None):
+        """action_space.sample() for every env, drawn on the device (pcgrl_sample_actions: the reference's random-action
+        loops, profile_env.py:134-139): int32 [N] (or [N, prod(act_window)]), fresh at every call and at every replay of a
+        HIP graph that captured the call."""
+        if out is None:
+            shape = (self.num_envs, self.action_entries) if self.action_entries > 1 else (self.num_envs,)
+            out = torch.empty(shape, dtype=torch.int32, device=self.device)
+        _lib.check(self._L.pcgrl_sample_actions(self._h, out.data_ptr(), int(seed) & (2 ** 64 - 1), self._stream()),
+                   "pcgrl_sample_actions")
+        return out
+
+    def reserve_solver_pool(self, n_slots=0, allow_lazy_growth=True):
+        """sokoban: size the device solver's workspace pool now (synchronous) instead of inside the first step that sees
+        the solver running; n_slots 0 = full size for this batch.  Returns the slots of the pool."""
+        _lib.check(self._L.pcgrl_reserve_solver_pool(self._h, int(n_slots), 1 if allow_lazy_growth else 0),
+                   "pcgrl_reserve_solver_pool")
+        return self.solver_pool_slots()[0]
+
+    def solver_pool_slots(self):
+        """(slots now, full size for this batch, last growth failed?)"""
+        full, failed = C.c_int32(0), C.c_int32(0)
+        n = int(self._L.pcgrl_solver_pool_slots(self._h, C.byref(full), C.byref(failed)))
+        return n, int(full.value), bool(failed.value)
+
     def step_raw(self, actions_ptr, stream):
         """Lowest-overhead launch: device pointer of int32 actions + raw hipStream_t."""
         return self._L.pcgrl_step(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],

@@ -35,7 +35,8 @@
  *   - return value 0 = success, otherwise a PCGRL_E* code; pcgrl_last_error() gives the message.
  *   - one handle per (process, GPU); a handle is not re-entrant; several handles may coexist.
  *
- * HIP graphs.  Every asynchronous entry point may be captured into a HIP graph (it only enqueues kernels on `stream`)
+ * HIP graphs.  Every asynchronous entry point except pcgrl_import_state (it reads the image header on the host) may be
+ * captured into a HIP graph (it only enqueues kernels and copies between engine-owned or caller-owned buffers on `stream`)
  * and replayed with new contents in the same buffers.  Three host-side decisions are taken when a launch is ISSUED and are
  * therefore frozen into a captured launch:
  *   - which step / rollout kernel runs: the compile-time 16x16 kernels carry no code for statistics left stale by
@@ -145,6 +146,15 @@ int pcgrl_step_seq(pcgrl_handle h, const int32_t *d_action_rows, int64_t row_str
 int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                   double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream);
 
+/* env.action_space.sample() for every env of the batch, on the device: what the reference's own throughput loops feed
+ * step() with (profile_env.py:134-139; random exploration in rl/train.py:144-184).  d_actions int32 [N] (or
+ * [N][prod(act_window)]), each entry uniform in [0, pcgrl_num_actions(h)).  Counter-based: entry i of the engine's c-th draw
+ * under `seed` is a pure function of (seed, c, i); the draw counter lives on the device and advances with every launch, so
+ * a [pcgrl_sample_actions -> pcgrl_step] pair captured in a HIP graph is a closed random-action loop with fresh actions at
+ * every replay.  Synthetic input, not env state: the counter is not part of pcgrl_export_state. */
+int pcgrl_sample_actions(pcgrl_handle h, int32_t *d_actions, uint64_t seed, void *stream);
+int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles + 4; wide: cells * n_tiles; act_window: n_tiles */
+
 /* Open-loop rollout: n_steps consecutive pcgrl_step()s of every env in ONE launch, for action sequences that do not
  * depend on the observations (random-action rollouts as in the reference's own env tests, replays, evaluation of stored
  * action sequences).  Results are identical to n_steps calls of pcgrl_step; there is no kernel boundary between steps.
@@ -253,15 +263,40 @@ int pcgrl_poll_error(pcgrl_handle h);
  *   pcgrl_export_state  d_buf uint8 [pcgrl_state_bytes]; *maybe_stale_out (host, may be NULL) = 1 when statistics left
  *                       stale by pcgrl_update may be among them -- hand it back to pcgrl_import_state
  *   pcgrl_import_state  into an engine created with the same config and batch size; d_mask uint8 [N] (NULL = all envs).
- *                       The image starts with a 256-byte header (magic, fingerprint of every config field + batch size +
- *                       library version + per-env layout); an image from any other engine is refused with PCGRL_EINVAL
- *                       before anything is overwritten.  Reading the header waits for `stream` once (the only
+ *                       The image starts with a 256-byte header (magic, fingerprint of every create-time config field +
+ *                       batch size + library version + per-env layout, and the three static-tile parameters
+ *                       pcgrl_set_static moves at run time); an image from any other engine is refused with PCGRL_EINVAL
+ *                       before anything is overwritten.  A full import (d_mask NULL) also takes over the exporter's
+ *                       static_prob / n_static_walls / eval mode (a curriculum's set_static call survives a checkpoint);
+ *                       a masked import leaves the engine-wide parameters alone.  pcgrl_export_state copies the header
+ *                       from pinned memory owned by the engine: capturable, replays carry the current parameters.  Reading the header waits for `stream` once (the only
  *                       synchronising call among the state entry points; not to be captured in a HIP graph).
  * The buffer is an opaque image for this library version and config; pcgrl_get_state / pcgrl_set_state remain the
  * portable (maps, positions, counters) form. */
 int64_t pcgrl_state_bytes(pcgrl_handle h);
 int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out, void *stream);
 int pcgrl_import_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_buf, int32_t maybe_stale, void *stream);
+/* sokoban: the device solver's workspace pool (one 46 MB slot per search in flight at the default solver_power).
+ * pcgrl_create allocates min(full, 64) slots (full = clamp(N / 4, 4, 512)); by default the engine grows the pool to full
+ * size the first time it has SEEN the solver running -- a synchronous hipMalloc + device synchronise inside whichever
+ * pcgrl_step / pcgrl_reset / pcgrl_rollout call notices it (never while `stream` itself is being captured; a capture in
+ * global mode on ANOTHER thread would be invalidated by it).  A caller that wants to choose the moment:
+ *   pcgrl_reserve_solver_pool(h, n_slots, allow_lazy_growth)   synchronous; n_slots > 0: at least that many (<= 512),
+ *       0: full size for the engine's batch, < 0: keep the pool as it is; allow_lazy_growth = 0 switches the implicit growth
+ *       off for this engine.  PCGRL_EHIP when the allocation fails (nothing stays allocated from the failed attempt; the
+ *       engine keeps working with the pool it has: searches beyond it wait for a slot -- speed, not results).
+ *   pcgrl_solver_pool_slots(h, &full, &failed)   slots of the current pool; `failed` = 1 when the last (implicit or explicit)
+ *       growth failed -- pcgrl_last_error() then holds the reason.  The implicit growth is not retried after a failure. */
+int pcgrl_reserve_solver_pool(pcgrl_handle h, int32_t n_slots, int32_t allow_lazy_growth);
+int32_t pcgrl_solver_pool_slots(pcgrl_handle h, int32_t *full_size_out, int32_t *grow_failed_out);
+
+/* Host utilities (no reference counterpart: a ctypes / cgo host needs them to stay on the HIP runtime this library is
+ * linked against, which owns the stream handles it is given): asynchronous device -> host copy on `stream`, wait for
+ * `stream`, hipGraphUpload of an instantiated graph (hipGraphExec_t as void*). */
+int pcgrl_copy_to_host(void *dst_host, const void *d_src, int64_t bytes, void *stream);
+int pcgrl_stream_synchronize(void *stream);
+int pcgrl_graph_upload(void *graph_exec, void *stream);
+
 /* Development aid: copies n 64-bit device counters to `out` (HOST pointer) and zeroes them.  They are only written by
  * a library built with -DPCGRL_PHASE_TIMING (tools/phase_timing.py); otherwise all zero. */
 int pcgrl_debug_counters(pcgrl_handle h, uint64_t *out, int32_t n);
