@@ -155,6 +155,13 @@ def main():
     ap.add_argument("--closed-loop-steps", type=int, default=-1,
                     help="steps of the secondary figure `closed_loop_device_actions` (a HIP graph of [pcgrl_sample_actions -> pcgrl_step] "
                          "pairs: an action drawn on the device at every step, SURVEY 8(d)'s literal protocol); 0 = skip; default max(steps, 2000)")
+    ap.add_argument("--short-protocol", default="fused", choices=["fused", "one", "gcd"],
+                    help="runs of 2..125 steps (the driver's --steps 20 --warmup 5): 'fused' = ONE HIP graph of the K step launches + the "
+                         "closing pcgrl_reduce_episodes launch, uploaded ahead of time, the W warm-up steps eager; 'one' = round 4's (the "
+                         "reduction launched separately); 'gcd' = a graph of gcd(W, K) steps, W / G untimed + K / G timed replays")
+    ap.add_argument("--sub-batches", default="2,4",
+                    help="secondary figure `async_sub_batches`: the batch as k engines of N / k envs on k streams, their step chains captured "
+                         "as parallel branches of one HIP graph (SubBatchedVecEnv); comma-separated k values, '' = skip")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
@@ -327,13 +334,22 @@ def main():
     # (hipGraphUpload: no launch), so that the timed region is a single replay; the W warm-up steps are eager launches.
     # Short runs, second form (round 5): a graph of gcd(W, K) steps replayed W / G times untimed and K / G times timed -- the
     # timed replays are then not the exec's first launch (that first launch costs ~60 us, a third of a 20-step region).
+    # Measured (round 5, profiles/r05_bench_lines.json): four replays of a 5-step graph cost MORE than one replay of a 20-step
+    # graph that was uploaded but never launched (11.2 vs 7.5 us per step: every replay pays its own launch latency and the
+    # device idles between replays), so the default puts the whole timed region into one graph: K steps + the reduction.
     import math
     G_short = K if 2 <= K <= 125 else 0
-    if G_short and W >= 2 and math.gcd(W, K) >= 2:
+    if G_short and args.short_protocol == "gcd" and W >= 2 and math.gcd(W, K) >= 2:
         G_short = math.gcd(W, K)
     G = args.graph_steps if args.graph_steps >= 0 else ((125 if K >= 250 else G_short) if inject is None else 0)
     if evo or sfg:
         G = 0
+    # the reporting path's buffers (pinned host memory takes milliseconds to allocate: nothing slow may sit between the
+    # warm-up steps and the timed region)
+    ep_dev = torch.zeros(3 + env.n_stats, dtype=torch.float64, device=dev)
+    ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
+    done_ev = torch.cuda.Event()
+    fuse_reduce = bool(G > 0 and G == K and 2 <= K <= 125 and args.short_protocol == "fused")
     graph = None
     if G > 0:
         # (thread-local capture mode: with N > 1 ranks the RCCL watchdog thread queries events while this thread captures;
@@ -349,6 +365,10 @@ def main():
                         rc = step_raw(base + (k % POOL) * stride, cap)
                         if rc:
                             raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
+                    if fuse_reduce:  # the path's exchange starts with this launch: part of the same graph
+                        rc = env._L.pcgrl_reduce_episodes(env._h, ep_dev.data_ptr() if use_coll else ep_host.data_ptr(), 1, cap)
+                        if rc:
+                            raise RuntimeError(f"pcgrl_reduce_episodes (capture) rc={rc}")
             stream.wait_stream(side)
             try:  # (best effort: the first replay of a graph that was never launched is otherwise slower)
                 env._L.pcgrl_graph_upload(graph.raw_cuda_graph_exec(), stream.cuda_stream)
@@ -358,7 +378,10 @@ def main():
         except Exception as exc:  # noqa: BLE001
             print(f"[bench] rank {rank}: graph capture failed ({exc!r}); eager launches", file=sys.stderr, flush=True)
             graph = None
+            fuse_reduce = False
             torch.cuda.synchronize(dev)
+    if graph is None:
+        fuse_reduce = False
 
     def run(n):
         if graph is None or n < G:
@@ -420,18 +443,12 @@ def main():
             del obs_r
         return rollout
 
-    # the reporting path's buffers (pinned host memory takes milliseconds to allocate: nothing slow may sit between the
-    # warm-up steps and the timed region)
-    ep_dev = torch.zeros(3 + env.n_stats, dtype=torch.float64, device=dev)
-    ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
-    done_ev = torch.cuda.Event()
-
-    def reduce_episodes(after=None):
-        """the path's only exchange: one pcgrl_reduce_episodes launch; world == 1: the kernel writes its 3 + n_stats
-        doubles straight into pinned host memory (no copy); world > 1: one small all-reduce over RCCL, then one
-        device -> host copy.  Ends with the device synchronised."""
+    def reduce_episodes(after=None, launched=False):
+        """the path's only exchange: one pcgrl_reduce_episodes launch (`launched`: it was the last node of the graph just
+        replayed); world == 1: the kernel writes its 3 + n_stats doubles straight into pinned host memory (no copy);
+        world > 1: one small all-reduce over RCCL, then one device -> host copy.  Ends with the device synchronised."""
         if not use_coll:
-            rc = env._L.pcgrl_reduce_episodes(env._h, ep_host.data_ptr(), 1, sptr)
+            rc = 0 if launched else env._L.pcgrl_reduce_episodes(env._h, ep_host.data_ptr(), 1, sptr)
             if rc:
                 raise RuntimeError(f"pcgrl_reduce_episodes rc={rc}")
             # (waiting on an event returns ~15 us sooner than the device-wide wait; the synchronise then finds an idle device)
@@ -441,7 +458,8 @@ def main():
             done_ev.synchronize()
             torch.cuda.synchronize(dev)
             return
-        env.reduce_episodes(clear=True, out=ep_dev)
+        if not launched:
+            env.reduce_episodes(clear=True, out=ep_dev)
         local_eps.copy_(ep_dev[2:3], non_blocking=True)  # (test evidence: this rank's own episode count)
         if coll_dev.type == "cpu":  # gloo test hook
             t = ep_dev.cpu()
@@ -507,7 +525,7 @@ def main():
     def measure_first_replay():
         """Round 4's short-run protocol, kept as a detail: ONE graph of all K steps, uploaded but never launched before the
         clock starts.  Returns ms per step of that first replay (+ the closing synchronise), or None."""
-        if not (2 <= K <= 125) or inject is not None or evo or sfg or graph is None or G == K:
+        if not (2 <= K <= 125) or inject is not None or evo or sfg or graph is None or (G == K and not fuse_reduce):
             return None
         try:
             g = torch.cuda.CUDAGraph()
@@ -578,7 +596,7 @@ def main():
     # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-reduce of the episode sums
     # cannot complete on any rank before every rank has contributed, i.e. finished its K launches; one collective instead
     # of an all-reduce followed by a barrier.  Ends with the device synchronised.
-    reduce_episodes(ev2)
+    reduce_episodes(ev2, launched=fuse_reduce)
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
     # the exchange on this rank's stream: reduction launch + (N > 1) the all-reduce, which also waits for the slowest rank
@@ -658,7 +676,10 @@ def main():
         # (pcgrl_reduce_episodes launch, N > 1: the all-reduce, which also absorbs rank skew, + the device->host copy) + host latency
         out["timed_region"] = {"wall_ms": elapsed * 1e3, "launches_ms": max(per_rank_kernel_ms) * K,
                                "exchange_ms": max(per_rank_exchange_ms), "exchange_share_of_wall": max(per_rank_exchange_ms) / (elapsed * 1e3),
-                               "protocol": (f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and W % G == 0 and K % G == 0
+                               "protocol": ("ONE replay of a HIP graph of the K step launches + the pcgrl_reduce_episodes launch (uploaded with hipGraphUpload, "
+                                            "never launched before; the W warm-up steps are eager launches); `launches_ms` includes that reduction launch"
+                                            if fuse_reduce else
+                                            f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and G < K and W % G == 0 and K % G == 0
                                             else f"replays of a HIP graph of {G} steps (+ {K % G} eager launches)" if graph is not None
                                             else "eager launches")}
         if closed is not None:
@@ -686,6 +707,13 @@ def main():
                 out["rllib_adapter"] = rllib_adapter_bench(problem, rep, shape, dev)
             except Exception as exc:  # noqa: BLE001
                 out["rllib_adapter"] = {"error": repr(exc)}
+        if args.sub_batches and inject is None and not evo and not sfg and not wkw:
+            try:
+                out["async_sub_batches"] = sub_batch_bench(args.workload, problem, rep, shape, N, dev,
+                                                           [int(x) for x in args.sub_batches.split(",") if int(x) > 1 and N % int(x) == 0],
+                                                           one_batch_us=(out["roofline"]["avg_launch_us"] if K >= 250 else None))
+            except Exception as exc:  # noqa: BLE001
+                out["async_sub_batches"] = {"error": repr(exc)}
         if not args.no_cpu_baseline:
             if pinned is not None:
                 try:
@@ -696,6 +724,12 @@ def main():
                 time.sleep(1.0)  # (the other ranks tear down their runtimes)
             out["cpu_baseline"] = cpu_baseline(problem, rep, shape, N, args.cpu_seconds, wkw, bfs_active, solver_active, REINJECT,
                                                mode="evo" if evo else "sfg" if sfg else "step", maps=sfg_host if sfg else None)
+        try:  # RCCL prints its version banner through C stdio; whatever sits in that buffer goes out BEFORE the line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stderr.flush()
         print(json.dumps(out), flush=True)
 
 
@@ -757,6 +791,65 @@ def launch_ranks(n):
         sys.stderr.write(f"bench.py launcher: {failed}; the remaining ranks were stopped\n")
         return 1
     return max(abs(rc) for rc in rcs)
+
+
+def sub_batch_bench(workload, problem, rep, shape, n_envs, dev, ks, graph_steps=50, replays=20, one_batch_us=None):
+    """`async_sub_batches`: a step launch waits for its slowest env; k independent sub-batch chains (k engines, k streams, one
+    HIP graph with k parallel branches: control_pcgrl_amd.SubBatchedVecEnv) shrink that synchronisation domain.  Same envs
+    (seeds), same action source as the timed region; us per step of the WHOLE batch by HIP events.  Never `value`."""
+    import numpy as np
+    import torch
+    from control_pcgrl_amd import SubBatchedVecEnv, VecPcgrlEnv
+    rows = []
+    main_s = torch.cuda.current_stream(dev)
+    for k in [1] + list(ks):
+        if k == 1:
+            env = VecPcgrlEnv(problem, rep, shape, n_envs, device=dev, seeds=0x5EED + np.arange(n_envs), auto_reset=True)
+        else:
+            env = SubBatchedVecEnv(problem, rep, shape, n_envs, k, device=dev, seeds=0x5EED + np.arange(n_envs), auto_reset=True)
+        env.reset()
+        g = torch.Generator(device=dev).manual_seed(1234)
+        acts = torch.randint(0, env.num_actions, (64, n_envs), generator=g, device=dev, dtype=torch.int32)
+        for t in range(3):
+            env.step(acts[t])
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(gr, stream=side, capture_error_mode="thread_local"):
+                if k == 1:
+                    for t in range(graph_steps):
+                        env.step(acts[t % 64])
+                else:  # the chains are independent over the whole graph: sub-batch i's launch t + 1 only follows ITS launch t
+                    n = n_envs // k
+                    for t in range(graph_steps):
+                        for i in range(k):
+                            env.step_async(i, acts[t % 64, i * n:(i + 1) * n])
+                    env.wait()
+        main_s.wait_stream(side)
+        for _ in range(4):
+            gr.replay()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main_s)
+        for _ in range(replays):
+            gr.replay()
+        e1.record(main_s)
+        torch.cuda.synchronize(dev)
+        env.check_errors()
+        us = e0.elapsed_time(e1) * 1e3 / (replays * graph_steps)
+        rows.append({"sub_batches": k, "us_per_step_of_whole_batch": us, "env_steps_per_s": n_envs / (us * 1e-6),
+                     "roofline_frac": ALGO_BYTES[workload] * n_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        del gr
+        env.close()
+    base = rows[0]["us_per_step_of_whole_batch"]
+    for r in rows:
+        r["speedup_vs_one_batch_same_protocol"] = base / r["us_per_step_of_whole_batch"]
+    return {"unit": "env-steps/s", "rows": rows, "graph_steps": graph_steps, "replays": replays,
+            "note": "k engines of N / k envs on k streams (SubBatchedVecEnv.step_async): sub-batch i's launch t + 1 only follows ITS launch "
+                    "t, so a launch waits for the slowest env of N / k instead of N and the chains overlap on the device; one HIP graph "
+                    "with k parallel branches; the first steps of an episode (3-D mazes: slower than the episode average behind `value`)"}
 
 
 def rllib_adapter_bench(problem, rep, shape, dev, sizes=(20, 2000, 4096), seconds=0.7):

@@ -9,7 +9,7 @@ The compute lives in csrc/libpcgrl_amd.so (hand-written HIP for gfx950) behind t
 include/pcgrl_amd.h; this package fails loudly if that library is missing -- there is no CPU fallback.
 """
 from .problems import PROBLEMS, REPRESENTATIONS, ProblemSpec, problem_spec  # noqa: F401
-from .vec_env import VecPcgrlEnv, make_vec_env  # noqa: F401
+from .vec_env import SubBatchedVecEnv, VecPcgrlEnv, make_vec_env  # noqa: F401
 from .envs import make_env, PcgrlGymEnv  # noqa: F401
 from .rllib_env import PcgrlVectorEnv  # noqa: F401
 from .dist import EpisodeStatsReducer, shard_env_range  # noqa: F401

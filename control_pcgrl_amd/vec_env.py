@@ -97,7 +97,7 @@ class VecPcgrlEnv:
     def __init__(self, problem, representation, map_shape, num_envs, device="cuda:0", obs_window=None, weights=None,
                  max_board_scans=3, change_percentage=None, seeds=None, auto_reset=True, solver_power=10000,
                  static_trgs=None, controls=None, reward_dtype=torch.float32, act_window=None, static_prob=None,
-                 n_static_walls=None, static_eval=False):
+                 n_static_walls=None, static_eval=False, _out=None):
         if not torch.cuda.is_available():
             raise RuntimeError("VecPcgrlEnv needs a GPU (ROCm device); there is no CPU fallback in the product path")
         self.device = torch.device(device)
@@ -131,10 +131,14 @@ class VecPcgrlEnv:
         # with an action patch the action is MultiDiscrete([n_tiles] * prod(act_window)): int32 [N, action_entries]
         self.action_entries = int(np.prod(self.act_window)) if self.act_window else 1
         N, dev = self.num_envs, self.device
-        self._obs = torch.empty((N,) + self.obs_shape, dtype=torch.uint8, device=dev)
-        self._reward = torch.empty(N, dtype=torch.float32, device=dev)
-        self._done = torch.empty(N, dtype=torch.uint8, device=dev)
-        self._stats = torch.empty((N, self.n_stats), dtype=torch.int32, device=dev)
+        if _out is not None:  # SubBatchedVecEnv: this engine writes its rows of the whole batch's output tensors
+            self._obs, self._reward, self._done, self._stats = _out
+            assert self._obs.shape == (N,) + self.obs_shape and self._obs.is_contiguous() and self._stats.is_contiguous()
+        else:
+            self._obs = torch.empty((N,) + self.obs_shape, dtype=torch.uint8, device=dev)
+            self._reward = torch.empty(N, dtype=torch.float32, device=dev)
+            self._done = torch.empty(N, dtype=torch.uint8, device=dev)
+            self._stats = torch.empty((N, self.n_stats), dtype=torch.int32, device=dev)
         self._ptrs = (self._obs.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._stats.data_ptr())
         # controllable mode / float64 rewards go through pcgrl_step_ex
         self._reward64 = torch.empty(N, dtype=torch.float64, device=dev) if reward_dtype == torch.float64 else None
@@ -456,7 +460,116 @@ class VecPcgrlEnv:
         self.set_rng_state(sd["rng"], mask=mask)
 
 
-def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
+class SubBatchedVecEnv:
+    """The batch cut into k independent sub-batches: k engines of N / k envs, each launched on a HIP stream of its own.
+
+    A step launch lasts as long as its slowest env (one long path search); with k chains a launch only waits for the
+    slowest env of ITS sub-batch and the chains overlap on the device (`async_sub_batches`: up to
+    1.3 x on 64 x 64 maps and the 15^3 maze, a loss on the 16 x 16 maps whose launches are already short).  Envs are
+    independent objects in the reference too (rl/utils.py:412-415 workers x envs); results are those of one batch of N.
+
+      step(actions)              all k launches forked from / joined back into the current stream: drop-in for
+                                 VecPcgrlEnv.step (outputs are [N, ...] tensors, sub-batch i owns rows [i*n, (i+1)*n)),
+                                 also under HIP-graph capture (k parallel branches)
+      step_async(i, actions_i)   launch sub-batch i alone on its stream -> its rows of the outputs; wait(i) makes the
+                                 current stream wait for it (Sample-Factory-style double buffering: the policy runs on
+                                 sub-batch i's observation while sub-batch j steps)
+    """
+
+    def __init__(self, problem, representation, map_shape, num_envs, sub_batches, device="cuda:0", seeds=None, **kw):
+        k = int(sub_batches)
+        if k < 1 or num_envs % k:
+            raise ValueError("num_envs must be a multiple of sub_batches")
+        self.k, self.num_envs, self.n_sub = k, int(num_envs), int(num_envs) // k
+        self.device = torch.device(device)
+        seeds = np.arange(num_envs) if seeds is None else np.broadcast_to(np.asarray(seeds), (num_envs,))
+        n = self.n_sub
+        probe = build_config(problem, representation, map_shape, kw.get("obs_window"), kw.get("weights"),
+                             kw.get("max_board_scans", 3), kw.get("change_percentage"), kw.get("solver_power", 10000),
+                             kw.get("static_trgs"), kw.get("controls"), kw.get("act_window"), kw.get("static_prob"),
+                             kw.get("n_static_walls"), kw.get("static_eval", False))
+        cfg, spec, obs_window = probe
+        nt = spec.n_tiles
+        if representation == "wide":
+            obs_shape = tuple(map_shape) + (nt,)
+        elif len(map_shape) == 3:
+            obs_shape = tuple(obs_window) + (4,)
+        else:
+            obs_shape = tuple(obs_window) + (nt + 1 + (1 if cfg.static_tiles else 0),)
+        N, dev = self.num_envs, self.device
+        self._obs = torch.empty((N,) + obs_shape, dtype=torch.uint8, device=dev)
+        self._reward = torch.empty(N, dtype=torch.float32, device=dev)
+        self._done = torch.empty(N, dtype=torch.uint8, device=dev)
+        self._stats = torch.empty((N, len(spec.stat_keys)), dtype=torch.int32, device=dev)
+        self.streams = [torch.cuda.Stream(dev) for _ in range(k)]
+        self.envs = []
+        for i in range(k):
+            sl = slice(i * n, (i + 1) * n)
+            self.envs.append(VecPcgrlEnv(problem, representation, map_shape, n, device=dev, seeds=seeds[sl],
+                                         _out=(self._obs[sl], self._reward[sl], self._done[sl], self._stats[sl]), **kw))
+        e0 = self.envs[0]
+        assert e0.obs_shape == obs_shape, (e0.obs_shape, obs_shape)
+        for a in ("obs_shape", "num_actions", "action_entries", "stat_keys", "n_stats", "spec", "cfg", "map_shape", "auto_reset",
+                  "problem", "representation"):
+            setattr(self, a, getattr(e0, a))
+        done = self._done.view(torch.bool)
+        self._step_out = (self._obs, self._reward, done, done, {"stats": self._stats})
+
+    def close(self):
+        for e in self.envs:
+            e.close()
+
+    def _fork(self, i):
+        self.streams[i].wait_stream(torch.cuda.current_stream(self.device))
+
+    def wait(self, i=None):
+        """the current stream waits for sub-batch i's stream (None: for all of them)"""
+        cur = torch.cuda.current_stream(self.device)
+        for j in (range(self.k) if i is None else (i,)):
+            cur.wait_stream(self.streams[j])
+
+    def reset(self, **kw):
+        n = self.n_sub
+        for i, e in enumerate(self.envs):
+            self._fork(i)
+            with torch.cuda.stream(self.streams[i]):
+                e.reset(**{key: (None if v is None else torch.as_tensor(v)[i * n:(i + 1) * n]) for key, v in kw.items()})
+        self.wait()
+        return self._obs, {}
+
+    def step_async(self, i, actions):
+        """sub-batch i alone, on its own stream (ordered after the work already queued on the current stream); returns
+        the sub-batch's step tuple -- valid once wait(i) has been called (or its stream synchronised)"""
+        self._fork(i)
+        with torch.cuda.stream(self.streams[i]):
+            return self.envs[i].step(actions)
+
+    def step(self, actions):
+        if self.envs[0]._ex:
+            raise NotImplementedError("controllable mode / float64 rewards: use step_async(i, ...) (per-sub-batch outputs)")
+        n = self.n_sub
+        a = actions.reshape(self.num_envs, -1)
+        for i in range(self.k):
+            self.step_async(i, a[i * n:(i + 1) * n])
+        self.wait()
+        return self._step_out
+
+    def get_state(self):
+        self.wait()
+        parts = [e.get_state() for e in self.envs]
+        return SimpleNamespace(**{key: torch.cat([getattr(p, key) for p in parts]) for key in
+                                  ("grids", "pos", "counters", "stats", "last_loss", "ep_return", "iteration", "changes", "n_step", "ep_len")})
+
+    def reduce_episodes(self, clear=True):
+        self.wait()
+        return torch.stack([e.reduce_episodes(clear=clear) for e in self.envs]).sum(0)
+
+    def check_errors(self):
+        for e in self.envs:
+            e.check_errors()
+
+
+def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True, sub_batches=1):
     """Batched counterpart of control_pcgrl/rl/envs.py:make_env(cfg).  `cfg` is the reference's Config-like
     object (attributes or dict keys): task.problem, task.map_shape, task.obs_window, task.weights,
     representation, max_board_scans, change_percentage."""
@@ -468,7 +581,8 @@ def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True):
     bad = {k: v for k, v in unsupported.items() if v not in (None, 0, False)}
     if bad:
         raise NotImplementedError(f"outside the accelerated hot path (SURVEY.md section 8f 'next'): {bad}")
-    return VecPcgrlEnv(
+    ctor = VecPcgrlEnv if int(sub_batches) <= 1 else (lambda **kw: SubBatchedVecEnv(sub_batches=sub_batches, **kw))
+    return ctor(
         problem=_cfg_get(cfg, "task.problem"), representation=_cfg_get(cfg, "representation"),
         map_shape=tuple(_cfg_get(cfg, "task.map_shape")), num_envs=num_envs, device=device,
         obs_window=_cfg_get(cfg, "task.obs_window"), weights=_cfg_get(cfg, "task.weights"),

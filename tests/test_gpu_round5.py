@@ -31,7 +31,9 @@ def _bench(*argv, env=None, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True,
                        timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines and r.stdout.strip().splitlines()[-1] == lines[-1], "the JSON line is the LAST line of stdout:\n" + r.stdout[-2000:]
+    return json.loads(lines[-1])
 
 
 # ------------------------------------------------------------------------------------- RCCL with one rank (SURVEY 8 e)
@@ -53,13 +55,19 @@ def test_bench_force_collective_runs_rccl_with_one_rank():
 
 
 def test_bench_driver_protocol_with_collective():
-    """the driver's own command line (--steps 20 --warmup 5) through the collective path: graph of gcd(5, 20) = 5 steps,
-    one untimed + four timed replays; the line carries the exchange cost and the closed-loop figure"""
+    """the driver's own command line (--steps 20 --warmup 5) through the collective path: the whole timed region is one
+    HIP graph (20 step launches + the reduction launch), then the all-reduce; the line carries the exchange cost, the
+    closed-loop figure and the sub-batch figure; the gcd protocol is still selectable"""
     out = _bench("--gpus", "1", "--force-collective", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0",
-                 "--rllib-adapter", "0", "--closed-loop-steps", "500")
+                 "--rllib-adapter", "0", "--closed-loop-steps", "500", "--sub-batches", "2")
     assert out["steps"] == 20 and out["warmup"] == 5
-    assert out["config"]["launch"] == "HIP graph of 5 steps per replay"
-    assert out["timed_region"]["protocol"].startswith("1 untimed + 4 timed replays")
+    assert out["config"]["launch"] == "HIP graph of 20 steps per replay"
+    assert out["timed_region"]["protocol"].startswith("ONE replay of a HIP graph of the K step launches + the pcgrl_reduce_episodes")
+    sb = out["async_sub_batches"]
+    assert "error" not in sb and [r["sub_batches"] for r in sb["rows"]] == [1, 2]
+    g = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0", "--rllib-adapter", "0",
+               "--closed-loop-steps", "0", "--sub-batches", "", "--short-protocol", "gcd")
+    assert g["timed_region"]["protocol"].startswith("1 untimed + 4 timed replays of one HIP graph of 5 steps")
     cl = out["closed_loop_device_actions"]
     assert "error" not in cl, cl
     assert cl["steps"] == 500 and cl["us_per_step"] > 0
@@ -426,3 +434,61 @@ def test_one_thread_two_handles_interleaved_on_two_streams():
             assert np.max(np.abs(outs[i][t][1].cpu().numpy().astype(np.float64) - orew)) <= REW_TOL
             assert np.array_equal(outs[i][t][2].cpu().numpy().astype(bool), odone)
         envs[i].check_errors()
+
+
+# ------------------------------------------------------------------------------------- sub-batch chains
+@pytest.mark.parametrize("problem,rep,shape,n,k", [("binary", "narrow", (40, 48), 96, 4), ("minecraft_3D_maze", "narrow", (7, 7, 7), 128, 2),
+                                                  ("zelda", "turtle", (16, 16), 120, 3)])
+def test_sub_batched_env_equals_one_batch_vs_oracle(problem, rep, shape, n, k):
+    """make_vec_env(..., sub_batches=k): k engines on k streams behind one step(); eager and as k parallel branches of a
+    captured HIP graph; double-buffered step_async / wait.  Same results as the oracle's single batch of n envs."""
+    from control_pcgrl_amd import make_vec_env
+    cfg = {"task": {"problem": problem, "map_shape": list(shape), "obs_window": None, "weights": None}, "representation": rep,
+           "change_percentage": 0.1}
+    env = make_vec_env(cfg, n, seeds=700 + np.arange(n), sub_batches=k)
+    assert env.k == k and len(env.envs) == k
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=700 + np.arange(n), threads=8, change_percentage=0.1)
+    obs, _ = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.reset())
+    g = torch.Generator().manual_seed(5)
+    T = 150
+    acts = torch.randint(0, env.num_actions, (T, n), generator=g, dtype=torch.int32)
+    dacts = acts.to(env.device)
+
+    def check(t, obs, rew, done, stats, want_obs):
+        oobs, orew, odone, ostats = orc.step(acts[t].numpy(), auto_reset=True, want_obs=want_obs)
+        assert np.array_equal(stats.cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL, f"reward @ {t}"
+        assert np.array_equal(done.cpu().numpy().astype(bool), odone), f"done @ {t}"
+        if want_obs:
+            assert np.array_equal(obs.cpu().numpy(), oobs), f"obs @ {t}"
+
+    for t in range(50):  # (a) eager, all sub-batches behind one step()
+        obs, rew, done, _, info = env.step(dacts[t])
+        check(t, obs, rew, done, info["stats"], t % 7 == 0)
+    # (b) one HIP graph with k parallel branches, replayed with new actions in the same buffer
+    buf = torch.zeros(n, dtype=torch.int32, device=env.device)
+    gr = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(env.device)
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gr, stream=side):
+            env.step(buf)
+    torch.cuda.current_stream(env.device).wait_stream(side)
+    for t in range(50, 100):
+        buf.copy_(dacts[t])
+        gr.replay()
+        obs, rew, done, _, info = env._step_out
+        check(t, obs, rew, done, info["stats"], t % 7 == 0)
+    # (c) double buffering: sub-batch i steps while the others' results are read
+    n_sub = env.n_sub
+    for t in range(100, T):
+        outs = [env.step_async(i, dacts[t, i * n_sub:(i + 1) * n_sub]) for i in range(k)]
+        for i in range(k):
+            env.wait(i)
+        obs = torch.cat([o[0] for o in outs]); rew = torch.cat([o[1] for o in outs])
+        done = torch.cat([o[2] for o in outs]); stats = torch.cat([o[4]["stats"] for o in outs])
+        check(t, obs, rew, done, stats, t % 7 == 0)
+    st, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"])
+    env.check_errors()
