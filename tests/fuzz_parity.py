@@ -606,6 +606,10 @@ if __name__ == "__main__":
     ap.add_argument("--case", type=str, default=None, help="replay one case (the JSON a failure printed)")
     ap.add_argument("--dry", action="store_true", help="only print the drawn cases (no GPU needed)")
     ap.add_argument("--only", type=str, default=None, help="comma-separated problems to keep (the others are drawn and skipped)")
+    ap.add_argument("--max-refused", type=int, default=-1,
+                    help="refusals (PCGRL_EUNSUPPORTED at run time) tolerated before the campaign FAILS (exit code 2); default: "
+                         "max(2, cases / 500) -- since round 4 nothing the generator draws is refused, so a kernel that newly reports "
+                         "ring overflows or solver limits on configurations it used to handle must not pass as '0 failures'")
     a = ap.parse_args()
     if a.dry:
         r = np.random.default_rng(a.seed)
@@ -622,5 +626,6 @@ if __name__ == "__main__":
             print("events:", " ".join(c.get("_trace", [])))
         sys.exit(0)
     f = sweep(a.cases, a.seed, stop_on_fail=not a.keep_going, budget_s=a.budget_s, only=a.only.split(",") if a.only else None)
-    print(f"{len(f)} failure(s), {len(sweep.refused)} refused (reported limits, see REFUSED lines)")
-    sys.exit(1 if f else 0)
+    limit = a.max_refused if a.max_refused >= 0 else max(2, a.cases // 500)
+    print(f"{len(f)} failure(s), {len(sweep.refused)} refused (reported limits, see REFUSED lines; tolerated: {limit})")
+    sys.exit(1 if f else (2 if len(sweep.refused) > limit else 0))

@@ -385,7 +385,7 @@ def test_two_handles_two_streams_two_host_threads_vs_oracle():
         assert np.array_equal(out[t][0], ostats), f"A stats @ {t}"
         assert np.max(np.abs(out[t][1].astype(np.float64) - orew)) <= REW_TOL and np.array_equal(out[t][2].astype(bool), odone), f"A @ {t}"
         fired += int((ostats[:, 4] != 8192).sum())
-    assert fired > 1000, "the device solver ran inside the step launches"
+    assert fired > 300, "the device solver ran inside the step launches"
     assert pool[0] >= 64 and not pool[2]
     for h in hl:
         assert np.array_equal(h, want_extra)
