@@ -5,18 +5,10 @@
 
 namespace pcgrl {
 template <int SC>
-static hipError_t launch_3d_sc(KernelId id, const Params &p, int cpl, hipStream_t s, bool runner) {
+static hipError_t launch_3d_sc(KernelId id, const Params &p, int cpl, hipStream_t s) {
   dim3 grid(p.n_envs), block(64);
   switch (id) {
-    case K_STEP:  // simulate + observe + helper waves (+ the pair runner: size class 0, small batches)
-      if constexpr (SC == 0) {
-        if (runner) {
-          hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 0, true>), grid, dim3(256), 0, s, p, cpl);
-          break;
-        }
-      }
-      hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(64 * (2 + m3_observers<SC>())), 0, s, p, cpl);
-      break;
+    case K_STEP: hipLaunchKernelGGL((m3_kernel<M3_STEP, SC>), grid, dim3(64 * (2 + m3_observers<SC>())), 0, s, p, cpl); break;  // simulate + observe + helper waves
     case K_RESET: hipLaunchKernelGGL((m3_kernel<M3_RESET, SC>), grid, block, 0, s, p, cpl); break;
     case K_OBSERVE: hipLaunchKernelGGL((m3_kernel<M3_OBSERVE, SC>), grid, block, 0, s, p, cpl); break;
     case K_GET_STATE: hipLaunchKernelGGL((m3_kernel<M3_GET_STATE, SC>), grid, block, 0, s, p, cpl); break;
@@ -34,14 +26,8 @@ hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s
   dim3 grid(p.n_envs), block(64);
   const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7 && p.cfg.obs_window[0] == 14 &&
                   p.cfg.obs_window[1] == 14 && p.cfg.obs_window[2] == 14;
-  // small batches: a fourth wavefront per env (the pair runner, pcgrl_kernels3d.h PLANE-PARALLEL CANDIDATE WALK) -- at 1024 envs
-  // a CU holds 4 workgroups of 3 waves and has room for twice that; from 4096 envs on the CUs are full and the extra wave
-  // would only take issue slots from other envs' simulate waves
-  static const int runner_max = getenv("PCGRL_M3_RUNNER_MAX") ? atoi(getenv("PCGRL_M3_RUNNER_MAX")) : 2048;  // (development: 0 = never)
-  const bool runner = p.n_envs <= runner_max;
   if (d7 && id == K_STEP) {
-    if (runner) hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7, true>), grid, dim3(256), 0, s, p, cpl);
-    else hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7>), grid, dim3(192), 0, s, p, cpl);
+    hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7>), grid, dim3(192), 0, s, p, cpl);
     return hipGetLastError();
   }
   if (d7 && id == K_ROLLOUT) {
@@ -57,6 +43,6 @@ hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s
     hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 15>), grid, dim3(64 * (2 + m3_observers<1>())), 0, s, p, cpl);
     return hipGetLastError();
   }
-  if (m3_size_class(p.cfg.dims[0], p.cfg.dims[1], p.cfg.dims[2]) == 0) return launch_3d_sc<0>(id, p, cpl, s, runner);
-  return launch_3d_sc<1>(id, p, cpl, s, false);
+  if (m3_size_class(p.cfg.dims[0], p.cfg.dims[1], p.cfg.dims[2]) == 0) return launch_3d_sc<0>(id, p, cpl, s);
+  return launch_3d_sc<1>(id, p, cpl, s);
 }

@@ -48,7 +48,10 @@ namespace pcgrl {
 // ([0] trips [1] queue entries [2] searches [3] search-loop cycles [4] regions [5] everything else [6] candidate walk incl.
 // the search loops) or, with -DPCGRL_M3_PHASES, the phases of the simulate wave ([0] loads until the barrier [1] columns +
 // move-table update [2] regions [3] candidate walk [4] overlay [5] outputs + write-back [6] fresh tables); [7] = wall clock.
-#if defined(PCGRL_M3_SPEC)  // [0] pairs run [1] with a remembered farthest cell [2] of which the helper's search was used
+#if defined(PCGRL_M3_TAIL)  // simulate wave (tools/tail_3d_walk.py): [0] cached start planes missing when the walk began [1] pairs of
+// searches it ran [3] candidate-walk cycles [5] speculative second searches used [6] everything else
+#define M3_MARK(coarse, fine) PHASE_MARK((coarse) == 3 ? 3 : 6)
+#elif defined(PCGRL_M3_SPEC)  // [0] pairs run [1] with a remembered farthest cell [2] of which the helper's search was used
 #define M3_MARK(coarse, fine) PHASE_MARK(6)
 #elif defined(PCGRL_M3_TRIPS)  // [0] chain trips [1] general trips [2] / [3] their cycles; the first four phases land in [6]
 #define M3_MARK(coarse, fine) PHASE_MARK((coarse) < 4 ? 6 : (coarse))
@@ -233,13 +236,10 @@ struct M3SlotHdr {
 };
 static_assert(sizeof(M3SlotHdr) == 4 * M3_SLOT_HDR, "slot header layout");
 
-// workspace of one search wave.  RING_: entries of the queue ring -- the simulate wave's holds M3C::RING; the helper waves of
-// the small-batch step kernel make do with half (their searches are speculative: one that would need more is given up and
-// run by the simulate wave, see m3_pair_runner)
-template <int SC, int RING_ = M3C<SC>::RING>
+// workspace of one search wave
+template <int SC>
 struct M3Work {
-  static constexpr int RING = RING_;
-  uint2 ent[RING_];                 // queue ring: cell | parent cell<<12 (0x1FFF: none) | move code<<25 | direction<<30 ; len
+  uint2 ent[M3C<SC>::RING];         // queue ring: cell | parent cell<<12 (0x1FFF: none) | move code<<25 | direction<<30 ; len
   uint2 best[M3C<SC>::CELLS];       // per cell: epoch<<24 | len of the accepted path (the `paths` dict) ; trip claim
   uint32_t info[M3C<SC>::CELLS];    // per cell, of the accepted entry: parent cell | move code<<13 | direction<<18
   uint16_t order[M3C<SC>::CELLS];   // cells in first-insertion order
@@ -529,10 +529,10 @@ __device__ inline uint32_t m3_update_moves(const M3Ctx &c, int ex, int ey, int e
 // tools/ubench/latency.hip -- so a trip costs its instruction count: ~60 here, ~100 in the 16-entry trip.)
 // `best` entries carry the search's epoch, so nothing is cleared between searches.
 // `cancel` (helper wave, see SPECULATION): the search gives up as soon as *cancel is set; its result is then meaningless.
-template <int SC, bool CANCEL = false, int RING = M3C<SC>::RING>
-__device__ inline int m3_search(M3Work<SC, RING> &W, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip, bool &overflow,
+template <int SC, bool CANCEL = false>
+__device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_t &epoch, uint32_t &trip, bool &overflow,
                                 const int *cancel PHASE_ARG) {
-  constexpr int RM = RING - 1;
+  constexpr int RING = M3C<SC>::RING, RM = RING - 1;
   const int16_t *mv = c.mv;
   uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch) + 1u;
   if (ep > 255u) {  // wrapped: clear the table once
@@ -702,7 +702,7 @@ __device__ inline int m3_search(M3Work<SC, RING> &W, const M3Ctx &c, int root, u
   (void)_t_prev;
   (void)dbg_trips;
   (void)dbg_pushed;
-#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES) && !defined(PCGRL_M3_SPEC)
+#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES) && !defined(PCGRL_M3_SPEC) && !defined(PCGRL_M3_TAIL)
   (void)_t_prev;
   _ph[0] += (uint32_t)dbg_trips;
   _ph[1] += (uint32_t)dbg_pushed;
@@ -722,8 +722,8 @@ __device__ inline int m3_search(M3Work<SC, RING> &W, const M3Ctx &c, int root, u
 // After a search: the first maximum of len(path) in first-insertion order (helper_3D.py:538-541) -> far; the accepted
 // cells -> W.racc; returns the coordinate values of those cells (bit v set if some accepted cell has x, y or z == v: the
 // marks of :531).
-template <int SC, int RING>
-__device__ inline uint32_t m3_collect(M3Work<SC, RING> &W, const M3Ctx &c, int n_order, int &far) {
+template <int SC>
+__device__ inline uint32_t m3_collect(M3Work<SC> &W, const M3Ctx &c, int n_order, int &far) {
   uint32_t mkl = 0, key = 0;  // len << 16 | (0xFFFF - k): max key = longest, earliest
   for (int k = c.lane; k < n_order; k += 64) {
     const int ci = W.order[k];
@@ -745,8 +745,8 @@ __device__ inline uint32_t m3_collect(M3Work<SC, RING> &W, const M3Ctx &c, int n
 // parent cells is walked first -- one dependent LDS read per hop and nothing else, hop h parked in lane h -- then the
 // lanes mark their hop's cell and the intermediate tiles of its move in parallel: an entry knows its move code and
 // direction (helper_3D.py:214-319; +-YX = one plane up / down).  n_j of an entry = the jumps along its chain (:283-319).
-template <int SC, int RING>
-__device__ inline int m3_path_tiles(M3Work<SC, RING> &W, const M3Ctx &c, int s, int far2) {
+template <int SC>
+__device__ inline int m3_path_tiles(M3Work<SC> &W, const M3Ctx &c, int s, int far2) {
   uint32_t *sp = c.spath(s);
   for (int i = c.lane; i < c.L.nw; i += 64) sp[i] = 0;
   int cell = far2, n_jump = 0;
@@ -805,11 +805,11 @@ __device__ inline int m3_ld(const int32_t *x) { return __hip_atomic_load(x, __AT
 __device__ inline void m3_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // second search of a pair from `root` in workspace W: accepted cells -> W.racc (OR-ed in), path tiles -> slot s.
-template <int SC, bool CANCEL, int RING>
-__device__ inline bool m3_second_search(M3Work<SC, RING> &W, const M3Ctx &c, int s, int root, uint32_t &epoch, uint32_t &trip, int &far2,
+template <int SC, bool CANCEL>
+__device__ inline bool m3_second_search(M3Work<SC> &W, const M3Ctx &c, int s, int root, uint32_t &epoch, uint32_t &trip, int &far2,
                                         int &max_dist, int &n_jump, const int *cancel PHASE_ARG) {
   bool overflow = false;
-  const int n_order = m3_search<SC, CANCEL, RING>(W, c, root, epoch, trip, overflow, cancel PHASE_PASS);
+  const int n_order = m3_search<SC, CANCEL>(W, c, root, epoch, trip, overflow, cancel PHASE_PASS);
   if (overflow) return false;
   (void)m3_collect(W, c, n_order, far2);
   max_dist = (int)(__builtin_amdgcn_readfirstlane((int)W.best[far2].x) & 0xFFFF);
@@ -820,8 +820,8 @@ __device__ inline bool m3_second_search(M3Work<SC, RING> &W, const M3Ctx &c, int
 // body of the helper wave: serve the simulate wave's jobs until it leaves
 // SEARCH: the wave also runs speculative second searches in its own workspace W (size class 0); otherwise it only counts
 // regions (size class 1: there is no LDS for a second workspace) and W is not touched.
-template <int SC, bool SEARCH, int RING>
-__device__ inline void m3_helper(const Params &p, M3Work<SC, RING> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
+template <int SC, bool SEARCH>
+__device__ inline void m3_helper(const Params &p, M3Work<SC> &W, const M3Ctx &c, M3Mail &m PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
   uint32_t epoch = 0, trip = 0;
   if constexpr (SEARCH) {
@@ -870,7 +870,7 @@ __device__ inline void m3_helper(const Params &p, M3Work<SC, RING> &W, const M3C
     const int root = __builtin_amdgcn_readfirstlane(m3_ld(&m.root)), s = __builtin_amdgcn_readfirstlane(m3_ld(&m.slot));
     for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
     int far2 = 0, max_dist = 0, n_jump = 0;
-    const bool ok = m3_second_search<SC, true, RING>(W, c, s, root, epoch, trip, far2, max_dist, n_jump, &m.cancel PHASE_PASS);
+    const bool ok = m3_second_search<SC, true>(W, c, s, root, epoch, trip, far2, max_dist, n_jump, &m.cancel PHASE_PASS);
     if (c.lane == 0) {
       m.ok = ok ? 1 : 0;
       m.far2 = far2;
@@ -884,10 +884,9 @@ __device__ inline void m3_helper(const Params &p, M3Work<SC, RING> &W, const M3C
 
 // The pair of searches of one start candidate (helper_3D.py:527-553) -> slot s of the env (result + accepted cells).
 // W2 / mail: the helper wave's workspace and mailbox (null: no helper).
-// CANCEL / cancel: the pair runner's fills (m3_pair_runner) give up as soon as *cancel is set (reported as overflow).
-template <int SC, int RING, int RING2, bool CANCEL = false>
-__device__ inline void m3_fill_slot(M3Work<SC, RING> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch, uint32_t &trip,
-                                    bool &overflow, M3Work<SC, RING2> *W2, M3Mail *mail, const int *cancel PHASE_ARG) {
+template <int SC>
+__device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int start_bit, int sz, uint32_t &epoch, uint32_t &trip,
+                                    bool &overflow, M3Work<SC> *W2, M3Mail *mail PHASE_ARG) {
   // the farthest cell of this plane's first search the last time it ran (+1; 0: none)
   const uint32_t far_word = mail != nullptr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)c.hdr(s)->far1) : 0u;
   int guess = (int)(far_word & 0xFFFFu) - 1;
@@ -911,7 +910,7 @@ __device__ inline void m3_fill_slot(M3Work<SC, RING> &W, const M3Ctx &c, int s, 
   if (c.lane == 0) c.hdr(s)->valid = 0;
   for (int i = c.lane; i < c.L.nw; i += 64) W.racc[i] = 0;
   const int root = sz * c.YX + start_bit;
-  int n_order = m3_search<SC, CANCEL, RING>(W, c, root, epoch, trip, overflow, cancel PHASE_PASS);
+  int n_order = m3_search<SC>(W, c, root, epoch, trip, overflow, nullptr PHASE_PASS);
   int far1 = 0, far2 = 0, n_jump = 0, max_dist = 0;
   uint32_t mk = 0;
   if (!overflow) mk = m3_collect(W, c, n_order, far1);
@@ -938,9 +937,13 @@ __device__ inline void m3_fill_slot(M3Work<SC, RING> &W, const M3Ctx &c, int s, 
 #if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_SPEC)
   _ph[0] += 1;
 #endif
+#if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_TAIL)
+  _ph[1] += 1;
+  _ph[5] += have2 ? 1u : 0u;
+#endif
   if (overflow) return;
   if (!have2) {
-    if (!m3_second_search<SC, CANCEL, RING>(W, c, s, far1, epoch, trip, far2, max_dist, n_jump, cancel PHASE_PASS)) {
+    if (!m3_second_search<SC, false>(W, c, s, far1, epoch, trip, far2, max_dist, n_jump, nullptr PHASE_PASS)) {
       overflow = true;
       return;
     }
@@ -959,99 +962,29 @@ __device__ inline void m3_fill_slot(M3Work<SC, RING> &W, const M3Ctx &c, int s, 
   }
 }
 
-// PLANE-PARALLEL CANDIDATE WALK (small batches: the fourth wavefront of m3_kernel<M3_STEP, 0, DIM, true>).  A step launch
-// lasts as long as its slowest env, and the slowest env of a launch is usually one whose edit dropped the cached results of
-// TWO start planes (tools/tail_3d.py: the slowest wave of a median launch runs three searches).  A slot's content is a pure
-// function of the map (start cell + move-table rows of the accepted cells), so whether the sequential walk of
-// calc_longest_path ends up looking at a plane or skips it (whole-plane marks of an earlier component, :531) does not matter
-// for what the slot holds: the simulate wave posts the slots that are missing at the start of its walk, takes the first
-// itself, and the "pair runner" wave fills the others meanwhile, each with both of its searches, in a workspace of its own.
-// The walk waits for a slot the runner has claimed only when it really needs it; results are those of the sequential walk.
-// At large batches the CUs are full of workgroups anyway and a fourth wave per env only takes their issue slots: the host
-// picks the variant by batch size (launch_3d).
-struct M3Jobs {
-  int32_t go;        // set by the simulate wave once todo / start[] are in place (at most once per launch)
-  int32_t todo;      // slots (bit s = start plane s + 1) whose cached result was missing when the walk began
-  int32_t claimed;   // slots taken, by either wave
-  int32_t done;      // slots the runner has filled (valid)
-  int32_t gaveup;    // slots the runner claimed and left invalid (cancelled, or its smaller queue ring overflowed)
-  int32_t cancel;    // the walk is over: stop
-  int32_t idle;      // the runner has left: it writes nothing of the env's record any more
-  int32_t start[8];  // start bit of each posted slot's plane
-};
-__device__ inline int m3_or(int32_t *x, int v) { return __hip_atomic_fetch_or(x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-template <int SC, int RING>
-__device__ inline void m3_pair_runner(M3Work<SC, RING> &W, const M3Ctx &c, M3Jobs &J, const M3Mail &mail PHASE_ARG) {
-  while (true) {  // a posting, or the end of the launch (most steps post nothing)
-    if (__builtin_amdgcn_readfirstlane(m3_ld(&J.go)) != 0) break;
-    if (__builtin_amdgcn_readfirstlane(m3_ld(&mail.exit)) != 0) return;
-    __builtin_amdgcn_s_sleep(2);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  uint32_t epoch = 0, trip = 0;
-  for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
-  while (true) {
-    if (__builtin_amdgcn_readfirstlane(m3_ld(&J.cancel)) != 0) break;
-    const uint32_t open = (uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&J.todo)) & ~(uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&J.claimed));
-    if (open == 0u) break;
-    const int s = __builtin_ctz(open);
-    int prev = 0;
-    if (c.lane == 0) prev = m3_or(&J.claimed, 1 << s);
-    prev = __builtin_amdgcn_readfirstlane(prev);
-    if ((prev >> s) & 1) continue;  // the simulate wave was faster
-    const int start = __builtin_amdgcn_readfirstlane(m3_ld(&J.start[s]));
-    bool ovf = false;
-    m3_fill_slot<SC, RING, RING, true>(W, c, s, start, s + 1, epoch, trip, ovf, (M3Work<SC, RING> *)nullptr, nullptr, &J.cancel PHASE_PASS);
-    if (c.lane == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      (void)m3_or(ovf ? &J.gaveup : &J.done, 1 << s);
-    }
-  }
-  if (c.lane == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    m3_st(&J.idle, 1);
-  }
-}
-
 // helper_3D.calc_longest_path + remove_stacked_path_tiles (path-length, n_jump and the overlay of
 // minecraft_3D_maze_prob.get_stats; the caller supplies the region count).
 // air: this lane's plane (lanes < Z).  Results uniform over the wave.  c.over receives the new overlay mask.
 // Slots that are still valid (see SLOT CACHE) are reused; the caller invalidates them for fresh maps.
-// jobs: the pair runner's mailbox (null: no runner), see PLANE-PARALLEL CANDIDATE WALK.
-template <int SC, int RINGH>
+template <int SC>
 __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<M3C<SC>::PW> air, int32_t *st, uint32_t &epoch,
-                                uint32_t &trip, uint32_t &filled, bool &overflow, M3Work<SC, RINGH> *W2, M3Mail *mail,
-                                M3Jobs *jobs PHASE_ARG) {
+                                uint32_t &trip, uint32_t &filled, bool &overflow, M3Work<SC> *W2, M3Mail *mail PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
   const PM<PW> above = pm_down(air), below = pm_up(air);
   const PM<PW> cand = (c.lane >= 1 && c.lane + 1 < c.Z) ? (air & above & ~below) : pm_zero<PW>();
   uint32_t marked = 0;  // z-planes of final_visited_map that are fully set (the fancy-index bug, :531)
   int final_value = 0, n_jump = 0, best_slot = -1;
-  uint32_t mine_mask = 0;
-  bool posted = false;
-  if (jobs != nullptr) {  // every lane looks at its own plane's slot: two or more missing -> the runner takes the others
+#if defined(PCGRL_PHASE_TIMING) && defined(PCGRL_M3_TAIL)
+  {  // start planes whose cached result is missing right now (most of them lie in planes the walk never looks at)
     bool need = false;
-    int mybit = 0;
     if (c.lane >= 1 && c.lane + 1 < c.Z && pm_any(cand)) {
-      mybit = pm_ctz(cand);
-      const uint32_t h0 = *(const uint32_t *)c.hdr(c.lane - 1);  // start | valid << 16
-      need = !((h0 >> 16) != 0u && (int)(h0 & 0xFFFFu) == mybit);
+      const uint32_t h0 = *(const uint32_t *)c.hdr(c.lane - 1);
+      need = !((h0 >> 16) != 0u && (int)(h0 & 0xFFFFu) == pm_ctz(cand));
     }
-    const uint32_t todo = (uint32_t)(M3_BALLOT(need) >> 1);  // plane z -> slot z - 1
-    if (__popc(todo) >= 2) {
-      if (need) jobs->start[c.lane - 1] = mybit;
-      mine_mask = todo & (0u - todo);  // the first missing plane is the simulate wave's own
-      if (c.lane == 0) {
-        jobs->todo = (int32_t)todo;
-        jobs->claimed = (int32_t)mine_mask;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        m3_st(&jobs->go, 1);
-      }
-      posted = true;
-    }
+    _ph[0] += (uint32_t)__popcll(M3_BALLOT(need));
   }
+#endif
   while (true) {
     const bool mine = c.lane < c.Z && pm_any(cand) && !((marked >> c.lane) & 1u);
     const uint64_t b = M3_BALLOT(mine);
@@ -1062,19 +995,7 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
     {
       const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t *)c.hdr(s));  // start | valid << 16
       if (!((h0 >> 16) != 0u && (int)(h0 & 0xFFFFu) == bit)) {
-        bool run_it = true;
-        if (posted && !((mine_mask >> s) & 1u)) {  // a posted slot: take it unless the runner has
-          int prev = 0;
-          if (c.lane == 0) prev = m3_or(&jobs->claimed, 1 << s);
-          prev = __builtin_amdgcn_readfirstlane(prev);
-          if ((prev >> s) & 1) {
-            while ((((uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&jobs->done)) | (uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&jobs->gaveup))) >> s & 1u) == 0u)
-              __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            run_it = (((uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&jobs->done)) >> s) & 1u) == 0u;  // (gave up: this wave's ring is larger)
-          }
-        }
-        if (run_it) m3_fill_slot<SC, M3C<SC>::RING, RINGH>(W, c, s, bit, sz, epoch, trip, overflow, W2, mail, nullptr PHASE_PASS);
+        m3_fill_slot(W, c, s, bit, sz, epoch, trip, overflow, W2, mail PHASE_PASS);
         filled |= 1u << s;
         if (overflow) break;
       }
@@ -1087,7 +1008,6 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
       best_slot = s;
     }
   }
-  if (posted && c.lane == 0) m3_st(&jobs->cancel, 1);  // (the caller waits for the runner to leave before it touches the record's slots)
   M3_MARK(3, 6);  // path searches (incl. the search loops counted in [3])
   if (overflow) return;  // reported by the caller; the overlay and the statistics stay those of the last finished update
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
@@ -1301,34 +1221,21 @@ __device__ inline void m3_copy_batched(uint4 *dst, const uint4 *src, int from, i
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
 // HELP (pcgrl_step): one more wavefront counts the regions while the simulate wave searches and, in size class 0 (HELP_S),
 // runs second searches speculatively, see SPECULATION.  Waves of a step workgroup: 0 simulate, 1 .. NOBS observe, then helper.
-// RUNNER (pcgrl_step, size class 0, small batches): a fourth wavefront fills other missing start planes while the simulate
-// wave searches the first (PLANE-PARALLEL CANDIDATE WALK); the two helper workspaces then hold half-size queue rings so that
-// four workgroups still share a CU's LDS (37 KB each).
-template <int MODE, int SC, int DIM = 0, bool RUNNER = false>
+template <int MODE, int SC, int DIM = 0>
 // (size class 0 step kernel: 129 VGPRs would mean 3 waves per SIMD = 4 workgroups per CU where the LDS allows 5; the
 // second launch bound asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
-__global__ __launch_bounds__(MODE == M3_STEP ? 64 * (2 + m3_observers<SC>() + (RUNNER ? 1 : 0)) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
+__global__ __launch_bounds__(MODE == M3_STEP ? 64 * (2 + m3_observers<SC>()) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
 void m3_kernel(Params p, int cpl) {
-  static_assert(!RUNNER || (MODE == M3_STEP && SC == 0), "the pair runner belongs to the size class 0 step kernel");
   constexpr int PW = M3C<SC>::PW;
   constexpr bool HELP = MODE == M3_STEP, HELP_S = HELP && SC == 0;
-  constexpr int RINGH = RUNNER ? M3C<SC>::RING / 2 : M3C<SC>::RING;  // queue ring of the helper waves' workspaces
   if (MODE == M3_STEP) touch_kernarg(p);  // every line of the argument block in one scalar-memory round trip
   __shared__ M3Env<SC> E;
   __shared__ M3Work<SC> W;
   __shared__ M3Mail mail;
-  M3Work<SC, RINGH> *WH = nullptr;  // the helper wave's workspace
+  M3Work<SC> *WH = nullptr;  // the helper wave's workspace
   if constexpr (HELP_S) {
-    __shared__ M3Work<SC, RINGH> wh_;
+    __shared__ M3Work<SC> wh_;
     WH = &wh_;
-  }
-  M3Work<SC, RINGH> *WB = nullptr;  // the pair runner's
-  M3Jobs *jobs = nullptr;
-  if constexpr (RUNNER) {
-    __shared__ M3Work<SC, RINGH> wb_;
-    __shared__ M3Jobs jobs_;
-    WB = &wb_;
-    jobs = &jobs_;
   }
   __shared__ M3ObsLds<SC> O;
   M3Ctx c;
@@ -1364,31 +1271,13 @@ void m3_kernel(Params p, int cpl) {
       mail.rdone = 0;
       mail.cancel = 0;
       mail.exit = 0;
-      if constexpr (RUNNER) {
-        jobs->go = 0;
-        jobs->todo = 0;
-        jobs->claimed = 0;
-        jobs->done = 0;
-        jobs->gaveup = 0;
-        jobs->cancel = 0;
-        jobs->idle = 0;
-      }
     }
     __syncthreads();  // (the waves of a workgroup start together: nobody waits here)
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1 + m3_observers<SC>()) {
       // ---------------------------------------------------------------------------------------- helper wave
-      if constexpr (HELP_S) m3_helper<SC, true, RINGH>(p, *WH, c, mail PHASE_PASS);
-      else m3_helper<SC, false, M3C<SC>::RING>(p, W, c, mail PHASE_PASS);  // (regions only: W is not touched)
+      m3_helper<SC, HELP_S>(p, HELP_S ? *WH : W, c, mail PHASE_PASS);  // (regions only: W is not touched)
       if (p.obs != nullptr) __syncthreads();  // (the closing barrier of the other two waves)
       return;
-    }
-    if constexpr (RUNNER) {
-      if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 2 + m3_observers<SC>()) {
-        // -------------------------------------------------------------------------------------- pair runner wave
-        m3_pair_runner<SC, RINGH>(*WB, c, *jobs, mail PHASE_PASS);
-        if (p.obs != nullptr) __syncthreads();
-        return;
-      }
     }
   }
   if constexpr (MODE == M3_STEP) {
@@ -1486,7 +1375,7 @@ void m3_kernel(Params p, int cpl) {
     M3_MARK(6, 5);  // column masks + move table
     st[0] = m3_regions<PW>(c, air, notx0, notxl);
     M3_MARK(2, 4);  // regions
-    m3_paths<SC, M3C<SC>::RING>(E, W, c, air, st, epoch, trip, dirty_full, ovf, (M3Work<SC> *)nullptr, nullptr, nullptr PHASE_PASS);
+    m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, nullptr, nullptr PHASE_PASS);
   };
   auto store_record = [&]() {  // the whole record
     for (int i = c.lane; i < c.L.rec_words / 4; i += 64) ((uint4 *)grec)[i] = ((const uint4 *)E.rec)[i];
@@ -1622,20 +1511,6 @@ void m3_kernel(Params p, int cpl) {
       if (need_rest) m3_copy_batched<16>((uint4 *)E.rec, (const uint4 *)grec, s0, s1, c.lane);
     }
     M3_MARK(0, 5);  // loads
-    // the pair runner writes into the record's slots: before this wave rebuilds the tables (auto-reset) or writes the
-    // record back it waits for the runner to have left, and takes over what the runner did to the slots
-    bool runner_seen = false;
-    auto quiesce_runner = [&]() {
-      if constexpr (RUNNER) {
-        if (runner_seen || __builtin_amdgcn_readfirstlane(m3_ld(&jobs->go)) == 0) return;
-        runner_seen = true;
-        while (__builtin_amdgcn_readfirstlane(m3_ld(&jobs->idle)) == 0) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t dn = (uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&jobs->done));
-        dirty_full |= dn;                                                                   // filled: the whole slot is new
-        dirty_hdr |= (uint32_t)__builtin_amdgcn_readfirstlane(m3_ld(&jobs->claimed)) & ~dn;  // given up: its header says invalid
-      }
-    };
     const int K = MODE == M3_ROLLOUT ? p.n_steps : 1;
     const size_t N = (size_t)p.n_envs;
     bool any_reset = false, whole_record = false, edited = false, mv_chg = false, upd_exit = false, over_dirty = false;
@@ -1718,7 +1593,7 @@ void m3_kernel(Params p, int cpl) {
         }
         flags &= ~ENV_STATS_DIRTY;
         M3_MARK(2, 4);  // regions
-        m3_paths<SC, RINGH>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP_S ? &mail : nullptr, jobs PHASE_PASS);
+        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP_S ? &mail : nullptr PHASE_PASS);
         over_dirty = true;
         if constexpr (HELP) {
           while (__builtin_amdgcn_readfirstlane(m3_ld(&mail.rdone)) != rjob) __builtin_amdgcn_s_sleep(1);
@@ -1750,7 +1625,6 @@ void m3_kernel(Params p, int cpl) {
           for (int i = 0; i < NS; i++) p.stats_out[o * NS + i] = st[i];
       }
       if (do_reset) {
-        quiesce_runner();
         if (!any_reset) {
           rp.load(p.rng[env].prob);  // (only this wave writes them, at the end)
           rr.load(p.rng[env].rep);
@@ -1775,7 +1649,6 @@ void m3_kernel(Params p, int cpl) {
     if ((ovf || ovf_any) && c.lane == 0) atomicOr(p.err, 4);
     // ---- write back, once the observe wave has read the old state
     if (HELP && c.lane == 0) m3_st(&mail.exit, 1);
-    quiesce_runner();
     if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();
     if (whole_record) {
       store_record();

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--replays", type=int, default=20)
     ap.add_argument("--warm-replays", type=int, default=4)
     ap.add_argument("--envs", type=int, default=0)
+    ap.add_argument("--mode", default="graph", choices=["graph", "threads"],
+                    help="graph: k parallel branches of one HIP graph; threads: k host threads, each issuing its own engine's launches "
+                         "eagerly (pcgrl_step_seq: one foreign call per chain, the GIL is released) on its own stream")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -61,6 +64,43 @@ def main():
                 for t in range(3):
                     e.step_raw(acts[i][t].data_ptr(), main_s.cuda_stream)
             torch.cuda.synchronize(dev)
+            if args.mode == "threads":
+                import threading, time
+                steps = G * args.replays
+                bar = threading.Barrier(k + 1)
+                strs = [torch.cuda.Stream(dev) for _ in range(k)]
+
+                def chain(i):
+                    torch.cuda.set_device(dev)
+                    e, a, st = envs[i], acts[i], strs[i]
+                    e.step_seq_raw(a.data_ptr(), n, POOL, 0, G, st.cuda_stream)  # warm
+                    st.synchronize()
+                    bar.wait()
+                    rc = e.step_seq_raw(a.data_ptr(), n, POOL, 0, steps, st.cuda_stream)
+                    assert rc == 0, rc
+                    st.synchronize()
+                    bar.wait()
+
+                ths = [threading.Thread(target=chain, args=(i,)) for i in range(k)]
+                for t in ths:
+                    t.start()
+                bar.wait()
+                t0 = time.perf_counter()
+                bar.wait()
+                us = (time.perf_counter() - t0) * 1e6 / steps
+                for t in ths:
+                    t.join()
+                for e in envs:
+                    e.check_errors()
+                row = {"workload": wl, "envs": N, "sub_batches": k, "envs_per_sub_batch": n, "mode": "threads", "steps": steps,
+                       "us_per_step_of_whole_batch": us, "env_steps_per_s": N / (us * 1e-6),
+                       "roofline_frac": bench.ALGO_BYTES[wl] * N / (us * 1e-6) / 1e9 / bench.HBM_PEAK_GBS}
+                rows.append(row)
+                print(json.dumps(row), flush=True)
+                for e in envs:
+                    e.close()
+                torch.cuda.empty_cache()
+                continue
             g = torch.cuda.CUDAGraph()
             cap.wait_stream(main_s)
             with torch.cuda.stream(cap):
