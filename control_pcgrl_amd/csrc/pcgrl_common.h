@@ -133,11 +133,6 @@ struct Params {
   // 3-D: plane bits (y * X + x, up to 256 of them) whose x is not 0 / not X - 1: constants of the map shape, filled in by
   // pcgrl_create (every wave used to rebuild them with Y multi-word range fills: 5 us of a 15^3 step)
   uint64_t m3_notx0[4], m3_notxl[4];
-  // 3-D, two-phase step (pcgrl_kernels3d.h "TWO-PHASE STEP"): m3_phase 0 = one launch does everything; 1 = the light launch
-  // (no search workspace: an env whose step needs a path search -- or an auto-reset -- leaves its state untouched and puts
-  // itself on the work list); 2 = the full kernel over the work list.  m3_work: [0] list length [1] ticket [2..] env ids
-  int32_t *m3_work;
-  int32_t m3_phase;
 };
 
 }  // namespace pcgrl

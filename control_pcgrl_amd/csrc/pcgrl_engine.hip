@@ -44,7 +44,6 @@ struct pcgrl_engine {
   int lpe = 16;
   size_t lds_bytes = 0;
   int cpl = 0;  // 3-D: cells per lane of the reset RNG split
-  bool m3_two_phase = false;  // 3-D: pcgrl_step / pcgrl_update as a light launch + the full kernel over its work list
   int32_t *seen_host = nullptr;  // sokoban: host-mapped counter of device solver runs
   int soko_slots = 0;            // sokoban: workspace slots of the current pool (p.soko)
   int32_t seen_last = 0, spread_left = 0;
@@ -239,18 +238,6 @@ static std::vector<JumpEntry> make_jump_table(int H, int W, int last = -1) {
     t[r] = JumpEntry{A.hi, A.lo, G.hi, G.lo};
   }
   return t;
-}
-
-// 3-D: where the two-phase step pays (pcgrl_kernels3d.h TWO-PHASE STEP).  Size class 1 (the reference's stock 15^3): the
-// one-launch kernel keeps 147 KB of LDS per env = one workgroup per CU, the light kernel 52 KB.  Size class 0 (7^3): at
-// BASELINE's 1024 envs a launch is its slowest env's pair of searches whichever kernel runs it, and the second launch only
-// adds its boundary; at large batches the CUs are full and the light kernel (no search workspace, fewer registers) holds
-// twice the workgroups.
-static bool m3_two_phase_for(int Z, int Y, int X, int n_envs) {
-  static const int force = getenv("PCGRL_M3_TWO_PHASE") ? atoi(getenv("PCGRL_M3_TWO_PHASE")) : -1;  // development: 0 / 1
-  if (force >= 0) return force != 0;
-  if (m3_size_class(Z, Y, X) == 1) return true;
-  return n_envs >= 4096;
 }
 
 // ---------------------------------------------------------------------------------------------- dispatch
@@ -643,9 +630,6 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   if (is3d) {
     // one record per env: tile bits, overlay bits, column masks, cached start-plane results, move table (M3Lay)
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * m3_layout(cfg->dims[0], cfg->dims[1], cfg->dims[2]).rec_words * sizeof(uint32_t)));
-    // work list of the two-phase step: [0] length [1] ticket [2..] env ids (zeroed: empty)
-    CREATE_CHK(dalloc((void **)&p.m3_work, (size_t)(n_envs + 2) * sizeof(int32_t)));
-    e->m3_two_phase = m3_two_phase_for(cfg->dims[0], cfg->dims[1], cfg->dims[2], n_envs);
   } else
     CREATE_CHK(dalloc(&p.planes, (size_t)n_envs * ROW_WORDS * H * (W > 32 ? sizeof(uint64_t) : sizeof(uint32_t))));
   CREATE_CHK(dalloc((void **)&p.st, (size_t)n_envs * sizeof(EnvState)));
@@ -772,7 +756,6 @@ int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uin
   p.reward = d_reward;
   p.done = d_done;
   p.stats_out = d_stats;
-  p.m3_phase = h->m3_two_phase ? 1 : 0;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
@@ -807,7 +790,6 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   p.done = d_done;
   p.stats_out = d_stats;
   p.ctrl_obs = d_ctrl_obs;
-  p.m3_phase = h->m3_two_phase ? 1 : 0;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }
@@ -848,7 +830,6 @@ int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void 
   p.actions = d_actions;
   p.obs = d_obs;
   p.update_only = 1;
-  p.m3_phase = h->m3_two_phase ? 1 : 0;
   h->maybe_stale = true;
   HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;

@@ -1,6 +1,5 @@
 // pcgrl_k_3d.hip -- translation unit: the minecraft_3D_maze kernels (see pcgrl_dispatch.h)
 #define PCGRL_KERNEL_TU
-#include <algorithm>
 #include "pcgrl_dispatch.h"
 #include "pcgrl_kernels3d.h"
 
@@ -27,39 +26,6 @@ hipError_t pcgrl::launch_3d(KernelId id, const Params &p, int cpl, hipStream_t s
   dim3 grid(p.n_envs), block(64);
   const bool d7 = p.cfg.dims[0] == 7 && p.cfg.dims[1] == 7 && p.cfg.dims[2] == 7 && p.cfg.obs_window[0] == 14 &&
                   p.cfg.obs_window[1] == 14 && p.cfg.obs_window[2] == 14;
-  // two-phase step (pcgrl_kernels3d.h TWO-PHASE STEP): the light kernel over every env, then the full kernel over the envs that
-  // put themselves on the work list (searches, auto-resets); pcgrl_update never searches: one light launch
-  if (id == K_STEP && p.m3_phase == 1 && p.m3_work != nullptr) {
-    const int sc = m3_size_class(p.cfg.dims[0], p.cfg.dims[1], p.cfg.dims[2]);
-    const bool d15_ = p.cfg.dims[0] == 15 && p.cfg.dims[1] == 15 && p.cfg.dims[2] == 15 && p.cfg.obs_window[0] == 30 &&
-                      p.cfg.obs_window[1] == 30 && p.cfg.obs_window[2] == 30;
-    Params q = p;
-    q.m3_phase = 2;
-    q.obs = nullptr;  // (the light launch's observe waves have written every env's observation)
-    // the second launch: one CU-load of workgroups that walk the work list (5 per CU at size class 0's 28-30 KB of LDS, 1 at
-    // size class 1's 143-152 KB)
-    static int n_cus = 0;
-    if (n_cus == 0) {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-      n_cus = v;
-    }
-    const dim3 grid2((unsigned)std::min(p.n_envs, n_cus * (sc == 0 ? 5 : 1)));
-    if (d7) {
-      hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7, true>), grid, dim3(192), 0, s, p, cpl);
-      if (!p.update_only) hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7>), grid2, dim3(192), 0, s, q, cpl);
-    } else if (d15_) {
-      hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 15, true>), grid, dim3(64 * (2 + m3_observers<1>())), 0, s, p, cpl);
-      if (!p.update_only) hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 15>), grid2, dim3(64 * (2 + m3_observers<1>())), 0, s, q, cpl);
-    } else if (sc == 0) {
-      hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 0, true>), grid, dim3(192), 0, s, p, cpl);
-      if (!p.update_only) hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 0>), grid2, dim3(192), 0, s, q, cpl);
-    } else {
-      hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 0, true>), grid, dim3(64 * (2 + m3_observers<1>())), 0, s, p, cpl);
-      if (!p.update_only) hipLaunchKernelGGL((m3_kernel<M3_STEP, 1, 0>), grid2, dim3(64 * (2 + m3_observers<1>())), 0, s, q, cpl);
-    }
-    return hipGetLastError();
-  }
   if (d7 && id == K_STEP) {
     hipLaunchKernelGGL((m3_kernel<M3_STEP, 0, 7>), grid, dim3(192), 0, s, p, cpl);
     return hipGetLastError();

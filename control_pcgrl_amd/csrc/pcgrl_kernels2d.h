@@ -576,15 +576,14 @@ struct ProbTraits<PCGRL_PROB_MC3DMAZE> {
 __device__ __attribute__((always_inline)) inline void touch_kernarg(const Params &p) {
   const int32_t *kw = (const int32_t *)&p;
   constexpr int L = (int)((sizeof(Params) + 63) / 64);
-  static_assert(L <= 16, "touch_kernarg: one operand per 64-byte line");
+  static_assert(L <= 14, "touch_kernarg: one operand per 64-byte line");
   asm volatile("" ::"s"(kw[0]), "s"(kw[16 < sizeof(Params) / 4 ? 16 : 0]), "s"(kw[32 < sizeof(Params) / 4 ? 32 : 0]),
                "s"(kw[48 < sizeof(Params) / 4 ? 48 : 0]), "s"(kw[64 < sizeof(Params) / 4 ? 64 : 0]),
                "s"(kw[80 < sizeof(Params) / 4 ? 80 : 0]), "s"(kw[96 < sizeof(Params) / 4 ? 96 : 0]),
                "s"(kw[112 < sizeof(Params) / 4 ? 112 : 0]), "s"(kw[128 < sizeof(Params) / 4 ? 128 : 0]),
                "s"(kw[144 < sizeof(Params) / 4 ? 144 : 0]), "s"(kw[160 < sizeof(Params) / 4 ? 160 : 0]),
                "s"(kw[176 < sizeof(Params) / 4 ? 176 : 0]), "s"(kw[192 < sizeof(Params) / 4 ? 192 : 0]),
-               "s"(kw[208 < sizeof(Params) / 4 ? 208 : 0]), "s"(kw[224 < sizeof(Params) / 4 ? 224 : 0]),
-               "s"(kw[240 < sizeof(Params) / 4 ? 240 : 0]));
+               "s"(kw[208 < sizeof(Params) / 4 ? 208 : 0]));
 }
 
 template <int LPE, typename M, bool HUGE>

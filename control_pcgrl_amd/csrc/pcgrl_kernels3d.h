@@ -82,7 +82,7 @@ __host__ __device__ inline bool m3_supported(int Z, int Y, int X) {
   return Z >= 1 && Y >= 1 && X >= 1 && Z <= 16 && Y <= 16 && X <= 16 && Y * X <= 256 && Z * Y * X <= 4096;
 }
 // words of one per-cell bit string of an env in HBM (even, so that 64-bit accesses stay aligned)
-__host__ __device__ constexpr int m3_words(int n_cells) { return (((n_cells + 31) >> 5) + 1) & ~1; }
+__host__ __device__ inline int m3_words(int n_cells) { return (((n_cells + 31) >> 5) + 1) & ~1; }
 // One env = one contiguous record of 32-bit words in HBM (Params::planes), mirrored word for word in LDS, so a step reads
 // it with a handful of 16-byte loads issued together:
 //   [0, nw)            tile bits (1 = DIRT), flat cell index (z*Y + y)*X + x
@@ -93,8 +93,8 @@ __host__ __device__ constexpr int m3_words(int n_cells) { return (((n_cells + 31
 struct M3Lay {
   int nw, n_slots, slot_words, o_over, o_col, o_slots, o_mv, rec_words;
 };
-__host__ __device__ constexpr M3Lay m3_layout(int Z, int Y, int X) {
-  M3Lay L{};
+__host__ __device__ inline M3Lay m3_layout(int Z, int Y, int X) {
+  M3Lay L;
   const int n_cells = Z * Y * X;
   L.nw = m3_words(n_cells);
   L.n_slots = Z > 2 ? Z - 2 : 0;  // start planes z = 1 .. Z-2
@@ -245,12 +245,10 @@ struct M3Work {
   uint16_t order[M3C<SC>::CELLS];   // cells in first-insertion order
   uint32_t racc[M3C<SC>::NW];       // accepted cells of the pair of searches being run (bit per cell)
 };
-// the env: its record (M3Lay); DIM: a cubic map of compile-time size holds exactly its own record (39.5 KB instead of the
-// size class's 48.9 KB at 15^3: what lets three workgroups of the light step kernel share a CU)
-template <int SC, int DIM = 0>
+// the env: its record (M3Lay)
+template <int SC>
 struct M3Env {
-  static constexpr int WORDS = DIM ? m3_layout(DIM ? DIM : 1, DIM ? DIM : 1, DIM ? DIM : 1).rec_words : M3C<SC>::REC;
-  alignas(16) uint32_t rec[WORDS + 4];
+  alignas(16) uint32_t rec[M3C<SC>::REC + 4];
 };
 // observe wavefronts of a pcgrl_step workgroup.  Size class 1 keeps 147 KB of LDS per env, i.e. ONE workgroup per CU, and
 // its observation is 108 KB at 15^3: four waves share it, a contiguous quarter each (16.7 us per env on one wave).
@@ -968,12 +966,9 @@ __device__ inline void m3_fill_slot(M3Work<SC> &W, const M3Ctx &c, int s, int st
 // minecraft_3D_maze_prob.get_stats; the caller supplies the region count).
 // air: this lane's plane (lanes < Z).  Results uniform over the wave.  c.over receives the new overlay mask.
 // Slots that are still valid (see SLOT CACHE) are reused; the caller invalidates them for fresh maps.
-// LITE (the light launch of the two-phase step): the wave has no search workspace; the first start plane whose result is
-// missing ends the walk with `needs_search` set and nothing written.
-template <int SC, bool LITE = false>
-__device__ inline void m3_paths(M3Work<SC> *Wp, const M3Ctx &c, PM<M3C<SC>::PW> air, int32_t *st, uint32_t &epoch,
-                                uint32_t &trip, uint32_t &filled, bool &overflow, M3Work<SC> *W2, M3Mail *mail,
-                                bool &needs_search PHASE_ARG) {
+template <int SC>
+__device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<M3C<SC>::PW> air, int32_t *st, uint32_t &epoch,
+                                uint32_t &trip, uint32_t &filled, bool &overflow, M3Work<SC> *W2, M3Mail *mail PHASE_ARG) {
   constexpr int PW = M3C<SC>::PW;
   // start candidates per plane: AIR with head-room, standing on something, z >= 1 (:520-526)
   const PM<PW> above = pm_down(air), below = pm_up(air);
@@ -1000,14 +995,9 @@ __device__ inline void m3_paths(M3Work<SC> *Wp, const M3Ctx &c, PM<M3C<SC>::PW> 
     {
       const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t *)c.hdr(s));  // start | valid << 16
       if (!((h0 >> 16) != 0u && (int)(h0 & 0xFFFFu) == bit)) {
-        if constexpr (LITE) {
-          needs_search = true;
-          break;
-        } else {
-          m3_fill_slot(*Wp, c, s, bit, sz, epoch, trip, overflow, W2, mail PHASE_PASS);
-          filled |= 1u << s;
-          if (overflow) break;
-        }
+        m3_fill_slot(W, c, s, bit, sz, epoch, trip, overflow, W2, mail PHASE_PASS);
+        filled |= 1u << s;
+        if (overflow) break;
       }
     }
     const uint32_t h1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t *)c.hdr(s))[1]);  // max_dist | n_jump << 16
@@ -1019,7 +1009,6 @@ __device__ inline void m3_paths(M3Work<SC> *Wp, const M3Ctx &c, PM<M3C<SC>::PW> 
     }
   }
   M3_MARK(3, 6);  // path searches (incl. the search loops counted in [3])
-  if (LITE && needs_search) return;  // (nothing has been written: the full kernel redoes this env's step)
   if (overflow) return;  // reported by the caller; the overlay and the statistics stay those of the last finished update
   // remove_stacked_path_tiles (:657-675) then the transposed overlay of process_observation (:84-93):
   // path tile (x,y,z) is drawn at array index [x][y][z]
@@ -1232,33 +1221,16 @@ __device__ inline void m3_copy_batched(uint4 *dst, const uint4 *src, int from, i
 // and the observation encoder are instruction-bound: constant strides and bounds take instructions away)
 // HELP (pcgrl_step): one more wavefront counts the regions while the simulate wave searches and, in size class 0 (HELP_S),
 // runs second searches speculatively, see SPECULATION.  Waves of a step workgroup: 0 simulate, 1 .. NOBS observe, then helper.
-//
-// TWO-PHASE STEP (Params::m3_phase; chosen by the host where a CU could hold more workgroups than the search workspace lets it:
-// size class 1 -- 147 KB of LDS, ONE workgroup per CU -- and large batches of size class 0).  Under random or trained edits
-// few steps need a path search (a cached start plane dropped, a new start cell) or an auto-reset: ~8 % at 7^3.  LITE is the
-// step kernel WITHOUT the search workspace (52 KB at 15^3: three workgroups per CU) and without the search code's registers:
-// it does everything for the envs that need no search, and an env that turns out to need one -- or whose episode ends --
-// writes NOTHING of its state or outputs (the observation apart: it does not depend on this step's statistics) and appends
-// itself to a work list.  The second launch is the full kernel over that list (phase 2: workgroup b takes env work[2 + b],
-// workgroups beyond the list leave at once; no observe work: the light launch has written the observations), which redoes
-// those envs' steps from the untouched state: results are those of the one-launch step by construction.
-template <int MODE, int SC, int DIM = 0, bool LITE = false>
+template <int MODE, int SC, int DIM = 0>
 // (size class 0 step kernel: 129 VGPRs would mean 3 waves per SIMD = 4 workgroups per CU where the LDS allows 5; the
-// second launch bound asks for 4 waves per SIMD, i.e. <= 128 VGPRs; the light size class 1 kernel: three workgroups of six
-// waves per CU = 5 waves per SIMD, <= 96 VGPRs)
-__global__ __launch_bounds__(MODE == M3_STEP ? 64 * (2 + m3_observers<SC>()) : 64,
-                             (MODE == M3_STEP && SC == 0) ? (LITE ? 6 : 4) : ((MODE == M3_STEP && LITE) ? 3 : 1))
+// second launch bound asks for 4 waves per SIMD, i.e. <= 128 VGPRs)
+__global__ __launch_bounds__(MODE == M3_STEP ? 64 * (2 + m3_observers<SC>()) : 64, (MODE == M3_STEP && SC == 0) ? 4 : 1)
 void m3_kernel(Params p, int cpl) {
-  static_assert(!LITE || MODE == M3_STEP, "the light kernel is a step kernel");
   constexpr int PW = M3C<SC>::PW;
-  constexpr bool HELP = MODE == M3_STEP, HELP_S = HELP && SC == 0 && !LITE;
+  constexpr bool HELP = MODE == M3_STEP, HELP_S = HELP && SC == 0;
   if (MODE == M3_STEP) touch_kernarg(p);  // every line of the argument block in one scalar-memory round trip
-  __shared__ M3Env<SC, DIM> E;
-  M3Work<SC> *Wp = nullptr;  // this wave's search workspace (none in the light kernel)
-  if constexpr (!LITE) {
-    __shared__ M3Work<SC> w_;
-    Wp = &w_;
-  }
+  __shared__ M3Env<SC> E;
+  __shared__ M3Work<SC> W;
   __shared__ M3Mail mail;
   M3Work<SC> *WH = nullptr;  // the helper wave's workspace
   if constexpr (HELP_S) {
@@ -1284,11 +1256,10 @@ void m3_kernel(Params p, int cpl) {
   c.slots = E.rec + c.L.o_slots;
   c.mv = (int16_t *)(E.rec + c.L.o_mv);
   const int nw = c.L.nw, n_slots = c.L.n_slots;
+  const int env = blockIdx.x;
   constexpr int NS = M3_NS;
   PHASE_DECL();
   TRACE_DECL();
-  // one env's step (or reset, observation ...): the whole kernel for every mode but the full step kernel over a work list
-  auto run_env = [&](const int env) {
   uint32_t *grec = (uint32_t *)p.planes + (size_t)env * c.L.rec_words;
   EnvState *S = &p.st[env];
 
@@ -1304,8 +1275,7 @@ void m3_kernel(Params p, int cpl) {
     __syncthreads();  // (the waves of a workgroup start together: nobody waits here)
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1 + m3_observers<SC>()) {
       // ---------------------------------------------------------------------------------------- helper wave
-      if constexpr (HELP_S) m3_helper<SC, true>(p, *WH, c, mail PHASE_PASS);
-      else m3_helper<SC, false>(p, *(M3Work<SC> *)nullptr, c, mail PHASE_PASS);  // (regions only: no workspace is touched)
+      m3_helper<SC, HELP_S>(p, HELP_S ? *WH : W, c, mail PHASE_PASS);  // (regions only: W is not touched)
       if (p.obs != nullptr) __syncthreads();  // (the closing barrier of the other two waves)
       return;
     }
@@ -1381,7 +1351,7 @@ void m3_kernel(Params p, int cpl) {
     // reset()/observe(): no path overlay (PcgrlEnv.reset does not call process_observation)
     for (int i = c.lane; i < 2 * nw; i += 64) E.rec[i] = grec[i];
     const int pos[3] = {S->pos[0], S->pos[1], S->pos[2]};
-    m3_encode_obs<false>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)Wp->info, M3C<SC>::CELLS / 2);
+    m3_encode_obs<false>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2);
     return;
   }
 
@@ -1389,8 +1359,7 @@ void m3_kernel(Params p, int cpl) {
   uint32_t epoch = 0, trip = 0;
   uint32_t dirty_hdr = 0, dirty_full = 0;  // slots whose header / whose whole record differs from the copy in HBM
   auto init_work = [&]() {
-    if constexpr (!LITE)
-      for (int i = c.lane; i < c.n_cells; i += 64) Wp->best[i] = make_uint2(0u, 0xFFFFFFFFu);
+    for (int i = c.lane; i < c.n_cells; i += 64) W.best[i] = make_uint2(0u, 0xFFFFFFFFu);
   };
   PM<PW> notx0, notxl;
   m3_edge_masks<PW>(p, notx0, notxl);
@@ -1406,8 +1375,7 @@ void m3_kernel(Params p, int cpl) {
     M3_MARK(6, 5);  // column masks + move table
     st[0] = m3_regions<PW>(c, air, notx0, notxl);
     M3_MARK(2, 4);  // regions
-    bool unused = false;
-    m3_paths<SC>(Wp, c, air, st, epoch, trip, dirty_full, ovf, nullptr, nullptr, unused PHASE_PASS);
+    m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, nullptr, nullptr PHASE_PASS);
   };
   auto store_record = [&]() {  // the whole record
     for (int i = c.lane; i < c.L.rec_words / 4; i += 64) ((uint4 *)grec)[i] = ((const uint4 *)E.rec)[i];
@@ -1547,7 +1515,6 @@ void m3_kernel(Params p, int cpl) {
     const size_t N = (size_t)p.n_envs;
     bool any_reset = false, whole_record = false, edited = false, mv_chg = false, upd_exit = false, over_dirty = false;
     bool ovf_any = false;
-    bool deferred = false;  // light launch: this env's step is left to the full kernel (nothing is written back)
     int mv_cell = 0, col_word = 0;
     for (int k = 0; k < K; k++) {
       const size_t o = (size_t)k * N + (size_t)env;  // index of this step's outputs
@@ -1593,16 +1560,10 @@ void m3_kernel(Params p, int cpl) {
       bool done = iteration > p.cfg.max_iterations;
       if (p.cfg.max_changes >= 0) done = done || changes > p.cfg.max_changes;
       const bool do_reset = done && p.auto_reset != 0;
-      if constexpr (LITE) {
-        if (do_reset) {  // the new episode's tables need every search: the full kernel's
-          deferred = true;
-          break;
-        }
-      }
       // the observation is assembled BEFORE the stats refresh (pcgrl_env.py:298-299 vs :314-323): it shows the path of
       // the previous stats update on the already edited map
       M3_MARK(1, 5);  // action + move-table update
-      if (!do_reset && want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, true, (uint2 *)Wp->info, M3C<SC>::CELLS / 2, obs_k);
+      if (!do_reset && want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, true, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       M3_MARK(1, 5);  // observation (rollout mode)
       if (change) {
         const PM<PW> air = plane_of(c.dirt);
@@ -1632,15 +1593,12 @@ void m3_kernel(Params p, int cpl) {
         }
         flags &= ~ENV_STATS_DIRTY;
         M3_MARK(2, 4);  // regions
-        m3_paths<SC, LITE>(Wp, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP_S ? &mail : nullptr, deferred PHASE_PASS);
+        m3_paths<SC>(E, W, c, air, st, epoch, trip, dirty_full, ovf, WH, HELP_S ? &mail : nullptr PHASE_PASS);
         over_dirty = true;
         if constexpr (HELP) {
           while (__builtin_amdgcn_readfirstlane(m3_ld(&mail.rdone)) != rjob) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           st[0] = __builtin_amdgcn_readfirstlane(m3_ld(&mail.r_out));
-        }
-        if constexpr (LITE) {
-          if (deferred) break;  // (after the helper's region job: nothing of this env is in flight any more)
         }
         if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
           for (int i = 0; i < NS; i++) st[i] = st_old[i];
@@ -1685,23 +1643,13 @@ void m3_kernel(Params p, int cpl) {
         ep_return = 0.0;
         trg.load(p, env, true);
         last_loss = trg.loss(p.cfg, st);
-        if (want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)Wp->info, M3C<SC>::CELLS / 2, obs_k);
+        if (want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       }
     }
     if ((ovf || ovf_any) && c.lane == 0) atomicOr(p.err, 4);
     // ---- write back, once the observe wave has read the old state
     if (HELP && c.lane == 0) m3_st(&mail.exit, 1);
     if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();
-    if constexpr (LITE) {
-      if (deferred) {  // onto the work list; the env's record, state and outputs are as the step found them
-        if (c.lane == 0) {
-          const int at = atomicAdd(&p.m3_work[0], 1);
-          p.m3_work[2 + at] = env;
-        }
-        PHASE_FLUSH();
-        return;
-      }
-    }
     if (whole_record) {
       store_record();
     } else {
@@ -1746,27 +1694,6 @@ void m3_kernel(Params p, int cpl) {
     TRACE_DRAIN();
     TRACE_PUT(2, TRACE_NOW());
   }
-  };  // run_env
-  if constexpr (MODE == M3_STEP && !LITE) {
-    if (p.m3_phase == 2) {
-      // The full kernel over the light launch's work list: a fixed grid of workgroups (one CU-load of them: launching one per
-      // env of the batch costs ~18 ns per workgroup that finds nothing to do -- 19 us at 1024 envs, 0.7 ms at 16 384), workgroup
-      // b takes entries b, b + gridDim.x, ...  Every wave reads the list length before the barrier; the last workgroup past it
-      // empties the list for the next step's light launch.
-      const int listed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&p.m3_work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      __syncthreads();
-      if (threadIdx.x == 0 && atomicAdd((unsigned int *)&p.m3_work[1], 1u) == gridDim.x - 1u) {
-        __hip_atomic_store(&p.m3_work[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.m3_work[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      for (int it = blockIdx.x; it < listed; it += gridDim.x) {
-        run_env(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&p.m3_work[2 + it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        __syncthreads();  // every wave is done with the mailbox and the env's tables before the next entry
-      }
-      return;
-    }
-  }
-  run_env((int)blockIdx.x);
 }
 
 }  // namespace pcgrl
