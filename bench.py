@@ -596,11 +596,19 @@ def main():
     # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-reduce of the episode sums
     # cannot complete on any rank before every rank has contributed, i.e. finished its K launches; one collective instead
     # of an all-reduce followed by a barrier.  Ends with the device synchronised.
-    reduce_episodes(ev2, launched=fuse_reduce)
+    if fuse_reduce and not use_coll:
+        # the whole region was that one graph (K launches + the reduction, which wrote pinned host memory): ev1 is its end.
+        # (Every further event record is a marker packet the command processor works through one after the other: three of
+        # them behind a 170 us region cost ~5 % of it.)
+        ev1.synchronize()
+        torch.cuda.synchronize(dev)
+        ev2 = None
+    else:
+        reduce_episodes(ev2, launched=fuse_reduce)
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
     # the exchange on this rank's stream: reduction launch + (N > 1) the all-reduce, which also waits for the slowest rank
-    exchange_ms = ev1.elapsed_time(ev2) if ev2.query() else float("nan")
+    exchange_ms = 0.0 if ev2 is None else (ev1.elapsed_time(ev2) if ev2.query() else float("nan"))
     env.check_errors()
     elapsed, per_rank_elapsed = max_over_ranks(elapsed)
     _, per_rank_eps = max_over_ranks(float(local_eps.item()))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # every bench line behind profiles/<tag>_bench_lines.json (collected by tools/finish_round.py).  On the GPU box, from the
 # repo root:  bash tools/bench_all.sh r4 [base|stock|sweep|all]
-T=${1:-r4}
+T=${1:-r5}
 WHAT=${2:-all}
 O=gpurun_out
 mkdir -p $O
@@ -14,6 +14,11 @@ if [ "$WHAT" = "base" ] || [ "$WHAT" = "all" ]; then
   python bench.py --envs 65536 --no-cpu-baseline > $O/bench_${T}_binary-narrow-65536.log 2>&1
   python bench.py --graph-steps 0 --no-cpu-baseline > $O/bench_${T}_binary-narrow-eager.log 2>&1
   python bench.py --steps 20 --warmup 5 > $O/bench_${T}_driver_20_5.log 2>&1
+  # the driver's command line through the N > 1 exchange (a world-size-1 RCCL group), and the older short-run protocols
+  python bench.py --steps 20 --warmup 5 --force-collective --no-cpu-baseline --rllib-adapter 0 > $O/bench_${T}_driver_20_5_nccl1.log 2>&1
+  python bench.py --steps 20 --warmup 5 --short-protocol gcd --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_gcd.log 2>&1
+  python bench.py --steps 20 --warmup 5 --short-protocol one --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_one.log 2>&1
+  python bench.py --steps 20 --warmup 5 --graph-steps 0 --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_eager.log 2>&1
   python tools/write_ceiling.py > $O/write_ceiling.json 2>/dev/null
   python tools/solver_bench.py > $O/solver_bench.log 2>&1
 fi
@@ -25,7 +30,7 @@ if [ "$WHAT" = "stock" ] || [ "$WHAT" = "all" ]; then
 fi
 if [ "$WHAT" = "sweep" ] || [ "$WHAT" = "all" ]; then
   # saturation sweeps: envs x4, x16 of the BASELINE batch
-  for WE in zelda-turtle:16384 zelda-turtle:65536 sokoban-wide:8192 sokoban-wide:32768 minecraft_3D_maze-narrow:4096 minecraft_3D_maze-narrow:16384; do
+  for WE in binary-narrow:16384 zelda-turtle:16384 zelda-turtle:65536 sokoban-wide:8192 sokoban-wide:32768 minecraft_3D_maze-narrow:4096 minecraft_3D_maze-narrow:16384; do
     W=${WE%%:*}; E=${WE##*:}
     python bench.py --workload $W --envs $E --steps 4000 --warmup 400 --no-cpu-baseline > $O/bench_${T}_$W-$E.log 2>&1
   done

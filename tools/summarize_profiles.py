@@ -37,9 +37,40 @@ def is_m3_step(name):
     return "m3_kernel<0" in name or "m3_kernel<(pcgrl::M3Mode)0" in name  # (<0, SC>, <0, 0, true>: the 7x7x7 variant)
 
 
-def summarize(w, stats_rows):
+def parse_entry(ent):
+    """'workload[@envs][+rollout]' (tools/profile_all.sh) -> (workload, envs, rollout?)"""
+    ro = ent.endswith("+rollout")
+    we = ent[:-len("+rollout")] if ro else ent
+    w, _, e = we.partition("@")
+    return w, (int(e) if e else ENVS.get(w, 0)), ro
+
+
+def compiler_resources():
+    """kernel name (as tools/kernel_resources.py prints it) -> the code object's own figures; rocprofv3's trace columns give
+    the architectural VGPRs and the STATIC LDS only"""
+    res = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_resources.txt"))):
+        for line in open(f):
+            t = line.split()
+            if len(t) >= 8 and t[1].isdigit():
+                res[" ".join(t[7:])] = {"vgpr": int(t[1]), "agpr": int(t[2]), "sgpr": int(t[3]), "static_lds_bytes": int(t[4]),
+                                        "scratch_bytes": int(t[5]), "source": os.path.basename(f)}
+    return res
+
+
+def launch_class(r):
+    return (int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0))
+
+
+def summarize(ent, stats_rows, resources):
     out = {}
-    dom = "m3_kernel" if "3D" in w else "stats_for_grids_kernel" if "stats-for-grids" in w else "step_kernel"
+    w0, n_envs, rollout = parse_entry(ent)
+    w = ent
+    dom = ("rollout_kernel" if rollout and "3D" not in w0 else "m3_kernel" if "3D" in w0
+           else "stats_for_grids_kernel" if "stats-for-grids" in w0 else "step_kernel")
+    is_dom = (lambda name: dom in name and ((("m3_kernel<5" in name or "M3Mode)5" in name) if rollout else is_m3_step(name)) or dom != "m3_kernel"))
+    cls = None
+    out["entry"] = {"workload": w0, "envs": n_envs, "kernel_profiled": "open-loop rollout (pcgrl_rollout, 64 steps per launch)" if rollout else "step"}
     ks = first(f"prof_{w}_kt/**/*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
@@ -51,8 +82,15 @@ def summarize(w, stats_rows):
                                 "pct": float(r["Percentage"])} for r in keep]
     kt = first(f"prof_{w}_kt/**/*kernel_trace.csv")
     if kt:
-        rows = [r for r in csv.DictReader(open(kt)) if dom in r["Kernel_Name"]
-                and (is_m3_step(r["Kernel_Name"]) or dom != "m3_kernel")]
+        rows = [r for r in csv.DictReader(open(kt)) if is_dom(r["Kernel_Name"])]
+        # one launch class: sokoban launches a workgroup per env ("spread") while its solver is busy, a different kernel
+        # geometry with different counters -- durations, geometry and PMC below all describe the most frequent class
+        classes = defaultdict(int)
+        for r in rows:
+            classes[launch_class(r)] += 1
+        cls = max(classes, key=classes.get) if classes else None
+        out["launch_classes"] = {f"grid {g} x workgroup {wg}": n for (g, wg), n in sorted(classes.items())}
+        rows = [r for r in rows if launch_class(r) == cls]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))  # (the trace is not always written in time order)
         if len(rows) > 2:
             gaps = [int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1)]
@@ -71,6 +109,12 @@ def summarize(w, stats_rows):
                 "median_gap_between_launches_ns": statistics.median(gaps),
                 "duration_ns": {"p10": q(0.1), "median": q(0.5), "p90": q(0.9), "p99": q(0.99), "mean": statistics.mean(durs)},
                 "median_start_to_start_ns": statistics.median(periods)}
+            # the compiler's own figures for this kernel (template arguments as c++filt prints them)
+            full = r0["Kernel_Name"].split("(pcgrl::Params")[0].replace("void ", "").strip()
+            comp = resources.get(full)
+            if comp:
+                out["dominant_kernel_launch"]["compiler"] = comp
+                out["dominant_kernel_launch"]["dynamic_lds_bytes"] = max(0, int(r0.get("LDS_Block_Size", 0) or 0) - comp["static_lds_bytes"]) or None
     counters = defaultdict(dict)
     for d in ("fetch", "write", "sq", "sq2"):
         f = first(f"prof_{w}_{d}/**/*counter_collection.csv")
@@ -79,12 +123,14 @@ def summarize(w, stats_rows):
         agg = defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "pcgrl" in r["Kernel_Name"]:
+                if is_dom(r["Kernel_Name"]) and cls is not None and launch_class(r) != (0, 0) and launch_class(r) != cls:
+                    continue  # (another launch class of the dominant kernel: not the one whose durations are reported)
                 agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             counters[k][c] = {"mean_per_launch": statistics.mean(v), "launches": len(v)}
     out["pmc"] = counters
-    step = next((k for k in counters if dom in k and (is_m3_step(k) or dom != "m3_kernel")), None)
-    n = ENVS.get(w, 0)
+    step = next((k for k in counters if is_dom(k)), None)
+    n = n_envs
     if step:
         c = counters[step]
         if "WRITE_SIZE" in c:
@@ -93,7 +139,7 @@ def summarize(w, stats_rows):
             # step kernel's store pattern): factor 1.00.
             wr = c["WRITE_SIZE"]["mean_per_launch"] * 1024
             rd = c.get("FETCH_SIZE", {"mean_per_launch": 0})["mean_per_launch"] * 1024
-            algo = int(bench.ALGO_BYTES[w] * n)
+            algo = int(bench.ALGO_BYTES[w0] * n) * (64 if rollout else 1)  # (a rollout launch = 64 steps, every observation written)
             out["hbm_traffic_per_launch"] = {"write_bytes": wr, "fetch_bytes_raw": rd, "fetch_bytes_x2_correction": 2 * rd,
                                              "traffic_bytes": wr + 2 * rd, "algorithmic_bytes": algo,
                                              "traffic_over_algorithmic": (wr + 2 * rd) / algo}
@@ -114,12 +160,14 @@ def main(tag, outdir=None):
     out = {"tag": tag, "source": "rocprofv3 on python3 bench.py --workload W (BASELINE.json batch sizes, 1 MI355X); tools/profile_all.sh",
            "workloads": {}, "hbm_traffic_per_launch_by_workload": {}}
     stats_rows = []
+    resources = compiler_resources()
     for d in sorted(glob.glob(os.path.join(G, "prof_*_kt"))):
-        w = os.path.basename(d)[5:-3]
-        s = summarize(w, stats_rows)
-        out["workloads"][w] = s
-        if "hbm_traffic_per_launch" in s:
-            out["hbm_traffic_per_launch_by_workload"][f"{w}@{ENVS.get(w, 0)}"] = s["hbm_traffic_per_launch"]
+        ent = os.path.basename(d)[5:-3]
+        s = summarize(ent, stats_rows, resources)
+        out["workloads"][ent] = s
+        w0, n_envs, rollout = parse_entry(ent)
+        if "hbm_traffic_per_launch" in s and not rollout:
+            out["hbm_traffic_per_launch_by_workload"][f"{w0}@{n_envs}"] = s["hbm_traffic_per_launch"]
     if stats_rows:
         with open(os.path.join(outdir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w_ = csv.DictWriter(f, fieldnames=["Workload"] + [k for k in stats_rows[0].keys() if k != "Workload"])
