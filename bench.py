@@ -484,6 +484,12 @@ def main():
             return None
         Gc = min(125, Kc)
         act_buf = torch.empty((N, env.action_entries), dtype=torch.int32, device=dev)
+        # (sokoban: how a step is launched while the device solver has recently been seen running -- a workgroup per env plus
+        # helper waves, for the next 16 launches -- is a host decision a capture freezes; let it lapse before capturing)
+        for _ in range(24):
+            env._L.pcgrl_sample_actions(env._h, act_buf.data_ptr(), 1234 + rank, sptr)
+            step_raw(act_buf.data_ptr(), sptr)
+        torch.cuda.synchronize(dev)
         try:
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream(dev)

@@ -81,7 +81,7 @@ NOTES = {
     "zelda_bigger-turtle": "`zelda_bigger` (64², window 128²; `zelda_bigger.yaml:5-6`): 621 MB of observations per launch, 64-bit row masks, chunks from tile codes",
     "minecraft_3D_maze-narrow-15": "the reference's stock 3-D map (`configs/config.py:153-157`), two whole episodes: one workgroup per CU (147 KB of LDS), three observe waves",
 }
-rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac (wall / kernel mean) | same-size fill µs (step ÷ fill) | rollout µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|---|"]
+rows = ["| workload | envs/GPU | env-steps/s | µs per step (wall) | kernel mean / median µs (rocprofv3) | roofline frac (wall / kernel mean) | same-size fill µs (step ÷ fill) | rollout µs/step | closed loop µs/step | CPU oracle steps/s (threads) | note |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle",
           "zelda_bigger-turtle", "minecraft_3D_maze-narrow-15", "zelda-turtle-bfs", "binary-narrow-static", "binary-narrow-patch3x3", "sokoban-wide-solver"):
     if w not in lines:
@@ -94,9 +94,14 @@ for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-na
     kf = (l['roofline']['algorithmic_bytes_per_launch'] / (k['mean'] * 1e-9) / 8e12) if k else None
     rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {ks} | {l['roofline']['frac']:.3f}" + (f" / {kf:.3f}" if kf else "") + " | "
                 + (f"{l['roofline']['fill_same_bytes']['us']:.2f} ({l['roofline']['fill_same_bytes']['step_over_fill']:.2f} ×)" if l['roofline'].get('fill_same_bytes') else "–") + " | "
-                + (f"{ro['us_per_step']:.2f}" if ro else "–") + " | " + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + f" | {NOTES.get(w, '')} |")
+                + (f"{ro['us_per_step']:.2f}" if ro else "–") + " | "
+                + (f"{l['closed_loop_device_actions']['us_per_step']:.2f}" if (l.get('closed_loop_device_actions') or {}).get('us_per_step') else "–") + " | "
+                + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + f" | {NOTES.get(w, '')} |")
 extra = []
-for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle", "minecraft_3D_maze-narrow-15"):
+for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle", "zelda_bigger-turtle",
+          "minecraft_3D_maze-narrow-15", "binary-narrow-static", "binary-narrow-patch3x3", "zelda-turtle-bfs", "binary-narrow-evo", "binary-stats-for-grids",
+          "zelda-stats-for-grids", "binary-narrow+rollout", "binary-narrow@16384", "binary-narrow@65536", "zelda-turtle@16384", "zelda-turtle@65536",
+          "sokoban-wide@8192", "sokoban-wide@32768", "minecraft_3D_maze-narrow@4096", "minecraft_3D_maze-narrow@16384"):
     s_ = summ["workloads"].get(w, {})
     if "hbm_traffic_per_launch" in s_ and "lds" in s_:
         extra.append(f"{w}: traffic {s_['hbm_traffic_per_launch']['traffic_bytes'] / 1e6:.1f} MB / launch = {s_['hbm_traffic_per_launch']['traffic_over_algorithmic']:.2f} × algorithmic, "
@@ -112,16 +117,17 @@ if sa:
                      f"{100 * sa['solver_active']['envs_solved_at_end']:.0f} % solved); CPU oracle: {sci(cb.get('value', 0))} on {cb.get('cores', '?')} threads.")
 
 # saturation sweeps: the BASELINE batch x1 / x4 / x16
-sweep_rows = ["| workload | envs/GPU | env-steps/s | µs per step launch | roofline frac | same-size fill µs (step ÷ fill) |", "|---|---|---|---|---|---|"]
-for w, sizes in (("binary-narrow", ("", "-65536")), ("zelda-turtle", ("", "-16384", "-65536")), ("sokoban-wide", ("", "-8192", "-32768")),
+sweep_rows = ["| workload | envs/GPU | env-steps/s | µs per step launch | roofline frac | same-size fill µs (step ÷ fill) | kernel mean / median µs (rocprofv3) |", "|---|---|---|---|---|---|---|"]
+for w, sizes in (("binary-narrow", ("", "-16384", "-65536")), ("zelda-turtle", ("", "-16384", "-65536")), ("sokoban-wide", ("", "-8192", "-32768")),
                  ("minecraft_3D_maze-narrow", ("", "-4096", "-16384"))):
     for sfx in sizes:
         l = lines.get(w + sfx)
         if not l:
             continue
         f_ = l["roofline"].get("fill_same_bytes")
+        kk = kernel_us(w + ("@" + sfx[1:] if sfx else ""))
         sweep_rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {l['roofline']['frac']:.3f} | "
-                          + (f"{f_['us']:.2f} ({f_['step_over_fill']:.2f} ×)" if f_ else "–") + " |")
+                          + (f"{f_['us']:.2f} ({f_['step_over_fill']:.2f} ×)" if f_ else "–") + " | " + (f"{kk['mean'] / 1e3:.2f} / {kk['median'] / 1e3:.2f}" if kk else "–") + " |")
 sweep_table = "\n".join(sweep_rows)
 
 # evolution-driver pattern
@@ -152,12 +158,44 @@ if ad:
                        + (f"{r['env_steps_per_s'] / b0['env_steps_per_s']:.2f} × ({sci(b0['env_steps_per_s'])})" if b0 else "–") + " |")
 adapter_table = "\n".join(ad_rows)
 
-blocks = {"HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active,
+# the driver's --steps 20 --warmup 5 under the short-run protocols, and through the collective path
+drv_rows = ["| protocol | µs per step (wall = `value`'s clock) | timed region µs | K launches by HIP events µs | closing exchange µs | env-steps/s |", "|---|---|---|---|---|---|"]
+for key, what in (("driver_20_5", "fused (default): one graph = 20 step launches + the reduction launch"),
+                  ("driver_20_5_nccl1", "the same through the N > 1 exchange: world-size-1 RCCL all-reduce + device→host copy (`--force-collective`)"),
+                  ("driver_20_5_one", "round 4: one graph of 20 steps, reduction launched separately"),
+                  ("driver_20_5_gcd", "graph of gcd(5, 20) = 5 steps: 1 untimed + 4 timed replays"),
+                  ("driver_20_5_eager", "20 eager launches (`pcgrl_step_seq`)")):
+    l = lines.get(key)
+    if not l:
+        continue
+    tr = l.get("timed_region", {})
+    drv_rows.append(f"| {what} | {l['ms_per_step'] * 1e3:.2f} | {tr.get('wall_ms', 0) * 1e3:.1f} | {tr.get('launches_ms', 0) * 1e3:.1f} | {tr.get('exchange_ms', 0) * 1e3:.1f} | {sci(l['value'])} |")
+driver_table = "\n".join(drv_rows)
+
+# sub-batch chains (bench.py async_sub_batches)
+sb_rows = ["| workload | envs/GPU | one batch µs/step (same protocol) | k = 2 | k = 4 | best |", "|---|---|---|---|---|---|"]
+for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle",
+          "zelda_bigger-turtle", "minecraft_3D_maze-narrow-15"):
+    sb = (lines.get(w) or {}).get("async_sub_batches")
+    if not sb or "rows" not in sb:
+        continue
+    r_ = {r["sub_batches"]: r for r in sb["rows"]}
+    best = max(r_.values(), key=lambda r: r["speedup_vs_one_batch_same_protocol"])
+    sb_rows.append(f"| {w} | {lines[w]['config']['envs_per_gpu']} | {r_[1]['us_per_step_of_whole_batch']:.2f} | "
+                   + " | ".join((f"{r_[k]['us_per_step_of_whole_batch']:.2f} ({r_[k]['speedup_vs_one_batch_same_protocol']:.2f} ×)" if k in r_ else "–") for k in (2, 4))
+                   + f" | k = {best['sub_batches']}: {best['speedup_vs_one_batch_same_protocol']:.2f} × |")
+subbatch_table = "\n".join(sb_rows)
+
+cl = (lines.get("binary-narrow") or {}).get("closed_loop_device_actions") or {}
+closed_loop = (f"{cl['us_per_step']:.2f} µs per step = {sci(cl['value'])} env-steps/s, {cl['roofline_frac']:.3f} of the roofline "
+               f"({cl['us_per_step'] - b['ms_per_step'] * 1e3:.2f} µs more than the pool figure: the sampler kernel and one more kernel boundary per step)") if cl.get("us_per_step") else "n/a"
+
+blocks = {"DRIVER_TABLE": driver_table, "SUBBATCH_TABLE": subbatch_table, "CLOSED_LOOP": closed_loop, "HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active,
           "SWEEP_TABLE": sweep_table, "EVO_TABLE": evo_table, "ADAPTER_TABLE": adapter_table}
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 for name, text in blocks.items():
-    inline = name in ("DRIVER20", "SOLVER_ACTIVE")
+    inline = name in ("DRIVER20", "SOLVER_ACTIVE", "CLOSED_LOOP")
     new = f"<!-- {name} -->{'' if inline else chr(10)}{text}{'' if inline else chr(10)}<!-- /{name} -->"
     if f"<!-- {name} -->" not in s and f"@@{name}@@" not in s:
         continue
@@ -172,4 +210,7 @@ print(sweep_table)
 print(evo_table)
 print(adapter_table)
 print(driver20)
+print(driver_table)
+print(subbatch_table)
+print(closed_loop)
 print(solver_active)
