@@ -12,7 +12,7 @@ N > 1: one process per GPU.  Started by `python -m torch.distributed.run --nproc
 the script is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment); started plainly it launches the N
 ranks itself (child processes, before anything in this process touches the GPU) and relays rank 0's line.
 
-Timed region = K launches + the path's only exchange (pcgrl_reduce_episodes: one launch; all-reduce over RCCL
+Timed region = K launches + the path's only exchange (pcgrl_reduce_episodes: one launch; all-gather over RCCL
 when N > 1; one device->host copy), bracketed by barrier + synchronize, max over ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM bandwidth with the algorithmic
@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--rollout-launches", type=int, default=200, help="timed pcgrl_rollout launches of the secondary figure")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: initialise a world-size-1 'nccl' (RCCL) process group and close the timed region through the "
-                         "N > 1 exchange (device all-reduce + device->host copy), so that a 1-GPU box executes the multi-GPU code path")
+                         "N > 1 exchange (device all-gather + device->host copy), so that a 1-GPU box executes the multi-GPU code path")
     ap.add_argument("--closed-loop-steps", type=int, default=-1,
                     help="steps of the secondary figure `closed_loop_device_actions` (a HIP graph of [pcgrl_sample_actions -> pcgrl_step] "
                          "pairs: an action drawn on the device at every step, SURVEY 8(d)'s literal protocol); 0 = skip; default max(steps, 2000)")
@@ -446,7 +446,7 @@ def main():
     def reduce_episodes(after=None, launched=False):
         """the path's only exchange: one pcgrl_reduce_episodes launch (`launched`: it was the last node of the graph just
         replayed); world == 1: the kernel writes its 3 + n_stats doubles straight into pinned host memory (no copy);
-        world > 1: one small all-reduce over RCCL, then one device -> host copy.  Ends with the device synchronised."""
+        world > 1: one small all-gather over RCCL, then one device -> host copy.  Ends with the device synchronised."""
         if not use_coll:
             rc = 0 if launched else env._L.pcgrl_reduce_episodes(env._h, ep_host.data_ptr(), 1, sptr)
             if rc:
@@ -458,22 +458,29 @@ def main():
             done_ev.synchronize()
             torch.cuda.synchronize(dev)
             return
+        # N > 1: ONE collective -- an all-gather of every rank's 3 + n_stats sums (north_star: "a RCCL all-gather over xGMI only for
+        # the episodic-return reduction") -- and ONE device -> host copy of the world x (3 + n_stats) doubles; the sum over the
+        # ranks, in rank order, is taken on the host.  (Round 4 all-reduced in place and needed one more device copy to keep this
+        # rank's own count: every operation behind the K launches is ~8 us of a 170 us region.)
         if not launched:
             env.reduce_episodes(clear=True, out=ep_dev)
-        local_eps.copy_(ep_dev[2:3], non_blocking=True)  # (test evidence: this rank's own episode count)
         if coll_dev.type == "cpu":  # gloo test hook
             t = ep_dev.cpu()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            ep_host.copy_(t)
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            ep_all_host.copy_(torch.cat(parts))
             if after is not None:
                 after.record(stream)
                 torch.cuda.synchronize(dev)
-            return
-        dist.all_reduce(ep_dev, op=dist.ReduceOp.SUM)
-        if after is not None:
-            after.record(stream)
-        ep_host.copy_(ep_dev, non_blocking=True)
-        torch.cuda.synchronize(dev)
+        else:
+            dist.all_gather_into_tensor(ep_all_dev, ep_dev)
+            if after is not None:
+                after.record(stream)
+            ep_all_host.copy_(ep_all_dev, non_blocking=True)
+            torch.cuda.synchronize(dev)
+        allr = ep_all_host.view(world, -1)
+        ep_host.copy_(allr.sum(0))
+        local_eps[0] = float(allr[rank, 2])
 
     def measure_closed_loop():
         """Secondary figure: SURVEY 8(d)'s protocol taken literally (profile_env.py:134-139: an action sampled at every step).
@@ -586,8 +593,10 @@ def main():
         del g, buf
         return {"bytes": nbytes, "us": us, "GBps": nbytes / us / 1e3, "frac_of_peak": nbytes / us / 1e3 / HBM_PEAK_GBS}
 
-    local_eps = torch.zeros(1, dtype=torch.float64, device=dev)
-    reduce_episodes()  # warm the reporting path (first all-reduce), clean accumulators
+    local_eps = [0.0]  # this rank's own episode count of the last reduction (test evidence)
+    ep_all_dev = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64, device=dev)
+    ep_all_host = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64).pin_memory()
+    reduce_episodes()  # warm the reporting path (first collective), clean accumulators
     fill = measure_fill() if not args.dry_run else None
     rollout = measure_rollout()
     run(W)
@@ -599,9 +608,9 @@ def main():
     run(K)
     ev1.record(stream)
     ev2 = torch.cuda.Event(enable_timing=True)
-    # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-reduce of the episode sums
+    # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-gather of the episode sums
     # cannot complete on any rank before every rank has contributed, i.e. finished its K launches; one collective instead
-    # of an all-reduce followed by a barrier.  Ends with the device synchronised.
+    # of a collective followed by a barrier.  Ends with the device synchronised.
     if fuse_reduce and not use_coll:
         # the whole region was that one graph (K launches + the reduction, which wrote pinned host memory): ev1 is its end.
         # (Every further event record is a marker packet the command processor works through one after the other: three of
@@ -613,11 +622,11 @@ def main():
         reduce_episodes(ev2, launched=fuse_reduce)
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
-    # the exchange on this rank's stream: reduction launch + (N > 1) the all-reduce, which also waits for the slowest rank
+    # the exchange on this rank's stream: reduction launch + (N > 1) the all-gather, which also waits for the slowest rank
     exchange_ms = 0.0 if ev2 is None else (ev1.elapsed_time(ev2) if ev2.query() else float("nan"))
     env.check_errors()
     elapsed, per_rank_elapsed = max_over_ranks(elapsed)
-    _, per_rank_eps = max_over_ranks(float(local_eps.item()))
+    _, per_rank_eps = max_over_ranks(float(local_eps[0]))
     _, per_rank_kernel_ms = max_over_ranks(kernel_ms)
     _, per_rank_exchange_ms = max_over_ranks(exchange_ms)
     first_replay_ms = measure_first_replay()
@@ -655,7 +664,7 @@ def main():
                        # (SURVEY 8(d) says torch.randint per step; the action source is not the hot path, so the rows are drawn
                        # once, on the device, before the timed region, and step k reads row k mod POOL)
                        "actions": f"pool of {POOL} pre-drawn rows of uniform random actions resident in HBM, row k mod {POOL} at step k",
-                       "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-reduce)",
+                       "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-gather)",
                        "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
                        "seed_ranges": [[0x5EED + lo, 0x5EED + hi - 1] for lo, hi in
                                        (shard_env_range(total_envs, r, world) for r in range(world))]},
@@ -676,18 +685,18 @@ def main():
             "episodes": ep,
         }
         # per rank: its own clock of the timed region, the HIP-event time of its K launches alone, and the closing exchange
-        # (reduction launch + all-reduce, which waits for the slowest rank): weak-scaling efficiency can be read off this
+        # (reduction launch + all-gather, which waits for the slowest rank): weak-scaling efficiency can be read off this
         # one line as  min(launch_ms_per_step at N = 1) / max(launch_ms_per_step)  and the exchange's share
         out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "ms_per_step": [t / K * 1e3 for t in per_rank_elapsed],
                            "launch_ms_per_step": per_rank_kernel_ms, "exchange_ms": per_rank_exchange_ms,
                            "episodes": per_rank_eps,
-                           "collective": "none" if not use_coll else f"{backend} all-reduce of {3 + env.n_stats} doubles"
+                           "collective": "none" if not use_coll else f"{backend} all-gather of {3 + env.n_stats} doubles per rank"
                                          + (" (world size 1: --force-collective)" if world == 1 else ""),
                            "cores": "all" if pinned is None else f"{len(pinned)} per rank (sched_setaffinity by LOCAL_RANK)"}
         if first_replay_ms is not None:  # round 4's protocol for short runs, for comparison (never `value`)
             out["per_rank"]["first_replay_of_one_graph_ms_per_step"] = per_rank_first
         # what the timed region consists of on the slowest rank: K launches (HIP events) + the closing exchange
-        # (pcgrl_reduce_episodes launch, N > 1: the all-reduce, which also absorbs rank skew, + the device->host copy) + host latency
+        # (pcgrl_reduce_episodes launch, N > 1: the all-gather, which also absorbs rank skew, + the device->host copy) + host latency
         out["timed_region"] = {"wall_ms": elapsed * 1e3, "launches_ms": max(per_rank_kernel_ms) * K,
                                "exchange_ms": max(per_rank_exchange_ms), "exchange_share_of_wall": max(per_rank_exchange_ms) / (elapsed * 1e3),
                                "protocol": ("ONE replay of a HIP graph of the K step launches + the pcgrl_reduce_episodes launch (uploaded with hipGraphUpload, "

@@ -45,7 +45,7 @@ def test_bench_force_collective_runs_rccl_with_one_rank():
     out = _bench("--gpus", "1", "--force-collective", "--envs", "256", "--steps", "800", "--warmup", "0", "--no-cpu-baseline",
                  "--rollout-steps", "0", "--closed-loop-steps", "0")
     pr = out["per_rank"]
-    assert pr["collective"].startswith("nccl all-reduce"), pr
+    assert pr["collective"].startswith("nccl all-gather"), pr
     assert out["config"]["launch"].startswith("HIP graph"), out["config"]["launch"]
     assert out["episodes"]["episodes"] == 256.0 and pr["episodes"] == [256.0]
     assert out["episodes"]["mean_length"] == 770.0
