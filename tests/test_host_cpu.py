@@ -53,6 +53,25 @@ def test_create_rejects_bad_configs_without_gpu():
         build_config("smb", "narrow", (16, 16))
 
 
+def test_round5_entry_points_check_their_arguments_without_gpu():
+    """the entry points added in 0.3 validate before any HIP call (null handles / pointers are errors, not crashes)"""
+    from control_pcgrl_amd import _lib
+    L = _lib.lib()
+    assert L.pcgrl_num_actions(None) == -1
+    assert L.pcgrl_sample_actions(None, None, 0, None) == 1 and b"pcgrl_sample_actions" in L.pcgrl_last_error()
+    assert L.pcgrl_reserve_solver_pool(None, 0, 1) == 1
+    assert L.pcgrl_solver_pool_slots(None, None, None) == 0
+    assert L.pcgrl_copy_to_host(None, None, 16, None) == 1
+    assert L.pcgrl_graph_upload(None, None) == 1
+    assert b"0.3" in L.pcgrl_version()
+
+
+def test_sub_batched_env_validates_the_split():
+    from control_pcgrl_amd import SubBatchedVecEnv
+    with pytest.raises(ValueError, match="multiple of sub_batches"):
+        SubBatchedVecEnv("binary", "narrow", (16, 16), 10, 4)
+
+
 @pytest.mark.parametrize("problem,shape", [("binary", (16, 16)), ("binary", (32, 32)), ("binary", (10, 14)),
                                            ("zelda", (16, 16)), ("zelda", (32, 32)), ("sokoban", (16, 16)),
                                            ("minecraft_3D_maze", (7, 7, 7))])
