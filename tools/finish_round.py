@@ -161,7 +161,7 @@ adapter_table = "\n".join(ad_rows)
 # the driver's --steps 20 --warmup 5 under the short-run protocols, and through the collective path
 drv_rows = ["| protocol | µs per step (wall = `value`'s clock) | timed region µs | K launches by HIP events µs | closing exchange µs | env-steps/s |", "|---|---|---|---|---|---|"]
 for key, what in (("driver_20_5", "fused (default): one graph = 20 step launches + the reduction launch"),
-                  ("driver_20_5_nccl1", "the same through the N > 1 exchange: world-size-1 RCCL all-reduce + device→host copy (`--force-collective`)"),
+                  ("driver_20_5_nccl1", "the same through the N > 1 exchange: world-size-1 RCCL all-gather + device→host copy (`--force-collective`)"),
                   ("driver_20_5_one", "round 4: one graph of 20 steps, reduction launched separately"),
                   ("driver_20_5_gcd", "graph of gcd(5, 20) = 5 steps: 1 untimed + 4 timed replays"),
                   ("driver_20_5_eager", "20 eager launches (`pcgrl_step_seq`)")):
