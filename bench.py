@@ -705,6 +705,12 @@ def main():
                                             f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and G < K and W % G == 0 and K % G == 0
                                             else f"replays of a HIP graph of {G} steps (+ {K % G} eager launches)" if graph is not None
                                             else "eager launches")}
+        if world > 1:
+            out["timed_region"]["vs_single_gpu_line"] = (
+                "the N = 1 line's region holds no collective and no device->host copy (its reduction kernel writes pinned host memory; "
+                "`--gpus 1 --force-collective` runs this exchange with one rank): value(N) / (N * value(1)) therefore charges the exchange "
+                "itself, ~30 us of a ~165 us region at the driver's 20 steps, before any loss from adding ranks; "
+                "per_rank.launch_ms_per_step compares the launches alone")
         if closed is not None:
             out["closed_loop_device_actions"] = closed
         if solver_active:
