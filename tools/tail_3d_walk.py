@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """What the slowest wave of a 3-D step launch does (timing build with -DPCGRL_M3_TAIL:  python tools/phase_timing.py --build
 --m3-tail  here, then this script on the GPU box): per launch the simulate wave with the longest lifetime, how many cached
-start planes it found missing, how many pairs of searches it ran itself / took from the pair runner, how often the
-speculative second search was used, and how its cycles split into the candidate walk and everything else.
-PCGRL_M3_RUNNER_MAX=0 switches the runner wave off for comparison."""
+start planes it found missing, how many pairs of searches it ran, how often the speculative second search was used, and how
+its cycles split into the candidate walk and everything else.  (The "runner" columns belong to the round-5 experiment with a
+fourth wavefront per env, commit bb5a491: zero with the shipped kernels.  profiles/r05_dev_traces.md has both outputs.)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
