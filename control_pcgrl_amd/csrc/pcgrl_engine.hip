@@ -794,11 +794,36 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   return PCGRL_OK;
 }
 
+// pcgrl_rollout on maps where the rollout kernel loses to stepping: that kernel keeps the env in registers and does both
+// roles on one wave, which pays where a step is short (16-row maps: 3.5 vs 5.9 us per step for binary, 10 vs 21 for the 7^3
+// maze) and costs where the observation is large and wants a wave of its own next to the statistics (round 4/5 bench lines:
+// zelda_big 49.6 vs 27.2 us per step, zelda_bigger 217 vs 116, binary_bigger 60 vs 48, the 15^3 maze 112 vs 78).  There the
+// call issues its n_steps as step launches -- same results by the entry point's own definition, never slower than stepping.
+static bool rollout_as_steps(const pcgrl_engine *h) {
+  const char *f = getenv("PCGRL_ROLLOUT_KERNEL");  // development / tests: 1 = always the rollout kernel, 0 = always step launches
+  if (f != nullptr && (f[0] == '0' || f[0] == '1')) return f[0] == '0';
+  const pcgrl_config &c = h->p.cfg;
+  if (c.problem == PCGRL_PROB_MC3DMAZE) return m3_size_class(c.dims[0], c.dims[1], c.dims[2]) == 1;
+  return h->lpe > 16;
+}
+
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs,
                      void *stream) {
   if (!h || !d_actions || n_steps < 1) return fail(PCGRL_EINVAL, "pcgrl_rollout: bad arguments");
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_rollout_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
+  if (rollout_as_steps(h)) {
+    const size_t N = (size_t)h->p.n_envs;
+    for (int32_t k = 0; k < n_steps; k++) {
+      const bool last = k == n_steps - 1;
+      uint8_t *obs_k = d_obs == nullptr ? nullptr : (obs_last_only ? (last ? d_obs : nullptr) : d_obs + (size_t)k * N * (size_t)h->obs_bytes);
+      const int rc = pcgrl_step_ex(h, d_actions + (size_t)k * N * (size_t)h->p.n_act, auto_reset, obs_k, d_reward ? d_reward + (size_t)k * N : nullptr,
+                                   d_reward64 ? d_reward64 + (size_t)k * N : nullptr, d_done ? d_done + (size_t)k * N : nullptr,
+                                   d_stats ? d_stats + (size_t)k * N * (size_t)h->p.cfg.n_stats : nullptr, last ? d_ctrl_obs : nullptr, stream);
+      if (rc != PCGRL_OK) return rc;
+    }
+    return PCGRL_OK;
+  }
   ON_DEVICE(h->device);
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;

@@ -281,7 +281,15 @@ def run_case(case, seed, verbose=False):
             K = int(rng.integers(2, 13)) if rng.random() < 0.85 else int(rng.integers(13, 41))
             want = str(rng.choice(["all", "last", "none"]))
             a = draw_actions(t, lead=(K,))
-            obs, rew, done, stats = env.rollout(a.to(env.device), want_obs=want)
+            # pcgrl_rollout picks its form by map size (one launch / n step launches); both forms stay under test on every shape
+            form = str(rng.choice(["auto", "1", "0"]))
+            if form != "auto":
+                os.environ["PCGRL_ROLLOUT_KERNEL"] = form
+            try:
+                obs, rew, done, stats = env.rollout(a.to(env.device), want_obs=want)
+            finally:
+                os.environ.pop("PCGRL_ROLLOUT_KERNEL", None)
+            case.setdefault("_trace", []).append(f"rollout_form={form}")
             rew, done, stats = rew.cpu().numpy().astype(np.float64), done.cpu().numpy(), stats.cpu().numpy()
             obs = None if obs is None else obs.cpu().numpy()
             for k in range(K):

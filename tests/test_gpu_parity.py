@@ -805,6 +805,37 @@ def test_rollout_kernel_equals_stepwise_and_oracle(problem, rep, shape, n_envs, 
     env.check_errors()
 
 
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_rollout_both_forms_on_a_large_and_a_small_map(force):
+    """pcgrl_rollout picks its form by map size (one launch on 16-row maps, step launches on larger ones: never slower than
+    stepping); PCGRL_ROLLOUT_KERNEL forces either form on both, and every combination equals the oracle"""
+    os.environ["PCGRL_ROLLOUT_KERNEL"] = force
+    try:
+        for problem, rep, shape, n, K, kw in (("binary", "narrow", (40, 48), 11, 90, dict(obs_window=(80, 96))),
+                                             ("zelda", "turtle", (16, 16), 70, 120, {}),
+                                             ("minecraft_3D_maze", "narrow", (10, 10, 10), 5, 60, {}),
+                                             ("binary", "narrow", (16, 16), 40, 100, dict(static_prob=0.2, n_static_walls=2))):
+            seeds = 21 + np.arange(n)
+            env = _vec(problem, rep, shape, n, seeds=seeds, auto_reset=True, change_percentage=0.1, **kw)
+            orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, change_percentage=0.1, **kw)
+            env.reset()
+            orc.reset()
+            a = torch.randint(0, env.num_actions, (K, n), dtype=torch.int32, generator=torch.Generator().manual_seed(6))
+            obs, rew, done, stats = env.rollout(a.to(env.device), want_obs="all")
+            for t in range(K):
+                oobs, orew, odone, ostats = orc.step(a[t].numpy(), auto_reset=True)
+                assert np.array_equal(stats[t].cpu().numpy(), ostats), f"{problem} {shape} stats @ {t}"
+                assert np.max(np.abs(rew[t].cpu().numpy().astype(np.float64) - orew)) <= REW_TOL and np.array_equal(done[t].cpu().numpy(), odone)
+                assert np.array_equal(obs[t].cpu().numpy(), oobs), f"{problem} {shape} obs @ {t}"
+            o_last, _, _, _ = env.rollout(a[:7].to(env.device), want_obs="last")
+            for t in range(7):
+                oobs, _, _, _ = orc.step(a[t].numpy(), auto_reset=True)
+            assert np.array_equal(o_last.cpu().numpy(), oobs)
+            env.check_errors()
+    finally:
+        del os.environ["PCGRL_ROLLOUT_KERNEL"]
+
+
 def test_rollout_kernel_3d_equals_oracle():
     n, K, shape = 96, 1100, (7, 7, 7)  # episode length 1031: auto-resets inside the launch
     seeds = 3 + np.arange(n)
