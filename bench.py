@@ -162,6 +162,10 @@ def main():
     ap.add_argument("--sub-batches", default="2,4",
                     help="secondary figure `async_sub_batches`: the batch as k engines of N / k envs on k streams, their step chains captured "
                          "as parallel branches of one HIP graph (SubBatchedVecEnv); comma-separated k values, '' = skip")
+    ap.add_argument("--graph-collective", action="store_true",
+                    help="experiment (N > 1 or --force-collective, fused short protocol): capture the all-gather and the device->host copy into "
+                         "the timed HIP graph as well, so that the whole exchange is one graph launch; NOT the default: it could only be tried "
+                         "with one rank on the builder's boxes")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
@@ -350,6 +354,13 @@ def main():
     ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
     done_ev = torch.cuda.Event()
     fuse_reduce = bool(G > 0 and G == K and 2 <= K <= 125 and args.short_protocol == "fused")
+    graph_coll = bool(args.graph_collective and use_coll and fuse_reduce and backend == "nccl")
+    local_eps = [0.0]  # this rank's own episode count of the last reduction (test evidence)
+    ep_all_dev = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64, device=dev)
+    ep_all_host = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64).pin_memory()
+    if graph_coll:  # (the communicator is set up by the first collective: not inside a capture)
+        dist.all_gather_into_tensor(ep_all_dev, ep_dev)
+        torch.cuda.synchronize(dev)
     graph = None
     if G > 0:
         # (thread-local capture mode: with N > 1 ranks the RCCL watchdog thread queries events while this thread captures;
@@ -369,6 +380,9 @@ def main():
                         rc = env._L.pcgrl_reduce_episodes(env._h, ep_dev.data_ptr() if use_coll else ep_host.data_ptr(), 1, cap)
                         if rc:
                             raise RuntimeError(f"pcgrl_reduce_episodes (capture) rc={rc}")
+                        if graph_coll:  # (experiment) the collective and the copy as graph nodes, too
+                            dist.all_gather_into_tensor(ep_all_dev, ep_dev)
+                            ep_all_host.copy_(ep_all_dev, non_blocking=True)
             stream.wait_stream(side)
             try:  # (best effort: the first replay of a graph that was never launched is otherwise slower)
                 env._L.pcgrl_graph_upload(graph.raw_cuda_graph_exec(), stream.cuda_stream)
@@ -464,7 +478,11 @@ def main():
         # rank's own count: every operation behind the K launches is ~8 us of a 170 us region.)
         if not launched:
             env.reduce_episodes(clear=True, out=ep_dev)
-        if coll_dev.type == "cpu":  # gloo test hook
+        if launched and graph_coll:  # (experiment: the all-gather and the copy were nodes of the graph just replayed)
+            if after is not None:
+                after.record(stream)
+            torch.cuda.synchronize(dev)
+        elif coll_dev.type == "cpu":  # gloo test hook
             t = ep_dev.cpu()
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
@@ -593,9 +611,6 @@ def main():
         del g, buf
         return {"bytes": nbytes, "us": us, "GBps": nbytes / us / 1e3, "frac_of_peak": nbytes / us / 1e3 / HBM_PEAK_GBS}
 
-    local_eps = [0.0]  # this rank's own episode count of the last reduction (test evidence)
-    ep_all_dev = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64, device=dev)
-    ep_all_host = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64).pin_memory()
     reduce_episodes()  # warm the reporting path (first collective), clean accumulators
     fill = measure_fill() if not args.dry_run else None
     rollout = measure_rollout()
@@ -690,7 +705,7 @@ def main():
         out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "ms_per_step": [t / K * 1e3 for t in per_rank_elapsed],
                            "launch_ms_per_step": per_rank_kernel_ms, "exchange_ms": per_rank_exchange_ms,
                            "episodes": per_rank_eps,
-                           "collective": "none" if not use_coll else f"{backend} all-gather of {3 + env.n_stats} doubles per rank"
+                           "collective": "none" if not use_coll else f"{backend} all-gather of {3 + env.n_stats} doubles per rank" + (" (captured in the timed graph)" if graph_coll and graph is not None else "")
                                          + (" (world size 1: --force-collective)" if world == 1 else ""),
                            "cores": "all" if pinned is None else f"{len(pinned)} per rank (sched_setaffinity by LOCAL_RANK)"}
         if first_replay_ms is not None:  # round 4's protocol for short runs, for comparison (never `value`)
