@@ -807,6 +807,8 @@ static bool rollout_as_steps(const pcgrl_engine *h) {
   return h->lpe > 16;
 }
 
+int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h) { return h ? (rollout_as_steps(h) ? 0 : 1) : -1; }
+
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs,
                      void *stream) {

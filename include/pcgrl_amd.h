@@ -170,6 +170,7 @@ int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles +
  * launch exactly as with pcgrl_step_ex. */
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
+int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h); /* 1: one launch per call; 0: n_steps step launches (larger maps) */
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats,
                      float *d_ctrl_obs, void *stream);
