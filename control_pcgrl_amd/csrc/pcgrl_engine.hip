@@ -794,17 +794,17 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
   return PCGRL_OK;
 }
 
-// pcgrl_rollout on maps where the rollout kernel loses to stepping: that kernel keeps the env in registers and does both
-// roles on one wave, which pays where a step is short (16-row maps: 3.5 vs 5.9 us per step for binary, 10 vs 21 for the 7^3
-// maze) and costs where the observation is large and wants a wave of its own next to the statistics (round 4/5 bench lines:
-// zelda_big 49.6 vs 27.2 us per step, zelda_bigger 217 vs 116, binary_bigger 60 vs 48, the 15^3 maze 112 vs 78).  There the
-// call issues its n_steps as step launches -- same results by the entry point's own definition, never slower than stepping.
+// pcgrl_rollout where the rollout kernel loses to stepping.  That kernel keeps the env in registers and does both roles on
+// one wave: it pays where a step is short or its launches wait for their slowest env (16-row maps: 3.5 vs 5.9 us per step
+// for binary; the 3-D mazes, whose waves then advance independently: 10 vs 21 us at 7^3, 112 vs 126 at 15^3 over the same
+// steps) and costs where the observation is computed chunk by chunk from tile codes (Params::obs_codes: the maps whose
+// one-hot rows would not fit the LDS), which wants a wave of its own next to the statistics -- zelda_big 49.7 vs 34 us per
+// step, zelda_bigger 217 vs 126, binary_bigger 60 vs 51 (bench lines of rounds 4 / 5).  There the call issues its n_steps as
+// step launches: same results by the entry point's own definition.
 static bool rollout_as_steps(const pcgrl_engine *h) {
   const char *f = getenv("PCGRL_ROLLOUT_KERNEL");  // development / tests: 1 = always the rollout kernel, 0 = always step launches
   if (f != nullptr && (f[0] == '0' || f[0] == '1')) return f[0] == '0';
-  const pcgrl_config &c = h->p.cfg;
-  if (c.problem == PCGRL_PROB_MC3DMAZE) return m3_size_class(c.dims[0], c.dims[1], c.dims[2]) == 1;
-  return h->lpe > 16;
+  return h->p.cfg.problem != PCGRL_PROB_MC3DMAZE && h->p.obs_codes > 0;
 }
 
 int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h) { return h ? (rollout_as_steps(h) ? 0 : 1) : -1; }
