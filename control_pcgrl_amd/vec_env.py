@@ -564,6 +564,36 @@ class SubBatchedVecEnv:
         self.wait()
         return torch.stack([e.reduce_episodes(clear=clear) for e in self.envs]).sum(0)
 
+    def last_episode(self):
+        self.wait()
+        parts = [e.last_episode() for e in self.envs]
+        return SimpleNamespace(**{key: torch.cat([getattr(p, key) for p in parts]) for key in ("ep_return", "ep_len", "final_stats", "n_episodes")})
+
+    def sample_actions(self, seed=0):
+        """one device-side draw per sub-batch (sub-batch i uses seed + i: its engines keep their own draw counters)"""
+        self.wait()
+        return torch.cat([e.sample_actions(seed + i) for i, e in enumerate(self.envs)])
+
+    def observe(self):
+        for i, e in enumerate(self.envs):
+            self._fork(i)
+            with torch.cuda.stream(self.streams[i]):
+                e.observe()
+        self.wait()
+        return self._obs
+
+    def state_dict(self):
+        """a list of the sub-batches' checkpoints (VecPcgrlEnv.state_dict); loads into an env with the same split"""
+        self.wait()
+        return {"sub_batches": [e.state_dict() for e in self.envs]}
+
+    def load_state_dict(self, sd):
+        if len(sd.get("sub_batches", ())) != self.k:
+            raise ValueError(f"state_dict of {len(sd.get('sub_batches', ()))} sub-batches, this env has {self.k}")
+        self.wait()
+        for e, part in zip(self.envs, sd["sub_batches"]):
+            e.load_state_dict(part)
+
     def check_errors(self):
         for e in self.envs:
             e.check_errors()

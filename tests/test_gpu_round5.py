@@ -491,4 +491,18 @@ def test_sub_batched_env_equals_one_batch_vs_oracle(problem, rep, shape, n, k):
         check(t, obs, rew, done, stats, t % 7 == 0)
     st, ost = env.get_state(), orc.get_state()
     assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"])
+    le, ole = env.last_episode(), orc.last_episode()
+    assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]) and np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"])
+    # checkpoint of the split env into a fresh one with the same split: continues with the oracle
+    other = make_vec_env(cfg, n, seeds=np.zeros(n, np.int64), sub_batches=k)
+    other.reset()
+    other.load_state_dict(env.state_dict())
+    a = env.sample_actions(seed=3)
+    assert a.shape[0] == n and int(a.max()) < env.num_actions
+    for t in range(5):
+        act = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = other.step(act.to(env.device))
+        oobs, orew, odone, ostats = orc.step(act.numpy(), auto_reset=True)
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats) and np.array_equal(obs.cpu().numpy(), oobs), f"restored split env @ {t}"
     env.check_errors()
+    other.check_errors()
