@@ -506,3 +506,30 @@ def test_sub_batched_env_equals_one_batch_vs_oracle(problem, rep, shape, n, k):
         assert np.array_equal(info["stats"].cpu().numpy(), ostats) and np.array_equal(obs.cpu().numpy(), oobs), f"restored split env @ {t}"
     env.check_errors()
     other.check_errors()
+
+
+# ------------------------------------------------------------------------------------- batches beyond 2^31 bytes of output
+@pytest.mark.parametrize("problem,rep,n", [("binary", "narrow", 720_000), ("zelda", "turtle", 250_000)])
+def test_batch_whose_observations_exceed_2_gib_vs_oracle(problem, rep, n):
+    """288 GB of HBM invite large batches: 720 000 binary envs write 2.2 GB of observations per launch (250 000 zelda envs
+    2.3 GB), so every byte offset beyond env 699 050 (233 016) needs more than 31 bits.  Reset, a few steps and the
+    observations of the LAST envs of the batch against the oracle."""
+    seeds = 5 + np.arange(n)
+    env = _vec(problem, rep, (16, 16), n, seeds=seeds, auto_reset=True)
+    orc = po.OracleVecEnv(problem, rep, (16, 16), n, seeds=seeds, threads=16)
+    obs, _ = env.reset()
+    oobs = orc.reset()
+    tail = slice(n - 3000, n)
+    assert np.array_equal(obs[tail].cpu().numpy(), oobs[tail]), "reset observation of the last envs"
+    g = torch.Generator().manual_seed(1)
+    for t in range(4):
+        a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a.to(env.device))
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True, want_obs=True)
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), f"stats @ {t}"
+        assert np.max(np.abs(rew.cpu().numpy().astype(np.float64) - orew)) <= REW_TOL
+        assert np.array_equal(obs[tail].cpu().numpy(), oobs[tail]), f"observation of the last envs @ {t}"
+        assert np.array_equal(obs[:2000].cpu().numpy(), oobs[:2000])
+    st, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"])
+    env.check_errors()
