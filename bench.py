@@ -166,6 +166,9 @@ def main():
                     help="experiment (N > 1 or --force-collective, fused short protocol): capture the all-gather and the device->host copy into "
                          "the timed HIP graph as well, so that the whole exchange is one graph launch; NOT the default: it could only be tried "
                          "with one rank on the builder's boxes")
+    ap.add_argument("--eager-head", type=int, default=3,
+                    help="fused short protocol: the first this-many of the K steps are eager launches issued right before the graph of the "
+                         "rest, so that the GPU is already stepping while the host pays the graph launch (0 = the whole region in the graph)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
@@ -355,6 +358,10 @@ def main():
     done_ev = torch.cuda.Event()
     fuse_reduce = bool(G > 0 and G == K and 2 <= K <= 125 and args.short_protocol == "fused")
     graph_coll = bool(args.graph_collective and use_coll and fuse_reduce and backend == "nccl")
+    # A graph launch costs the host ~15-20 us before its first kernel runs; a plain launch ~8.  The first HEAD steps of the region
+    # are therefore eager launches and the graph (steps HEAD .. K - 1 + the reduction) is launched behind them: the device is
+    # already stepping while the host pays for the graph launch.
+    HEAD = max(0, min(args.eager_head, K - 2)) if fuse_reduce else 0
     local_eps = [0.0]  # this rank's own episode count of the last reduction (test evidence)
     ep_all_dev = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64, device=dev)
     ep_all_host = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64).pin_memory()
@@ -372,7 +379,7 @@ def main():
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     cap = torch.cuda.current_stream(dev).cuda_stream
-                    for k in range(G):
+                    for k in range(HEAD, G):
                         rc = step_raw(base + (k % POOL) * stride, cap)
                         if rc:
                             raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
@@ -400,6 +407,10 @@ def main():
     def run(n):
         if graph is None or n < G:
             return run_eager(n)
+        if fuse_reduce:  # (n == G == K) the region: HEAD eager launches, then the graph of the rest + the reduction
+            run_eager(HEAD)
+            graph.replay()
+            return
         for _ in range(n // G):
             graph.replay()
         run_eager(n % G, first=G)
@@ -683,7 +694,7 @@ def main():
                        # once, on the device, before the timed region, and step k reads row k mod POOL)
                        "actions": f"pool of {POOL} pre-drawn rows of uniform random actions resident in HBM, row k mod {POOL} at step k",
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-gather)",
-                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
+                       "launch": (f"{HEAD} eager launches + one HIP graph of {G - HEAD} steps and the reduction launch" if fuse_reduce and HEAD else f"HIP graph of {G} steps per replay") if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
                        "seed_ranges": [[0x5EED + lo, 0x5EED + hi - 1] for lo, hi in
                                        (shard_env_range(total_envs, r, world) for r in range(world))]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -717,8 +728,9 @@ def main():
         # (pcgrl_reduce_episodes launch, N > 1: the all-gather, which also absorbs rank skew, + the device->host copy) + host latency
         out["timed_region"] = {"wall_ms": elapsed * 1e3, "launches_ms": max(per_rank_kernel_ms) * K,
                                "exchange_ms": max(per_rank_exchange_ms), "exchange_share_of_wall": max(per_rank_exchange_ms) / (elapsed * 1e3),
-                               "protocol": ("ONE replay of a HIP graph of the K step launches + the pcgrl_reduce_episodes launch (uploaded with hipGraphUpload, "
-                                            "never launched before; the W warm-up steps are eager launches); `launches_ms` includes that reduction launch"
+                               "protocol": (f"{HEAD} eager launches, then ONE replay of a HIP graph of the other {K - HEAD} step launches + the pcgrl_reduce_episodes launch "
+                                            "(uploaded with hipGraphUpload, never launched before; the W warm-up steps are eager launches); `launches_ms` "
+                                            "includes that reduction launch"
                                             if fuse_reduce else
                                             f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and G < K and W % G == 0 and K % G == 0
                                             else f"replays of a HIP graph of {G} steps (+ {K % G} eager launches)" if graph is not None
