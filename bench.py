@@ -166,9 +166,9 @@ def main():
                     help="experiment (N > 1 or --force-collective, fused short protocol): capture the all-gather and the device->host copy into "
                          "the timed HIP graph as well, so that the whole exchange is one graph launch; NOT the default: it could only be tried "
                          "with one rank on the builder's boxes")
-    ap.add_argument("--eager-head", type=int, default=3,
-                    help="fused short protocol: the first this-many of the K steps are eager launches issued right before the graph of the "
-                         "rest, so that the GPU is already stepping while the host pays the graph launch (0 = the whole region in the graph)")
+    ap.add_argument("--eager-head", type=int, default=0,
+                    help="fused short protocol (experiment, measured without gain: 169-205 us against 169-179 us per 20-step region): the first "
+                         "this-many of the K steps as eager launches issued right before the graph of the rest; 0 = the whole region in the graph")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
@@ -358,9 +358,8 @@ def main():
     done_ev = torch.cuda.Event()
     fuse_reduce = bool(G > 0 and G == K and 2 <= K <= 125 and args.short_protocol == "fused")
     graph_coll = bool(args.graph_collective and use_coll and fuse_reduce and backend == "nccl")
-    # A graph launch costs the host ~15-20 us before its first kernel runs; a plain launch ~8.  The first HEAD steps of the region
-    # are therefore eager launches and the graph (steps HEAD .. K - 1 + the reduction) is launched behind them: the device is
-    # already stepping while the host pays for the graph launch.
+    # (--eager-head: the first HEAD steps of the region as eager launches with the graph of the rest launched behind them, so that
+    # the device is already stepping while the host pays for the graph launch -- tried, no gain, default 0)
     HEAD = max(0, min(args.eager_head, K - 2)) if fuse_reduce else 0
     local_eps = [0.0]  # this rank's own episode count of the last reduction (test evidence)
     ep_all_dev = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64, device=dev)
@@ -728,7 +727,7 @@ def main():
         # (pcgrl_reduce_episodes launch, N > 1: the all-gather, which also absorbs rank skew, + the device->host copy) + host latency
         out["timed_region"] = {"wall_ms": elapsed * 1e3, "launches_ms": max(per_rank_kernel_ms) * K,
                                "exchange_ms": max(per_rank_exchange_ms), "exchange_share_of_wall": max(per_rank_exchange_ms) / (elapsed * 1e3),
-                               "protocol": (f"{HEAD} eager launches, then ONE replay of a HIP graph of the other {K - HEAD} step launches + the pcgrl_reduce_episodes launch "
+                               "protocol": ((f"{HEAD} eager launches, then " if HEAD else "") + f"ONE replay of a HIP graph of {K - HEAD} step launches + the pcgrl_reduce_episodes launch "
                                             "(uploaded with hipGraphUpload, never launched before; the W warm-up steps are eager launches); `launches_ms` "
                                             "includes that reduction launch"
                                             if fuse_reduce else

@@ -61,8 +61,8 @@ def test_bench_driver_protocol_with_collective():
     out = _bench("--gpus", "1", "--force-collective", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0",
                  "--rllib-adapter", "0", "--closed-loop-steps", "500", "--sub-batches", "2")
     assert out["steps"] == 20 and out["warmup"] == 5
-    assert out["config"]["launch"] == "3 eager launches + one HIP graph of 17 steps and the reduction launch"
-    assert out["timed_region"]["protocol"].startswith("3 eager launches, then ONE replay of a HIP graph of the other 17 step launches")
+    assert out["config"]["launch"] == "HIP graph of 20 steps per replay"
+    assert out["timed_region"]["protocol"].startswith("ONE replay of a HIP graph of 20 step launches + the pcgrl_reduce_episodes")
     sb = out["async_sub_batches"]
     assert "error" not in sb and [r["sub_batches"] for r in sb["rows"]] == [1, 2]
     g = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0", "--rllib-adapter", "0",
