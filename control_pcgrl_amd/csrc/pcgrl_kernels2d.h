@@ -155,7 +155,7 @@ struct Grp {
     } else {
       // gfx9 DPP wave shift: one lane across the whole wavefront (crosses the 16-lane DPP rows)
       r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
-      r = row == 0 ? 0u : r;
+      if constexpr (LPE < 64) r = row == 0 ? 0u : r;  // (64 rows: the group is the wave, bound_ctrl gives lane 0 its zero)
     }
     return r;
   }
@@ -166,7 +166,7 @@ struct Grp {
       if constexpr (LPE < 16) r = row == LPE - 1 ? 0u : r;
     } else {
       r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
-      r = row == LPE - 1 ? 0u : r;
+      if constexpr (LPE < 64) r = row == LPE - 1 ? 0u : r;
     }
     return r;
   }
@@ -241,6 +241,44 @@ __device__ __attribute__((always_inline)) inline M bfs_level(const Grp<LPE> &g, 
         : "v"((uint32_t)front));
     free_cells = (M)fr;
     return (M)nb;
+  } else if constexpr (LPE == 64 && sizeof(M) == 4) {
+    // 64-row maps, 32-bit masks: the same six instructions with the DPP wave shifts (the group is the whole wavefront, so
+    // bound_ctrl supplies the zeros at rows 0 and 63)
+    uint32_t nb, a, b, fr = (uint32_t)free_cells;
+    asm("v_lshlrev_b32 %1, 1, %4\n\t"
+        "v_lshrrev_b32 %2, 1, %4\n\t"
+        "v_or_b32_dpp %1, %4, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_or_b32_dpp %2, %4, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8\n\t"
+        "v_bitop3_b32 %3, %1, %2, %3 bitop3:2"
+        : "=&v"(nb), "=&v"(a), "=&v"(b), "+v"(fr)
+        : "v"((uint32_t)front));
+    free_cells = (M)fr;
+    return (M)nb;
+  } else if constexpr (LPE == 64 && sizeof(M) == 8) {
+    // 64 x 64 maps (the reference's binary_bigger / zelda_bigger): a level in twelve 32-bit instructions on the two halves of
+    // the row masks -- the one-bit shifts across the halves are v_alignbit_b32, the row shifts ride on the ORs, both results
+    // of a half come from one three-input bit operation each.  (The compiler's form: two 64-bit shifts, four DPP moves, and a
+    // chain of 64-bit ORs / ANDs, ~22 instructions; a launch of 4096 such envs ends with the env whose path sweeps are longest.)
+    uint32_t flo = (uint32_t)front, fhi = (uint32_t)((uint64_t)front >> 32);
+    uint32_t rlo = (uint32_t)free_cells, rhi = (uint32_t)((uint64_t)free_cells >> 32);
+    uint32_t nlo, nhi, alo, ahi, blo, bhi;
+    asm("v_lshlrev_b32 %2, 1, %8\n\t"
+        "v_alignbit_b32 %3, %9, %8, 31\n\t"
+        "v_alignbit_b32 %4, %9, %8, 1\n\t"
+        "v_lshrrev_b32 %5, 1, %9\n\t"
+        "v_or_b32_dpp %2, %8, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_or_b32_dpp %3, %9, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_or_b32_dpp %4, %8, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_or_b32_dpp %5, %9, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_bitop3_b32 %0, %2, %4, %6 bitop3:0xa8\n\t"
+        "v_bitop3_b32 %6, %2, %4, %6 bitop3:2\n\t"
+        "v_bitop3_b32 %1, %3, %5, %7 bitop3:0xa8\n\t"
+        "v_bitop3_b32 %7, %3, %5, %7 bitop3:2"
+        : "=&v"(nlo), "=&v"(nhi), "=&v"(alo), "=&v"(ahi), "=&v"(blo), "=&v"(bhi), "+v"(rlo), "+v"(rhi)
+        : "v"(flo), "v"(fhi));
+    free_cells = (M)((uint64_t)rlo | ((uint64_t)rhi << 32));
+    return (M)((uint64_t)nlo | ((uint64_t)nhi << 32));
   } else {
     const M nb = expand(g, front) & free_cells;
     free_cells ^= nb;
