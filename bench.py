@@ -463,8 +463,8 @@ def main():
             rollout = {"value": total_envs * R * GR / el_r, "unit": "env-steps/s", "steps_per_launch": GR, "launches": R,
                        "us_per_step": us, "roofline_frac": ALGO_BYTES[args.workload] * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                        "form": ("one launch per call" if env._L.pcgrl_rollout_is_one_launch(env._h) == 1 else
-                                "issued as step launches by the one call (a large 2-D map whose observation is computed from tile codes: "
-                                "the one-launch kernel loses to stepping there)"),
+                                "issued as step launches by the one call (a 2-D map of more than 16 rows: the one-launch kernel loses to "
+                                "stepping there)"),
                        "note": "open-loop action sequences only (actions known in advance); all per-step outputs written; "
                                "measured before the timed region"}
             del obs_r

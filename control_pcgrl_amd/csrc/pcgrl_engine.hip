@@ -797,14 +797,16 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
 // pcgrl_rollout where the rollout kernel loses to stepping.  That kernel keeps the env in registers and does both roles on
 // one wave: it pays where a step is short or its launches wait for their slowest env (16-row maps: 3.5 vs 5.9 us per step
 // for binary; the 3-D mazes, whose waves then advance independently: 10 vs 21 us at 7^3, 112 vs 126 at 15^3 over the same
-// steps) and costs where the observation is computed chunk by chunk from tile codes (Params::obs_codes: the maps whose
-// one-hot rows would not fit the LDS), which wants a wave of its own next to the statistics -- zelda_big 49.7 vs 34 us per
-// step, zelda_bigger 217 vs 126, binary_bigger 60 vs 51 (bench lines of rounds 4 / 5).  There the call issues its n_steps as
-// step launches: same results by the entry point's own definition.
+// steps) and costs on the 2-D maps of more than 16 rows, where the observation is large (or computed chunk by chunk from tile
+// codes, Params::obs_codes) and wants a wave of its own next to the statistics -- zelda_big 49.7 vs 34 us per step,
+// zelda_bigger 217 vs 126, binary_bigger 60 vs 51, binary_big 16.7 vs 15.5 (bench lines of rounds 4 / 5).  There the call
+// issues its n_steps as step launches: same results by the entry point's own definition.
 static bool rollout_as_steps(const pcgrl_engine *h) {
   const char *f = getenv("PCGRL_ROLLOUT_KERNEL");  // development / tests: 1 = always the rollout kernel, 0 = always step launches
   if (f != nullptr && (f[0] == '0' || f[0] == '1')) return f[0] == '0';
-  return h->p.cfg.problem != PCGRL_PROB_MC3DMAZE && h->p.obs_codes > 0;
+  // (maps of more than 16 rows without tile codes, e.g. binary_big 32 x 32: 16.7 us per step in one launch -- its kernel sits at
+  // 256 VGPRs -- against 15.0-15.5 as step launches)
+  return h->p.cfg.problem != PCGRL_PROB_MC3DMAZE && (h->p.obs_codes > 0 || h->lpe > 16);
 }
 
 int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h) { return h ? (rollout_as_steps(h) ? 0 : 1) : -1; }

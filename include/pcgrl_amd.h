@@ -158,10 +158,9 @@ int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles +
 /* Open-loop rollout: n_steps consecutive pcgrl_step()s of every env in ONE launch, for action sequences that do not
  * depend on the observations (random-action rollouts as in the reference's own env tests, replays, evaluation of stored
  * action sequences).  Results are identical to n_steps calls of pcgrl_step; there is no kernel boundary between steps.
- * (One launch where that is the faster form: 1.7 x / 2 x the stepping rate for binary-narrow / the 7^3 maze.  On the large
- * 2-D maps whose observation is computed from tile codes -- cropped windows whose one-hot rows exceed 20 KB of LDS per
- * workgroup, e.g. 32 x 32 zelda, 64 x 64 binary -- the observation wants a wavefront of its own next to the statistics and
- * the call issues its n_steps as step launches instead: same results.)
+ * (One launch where that is the faster form: 2-D maps of up to 16 rows and the 3-D mazes -- 1.7 x / 2 x the stepping rate
+ * for binary-narrow / the 7^3 maze.  On 2-D maps of more than 16 rows the observation wants a wavefront of its own next to
+ * the statistics and the call issues its n_steps as step launches instead: same results.)
  *   d_actions int32 [n_steps][N]          d_reward float [n_steps][N]      d_done uint8 [n_steps][N]
  *   d_stats   int32 [n_steps][N][n_stats] d_obs uint8 [n_steps][N][obs_bytes], or [N][obs_bytes] (the observation
  *             after the last step only) when obs_last_only != 0.  Any output pointer may be NULL.
@@ -171,7 +170,7 @@ int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles +
  * launch exactly as with pcgrl_step_ex. */
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
-int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h); /* 1: one launch per call; 0: n_steps step launches (large 2-D maps) */
+int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h); /* 1: one launch per call; 0: n_steps step launches (2-D maps of more than 16 rows) */
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats,
                      float *d_ctrl_obs, void *stream);

@@ -807,8 +807,8 @@ def test_rollout_kernel_equals_stepwise_and_oracle(problem, rep, shape, n_envs, 
 
 @pytest.mark.parametrize("force", ["1", "0"])
 def test_rollout_both_forms_on_a_large_and_a_small_map(force):
-    """pcgrl_rollout picks its form by configuration (step launches on the large 2-D maps whose observation is computed from
-    tile codes, one launch elsewhere); PCGRL_ROLLOUT_KERNEL forces either form, and every combination equals the oracle"""
+    """pcgrl_rollout picks its form by configuration (step launches on 2-D maps of more than 16 rows, one launch elsewhere);
+    PCGRL_ROLLOUT_KERNEL forces either form, and every combination equals the oracle"""
     os.environ["PCGRL_ROLLOUT_KERNEL"] = force
     try:
         for problem, rep, shape, n, K, kw in (("binary", "narrow", (40, 48), 11, 90, dict(obs_window=(80, 96))),

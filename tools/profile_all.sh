@@ -28,7 +28,9 @@ for ENT in $ENTRIES; do
   if [ $RO = 1 ]; then  # few step launches, many rollout launches: the rollout kernel dominates the passes
     KT="$ARGS --steps 20 --warmup 5 --rollout-launches 100"; PM="$ARGS --steps 20 --warmup 5 --rollout-launches 40"
   else
-    KT="$ARGS --steps $S --warmup 100 --rollout-launches 20"; PM="$ARGS --steps $P --warmup 100 --rollout-steps 0"
+    # (no rollouts in a step-kernel entry: on the larger 2-D maps pcgrl_rollout issues step launches, which would mix into the
+    # dominant kernel's statistics with their own, larger output footprint)
+    KT="$ARGS --steps $S --warmup 100 --rollout-steps 0"; PM="$ARGS --steps $P --warmup 100 --rollout-steps 0"
   fi
   D=$R/gpurun_out/prof_${ENT}
   rocprofv3 --kernel-trace --stats --output-format csv -d ${D}_kt -- python3 $R/bench.py $KT > ${D}_kt.log 2>&1
