@@ -241,6 +241,7 @@ __device__ __attribute__((always_inline)) inline M bfs_level(const Grp<LPE> &g, 
         : "v"((uint32_t)front));
     free_cells = (M)fr;
     return (M)nb;
+#ifndef PCGRL_NO_BFS32_ASM  // (development: A/B builds, tools/ab_bench.sh)
   } else if constexpr (LPE == 32 && sizeof(M) == 4) {
     // 32-row maps (two envs per wavefront): the wave shifts cross the group edge at lanes 31 / 32, so the shifted rows are
     // masked by per-lane constants inside the DPP instruction itself (v_and_b32_dpp): seven instructions instead of eleven
@@ -257,6 +258,7 @@ __device__ __attribute__((always_inline)) inline M bfs_level(const Grp<LPE> &g, 
         : "v"((uint32_t)front), "v"(mu), "v"(md));
     free_cells = (M)fr;
     return (M)nb;
+#endif
   } else if constexpr (LPE == 64 && sizeof(M) == 4) {
     // 64-row maps, 32-bit masks: the same six instructions with the DPP wave shifts (the group is the whole wavefront, so
     // bound_ctrl supplies the zeros at rows 0 and 63)
