@@ -1794,11 +1794,14 @@ __device__ inline void accumulate_episode(EnvState *S) {
 // workgroups to dispatch at 4096 envs: 6.65 -> 6.57 us per launch; 4 pairs are slower, 7.7 us; zelda, whose launch is
 // bound by its observation stores, is faster with 1).
 template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
+#ifndef PCGRL_B64_WAVES
+#define PCGRL_B64_WAVES 6  // waves per SIMD the binary 64-bit-mask step kernel is compiled for (development: A/B builds)
+#endif
 #ifndef PCGRL_STEP_WAVES
 #define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
 #endif
 __global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 512 : 128 * PAIRS,
-                             (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? 6 : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : ((FAST && PROB == PCGRL_PROB_SOKOBAN && !CTRL) ? 4 : 1))))
+                             (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? PCGRL_B64_WAVES : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : ((FAST && PROB == PCGRL_PROB_SOKOBAN && !CTRL) ? 4 : 1))))
 void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks
