@@ -597,10 +597,6 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     const int Hc = cfg->dims[0], Wc = cfg->dims[1], OWc = cfg->obs_window[1], Cc = p.n_tiles + 1;
     const bool fast_cfg = Hc == 16 && Wc == 16 && cfg->obs_window[0] == 32 && OWc == 32;
     p.obs16 = (!is3d && fast_cfg) ? 1 : 0;
-    {  // PREFLOOD only where the simulate wave's chain bounds the launch (see step_kernel)
-      static const int pre_max = getenv("PCGRL_PREFLOOD_MAX") ? atoi(getenv("PCGRL_PREFLOOD_MAX")) : 8192;  // (development: A/B)
-      if (p.obs16 && n_envs > pre_max) p.obs16 |= 2;
-    }
     // (only where the one-hot rows are what limits occupancy: at 13 KB per workgroup -- binary 32 x 32 -- the rows are
     // cheaper: 14.0 vs 15.6 us per launch; at 26 KB -- binary 64 x 64 -- 67 vs 47.5; at 38 KB -- zelda 32 x 32 -- 44 vs 27.6)
     if (!is3d && cfg->representation != PCGRL_REP_WIDE && !cfg->static_tiles && !fast_cfg && (OWc * Cc) % 16 == 0 &&

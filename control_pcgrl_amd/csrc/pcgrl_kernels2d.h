@@ -1915,10 +1915,7 @@ void step_kernel(Params p) {
     if constexpr (PRE) {
       // narrow: the next edit goes to `pos`; turtle: an edit can only happen at `pos` (moves edit nothing).  Flood the
       // component of that cell ahead of time.
-      // (obs16 bit 1: PREFLOOD off.  The flood is computed at EVERY step and used by the half of the steps that change the
-      // map: it takes ~100 instructions off the simulate wave's chain where that chain bounds the launch -- small batches --
-      // and is wasted issue bandwidth where the launch is bound by VALU issue and stores: the host switches it off by batch size)
-      if (p.cfg.representation != PCGRL_REP_WIDE && (p.obs16 & 2) == 0) {
+      if (p.cfg.representation != PCGRL_REP_WIDE) {
         const M xbit = (rowok && g.row == pos[0]) ? (M(1) << pos[1]) : M(0);
         const M comp = flood(g, xbit, (~b[0] & colmask) | xbit);
         if (rowok) *pre_word = comp | (M)PRE_VALID;
