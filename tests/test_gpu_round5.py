@@ -68,6 +68,11 @@ def test_bench_driver_protocol_with_collective():
     g = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0", "--rllib-adapter", "0",
                "--closed-loop-steps", "0", "--sub-batches", "", "--short-protocol", "gcd")
     assert g["timed_region"]["protocol"].startswith("1 untimed + 4 timed replays of one HIP graph of 5 steps")
+    # (experiment flag, kept alive: the exchange captured in the timed graph as well)
+    gc = _bench("--gpus", "1", "--force-collective", "--graph-collective", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                "--rollout-steps", "0", "--rllib-adapter", "0", "--closed-loop-steps", "0", "--sub-batches", "")
+    assert "captured in the timed graph" in gc["per_rank"]["collective"], gc["per_rank"]
+    assert gc["episodes"]["episodes"] == 0.0 and gc["steps"] == 20
     cl = out["closed_loop_device_actions"]
     assert "error" not in cl, cl
     assert cl["steps"] == 500 and cl["us_per_step"] > 0
