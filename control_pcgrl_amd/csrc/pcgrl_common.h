@@ -72,7 +72,8 @@ struct Params {
   int32_t n_tiles;
   int32_t n_cells;
   int32_t obs_chunks;  // 16-byte chunks per observation row
-  int32_t obs16;       // 16x16 map, 32x32 window: the general kernels use the compile-time observation encoder, too
+  int32_t obs16;       // bit 0: 16x16 map, 32x32 window: the general kernels use the compile-time observation encoder, too;
+                       // bit 1: that encoder's stores are non-temporal (observations per launch far beyond the last-level cache)
   int32_t obs_codes;   // general kernels, cropped window: > 0 = observation chunks are generated from per-cell tile codes in
                        // LDS (encode_obs_codes); the value is the byte stride of a code row.  0 = one-hot rows in LDS
   void *planes;

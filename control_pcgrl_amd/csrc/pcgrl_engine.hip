@@ -597,6 +597,10 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     const int Hc = cfg->dims[0], Wc = cfg->dims[1], OWc = cfg->obs_window[1], Cc = p.n_tiles + 1;
     const bool fast_cfg = Hc == 16 && Wc == 16 && cfg->obs_window[0] == 32 && OWc == 32;
     p.obs16 = (!is3d && fast_cfg) ? 1 : 0;
+    {  // non-temporal observation stores where a launch writes far more than the 256 MB last-level cache holds (store_obs16_nt)
+      static const long nt_mb = getenv("PCGRL_OBS_NT_MB") ? atol(getenv("PCGRL_OBS_NT_MB")) : 384;  // (development: A/B; 0 = never)
+      if (p.obs16 && nt_mb > 0 && (int64_t)n_envs * obs_bytes >= (int64_t)nt_mb * 1000000) p.obs16 |= 2;
+    }
     // (only where the one-hot rows are what limits occupancy: at 13 KB per workgroup -- binary 32 x 32 -- the rows are
     // cheaper: 14.0 vs 15.6 us per launch; at 26 KB -- binary 64 x 64 -- 67 vs 47.5; at 38 KB -- zelda 32 x 32 -- 44 vs 27.6)
     if (!is3d && cfg->representation != PCGRL_REP_WIDE && !cfg->static_tiles && !fast_cfg && (OWc * Cc) % 16 == 0 &&

@@ -1115,7 +1115,28 @@ __device__ inline void store_obs16(void *dst, uint4 v) {
   u32x4_t w = {v.x, v.y, v.z, v.w};
   // the trailing s_nop covers the gfx9 hazard "VALU overwrites the data VGPRs of a >64-bit VMEM store" (2 wait states),
   // which the compiler's hazard recognizer cannot see through an asm statement
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
+#ifndef PCGRL_OBS_STORE_SEL
+#define PCGRL_OBS_STORE_SEL 0  // (development: A/B builds of other cache-policy bits, profiles/r05_dev_traces.md)
+#endif
+#if PCGRL_OBS_STORE_SEL == 1
+#define PCGRL_OBS_STORE_MODS "sc1 nt"
+#elif PCGRL_OBS_STORE_SEL == 2
+#define PCGRL_OBS_STORE_MODS "nt"
+#elif PCGRL_OBS_STORE_SEL == 3
+#define PCGRL_OBS_STORE_MODS ""
+#else
+#define PCGRL_OBS_STORE_MODS "sc1"
+#endif
+  asm volatile("global_store_dwordx4 %0, %1, off " PCGRL_OBS_STORE_MODS "\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
+}
+// ... write-through AND non-temporal (sc1 nt): for launches whose observations are far larger than the 256 MB last-level cache
+// (Params::obs16 bit 1, set by pcgrl_create from the batch size).  Measured with A/B builds (profiles/r05_dev_traces.md): the
+// 16x16 kernels gain 1.13 x at 604 MB per launch (zelda-turtle, 65 536 envs) and 1.46 x at 439 / 878 MB (binary-narrow, 131 072 /
+// 262 144 envs: 0.51 -> 0.75 of the HBM peak), and LOSE 7 - 18 % below ~320 MB, where lines written through stay useful to the
+// cache: hence the switch.
+__device__ inline void store_obs16_nt(void *dst, uint4 v) {
+  u32x4_t w = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
 }
 
 // The env's observation as `total` consecutive 16-byte chunks, lane r of the group taking chunks r, r + LPE, ...: every store
@@ -1409,9 +1430,15 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
             v[j] = *(const uint4 *)(((unsigned)m < (unsigned)H ? lds + (g.gbase + m) * STRIDE : oob_row) + q * 16);
           }
         }
+        if (p.obs16 & 2) {  // (wave-uniform: a scalar branch)
 #pragma unroll
-        for (int j = 0; j < BATCH; j++)
-          if (it0 + j < ITERS) store_obs16(base + (size_t)((it0 + j) * LPE + g.row) * 16, v[j]);
+          for (int j = 0; j < BATCH; j++)
+            if (it0 + j < ITERS) store_obs16_nt(base + (size_t)((it0 + j) * LPE + g.row) * 16, v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < BATCH; j++)
+            if (it0 + j < ITERS) store_obs16(base + (size_t)((it0 + j) * LPE + g.row) * 16, v[j]);
+        }
       }
     } else if (RB & 15) {
       const int gb = g.gbase;
