@@ -30,7 +30,7 @@ if [ "$WHAT" = "stock" ] || [ "$WHAT" = "all" ]; then
 fi
 if [ "$WHAT" = "sweep" ] || [ "$WHAT" = "all" ]; then
   # saturation sweeps: envs x4, x16 of the BASELINE batch
-  for WE in binary-narrow:16384 zelda-turtle:16384 zelda-turtle:65536 sokoban-wide:8192 sokoban-wide:32768 minecraft_3D_maze-narrow:4096 minecraft_3D_maze-narrow:16384; do
+  for WE in binary-narrow:16384 binary-narrow:262144 zelda-turtle:16384 zelda-turtle:65536 sokoban-wide:8192 sokoban-wide:32768 minecraft_3D_maze-narrow:4096 minecraft_3D_maze-narrow:16384; do
     W=${WE%%:*}; E=${WE##*:}
     python bench.py --workload $W --envs $E --steps 4000 --warmup 400 --no-cpu-baseline > $O/bench_${T}_$W-$E.log 2>&1
   done

@@ -118,7 +118,7 @@ if sa:
 
 # saturation sweeps: the BASELINE batch x1 / x4 / x16
 sweep_rows = ["| workload | envs/GPU | env-steps/s | µs per step launch | roofline frac | same-size fill µs (step ÷ fill) | kernel mean / median µs (rocprofv3) |", "|---|---|---|---|---|---|---|"]
-for w, sizes in (("binary-narrow", ("", "-16384", "-65536")), ("zelda-turtle", ("", "-16384", "-65536")), ("sokoban-wide", ("", "-8192", "-32768")),
+for w, sizes in (("binary-narrow", ("", "-16384", "-65536", "-262144")), ("zelda-turtle", ("", "-16384", "-65536")), ("sokoban-wide", ("", "-8192", "-32768")),
                  ("minecraft_3D_maze-narrow", ("", "-4096", "-16384"))):
     for sfx in sizes:
         l = lines.get(w + sfx)
