@@ -604,7 +604,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     const bool fast_cfg = Hc == 16 && Wc == 16 && cfg->obs_window[0] == 32 && OWc == 32;
     p.obs16 = (!is3d && fast_cfg) ? 1 : 0;
     // non-temporal observation stores where a launch writes far more than the 256 MB last-level cache holds (store_obs16_nt)
-    if (p.obs16 && obs_nt_for((int64_t)n_envs * obs_bytes)) p.obs16 |= 2;
+    if ((p.obs16 || is3d) && obs_nt_for((int64_t)n_envs * obs_bytes)) p.obs16 |= 2;  // (3-D: bit 1 alone)
     // (only where the one-hot rows are what limits occupancy: at 13 KB per workgroup -- binary 32 x 32 -- the rows are
     // cheaper: 14.0 vs 15.6 us per launch; at 26 KB -- binary 64 x 64 -- 67 vs 47.5; at 38 KB -- zelda 32 x 32 -- 44 vs 27.6)
     if (!is3d && cfg->representation != PCGRL_REP_WIDE && !cfg->static_tiles && !fast_cfg && (OWc * Cc) % 16 == 0 &&
@@ -847,7 +847,7 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
   p.obs_last_only = obs_last_only;
   p.obs_env_bytes = h->obs_bytes;
   // (a rollout that keeps every step's observation writes n_steps times a step launch's bytes: 805 MB for 64 steps of 4096 binary envs)
-  if (p.obs16 && d_obs && !obs_last_only && obs_nt_for((int64_t)n_steps * h->p.n_envs * h->obs_bytes)) p.obs16 |= 2;
+  if ((p.obs16 || h->p.cfg.problem == PCGRL_PROB_MC3DMAZE) && d_obs && !obs_last_only && obs_nt_for((int64_t)n_steps * h->p.n_envs * h->obs_bytes)) p.obs16 |= 2;
   p.reward = d_reward;
   p.reward64 = d_reward64;
   p.done = d_done;

@@ -1462,7 +1462,7 @@ template <int PROB, int LPE, bool FAST, typename M>
 __device__ inline void encode_obs_any(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
                                       uint8_t *lds, uint8_t *obs_base = nullptr) {
   if constexpr (!FAST && LPE == 16 && sizeof(M) == 4) {
-    if (p.obs16) {
+    if (p.obs16 & 1) {
       encode_obs<PROB, LPE, true, M>(g, p, env, active, b, pos, lds, obs_base);
       return;
     }

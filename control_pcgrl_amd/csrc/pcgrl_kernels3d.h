@@ -1141,10 +1141,17 @@ __device__ inline void m3_encode_obs(const uint32_t *dirt, const uint32_t *over,
   int ch = ch_lo + c.lane;
   for (; ch + 3 * stride < ch_hi; ch += 4 * stride) {
     const uint4 v0 = chunk(ch), v1 = chunk(ch + stride), v2 = chunk(ch + 2 * stride), v3 = chunk(ch + 3 * stride);
-    store_obs16(dst + ch, v0);
-    store_obs16(dst + ch + stride, v1);
-    store_obs16(dst + ch + 2 * stride, v2);
-    store_obs16(dst + ch + 3 * stride, v3);
+    if (p.obs16 & 2) {  // (launches that write far more than the last-level cache holds: non-temporal, see store_obs16_nt)
+      store_obs16_nt(dst + ch, v0);
+      store_obs16_nt(dst + ch + stride, v1);
+      store_obs16_nt(dst + ch + 2 * stride, v2);
+      store_obs16_nt(dst + ch + 3 * stride, v3);
+    } else {
+      store_obs16(dst + ch, v0);
+      store_obs16(dst + ch + stride, v1);
+      store_obs16(dst + ch + 2 * stride, v2);
+      store_obs16(dst + ch + 3 * stride, v3);
+    }
   }
   for (; ch < ch_hi; ch += stride) store_obs16(dst + ch, chunk(ch));
 }
