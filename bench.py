@@ -12,8 +12,11 @@ N > 1: one process per GPU.  Started by `python -m torch.distributed.run --nproc
 the script is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment); started plainly it launches the N
 ranks itself (child processes, before anything in this process touches the GPU) and relays rank 0's line.
 
-Timed region = K launches + the path's only exchange (pcgrl_reduce_episodes: one launch; all-gather over RCCL
-when N > 1; one device->host copy), bracketed by barrier + synchronize, max over ranks.
+Timed region (every N) = K launches + the pcgrl_reduce_episodes launch + ONE synchronise, bracketed by barrier +
+synchronize, max over ranks.  N > 1: the path's only collective -- the RCCL all-gather of the episode sums + its
+device->host copy -- ships the PREVIOUS interval's sums on a side stream while this interval steps (SURVEY 8 e), so the
+N > 1 region has the N = 1 region's structure and no rank waits for another inside it (--exchange serial: round 5's form).
+A rank that does not finish within PCGRL_BENCH_RANK_TIMEOUT seconds (default 1500) exits with code 3.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM bandwidth with the algorithmic
 bytes of SURVEY.md section 8(d): `achieved` / `frac` use the same wall clock as `value`, `achieved_hip_events` /
@@ -162,13 +165,11 @@ def main():
     ap.add_argument("--sub-batches", default="2,4",
                     help="secondary figure `async_sub_batches`: the batch as k engines of N / k envs on k streams, their step chains captured "
                          "as parallel branches of one HIP graph (SubBatchedVecEnv); comma-separated k values, '' = skip")
-    ap.add_argument("--graph-collective", action="store_true",
-                    help="experiment (N > 1 or --force-collective, fused short protocol): capture the all-gather and the device->host copy into "
-                         "the timed HIP graph as well, so that the whole exchange is one graph launch; NOT the default: it could only be tried "
-                         "with one rank on the builder's boxes")
-    ap.add_argument("--eager-head", type=int, default=0,
-                    help="fused short protocol (experiment, measured without gain: 169-205 us against 169-179 us per 20-step region): the first "
-                         "this-many of the K steps as eager launches issued right before the graph of the rest; 0 = the whole region in the graph")
+    ap.add_argument("--exchange", default="overlap", choices=["overlap", "serial"],
+                    help="N > 1 (or --force-collective): 'overlap' (default) = the timed region has the N = 1 region's structure -- K step "
+                         "launches + the pcgrl_reduce_episodes launch + one synchronise -- while the all-gather + device->host copy of the "
+                         "PREVIOUS interval's sums run on a side stream under the stepping (SURVEY 8 e: 'issue it on a side stream so it never "
+                         "blocks stepping'); 'serial' = round 5's region: reduction -> all-gather -> copy behind the K launches, as the closing barrier")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
@@ -210,8 +211,24 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # A rank that hangs (a peer that never joins a collective, a wedged device) must END, with a non-zero code -- never a
+    # re-exec or an in-process fallback of a process that has touched the GPU: the launcher (ours or torch.distributed.run) then
+    # stops the other ranks and the run fails visibly instead of sitting in a collective for ever.
+    import threading
+    rank_timeout = float(os.environ.get("PCGRL_BENCH_RANK_TIMEOUT", "1500"))
+
+    def _rank_timed_out():
+        sys.stderr.write(f"bench.py: rank {rank} did not finish within {rank_timeout:.0f} s (PCGRL_BENCH_RANK_TIMEOUT): exit code 3\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    watchdog = threading.Timer(rank_timeout, _rank_timed_out)
+    watchdog.daemon = True
+    watchdog.start()
     if args.dry_run:
         n_envs = args.envs or WORKLOADS[args.workload][3]
+        if os.environ.get("PCGRL_BENCH_TEST_HANG_RANK") == str(rank):  # (test hook: a rank that never reaches the rendezvous)
+            time.sleep(1e6)
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
@@ -245,10 +262,12 @@ def main():
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", str(world))
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=min(rank_timeout, 600.0))  # (a collective that waits longer than this aborts the rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     problem, rep, shape, default_envs = WORKLOADS[args.workload][:4]
@@ -357,16 +376,15 @@ def main():
     ep_host = torch.zeros(3 + env.n_stats, dtype=torch.float64).pin_memory()
     done_ev = torch.cuda.Event()
     fuse_reduce = bool(G > 0 and G == K and 2 <= K <= 125 and args.short_protocol == "fused")
-    graph_coll = bool(args.graph_collective and use_coll and fuse_reduce and backend == "nccl")
-    # (--eager-head: the first HEAD steps of the region as eager launches with the graph of the rest launched behind them, so that
-    # the device is already stepping while the host pays for the graph launch -- tried, no gain, default 0)
-    HEAD = max(0, min(args.eager_head, K - 2)) if fuse_reduce else 0
+    overlap = bool(use_coll and args.exchange == "overlap")
     local_eps = [0.0]  # this rank's own episode count of the last reduction (test evidence)
     ep_all_dev = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64, device=dev)
     ep_all_host = torch.zeros(world * (3 + env.n_stats), dtype=torch.float64).pin_memory()
-    if graph_coll:  # (the communicator is set up by the first collective: not inside a capture)
-        dist.all_gather_into_tensor(ep_all_dev, ep_dev)
-        torch.cuda.synchronize(dev)
+    # overlapped exchange: the previous interval's sums (this rank's), the side stream they are gathered on, its end marker
+    ep_prev_dev = torch.zeros(3 + env.n_stats, dtype=torch.float64, device=dev)
+    ep_prev_cpu = torch.zeros(3 + env.n_stats, dtype=torch.float64)
+    xstream = torch.cuda.Stream(dev) if overlap else None
+    ev_x = torch.cuda.Event(enable_timing=True)
     graph = None
     if G > 0:
         # (thread-local capture mode: with N > 1 ranks the RCCL watchdog thread queries events while this thread captures;
@@ -378,7 +396,7 @@ def main():
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     cap = torch.cuda.current_stream(dev).cuda_stream
-                    for k in range(HEAD, G):
+                    for k in range(G):
                         rc = step_raw(base + (k % POOL) * stride, cap)
                         if rc:
                             raise RuntimeError(f"pcgrl_step (capture) rc={rc}")
@@ -386,9 +404,6 @@ def main():
                         rc = env._L.pcgrl_reduce_episodes(env._h, ep_dev.data_ptr() if use_coll else ep_host.data_ptr(), 1, cap)
                         if rc:
                             raise RuntimeError(f"pcgrl_reduce_episodes (capture) rc={rc}")
-                        if graph_coll:  # (experiment) the collective and the copy as graph nodes, too
-                            dist.all_gather_into_tensor(ep_all_dev, ep_dev)
-                            ep_all_host.copy_(ep_all_dev, non_blocking=True)
             stream.wait_stream(side)
             try:  # (best effort: the first replay of a graph that was never launched is otherwise slower)
                 env._L.pcgrl_graph_upload(graph.raw_cuda_graph_exec(), stream.cuda_stream)
@@ -406,8 +421,7 @@ def main():
     def run(n):
         if graph is None or n < G:
             return run_eager(n)
-        if fuse_reduce:  # (n == G == K) the region: HEAD eager launches, then the graph of the rest + the reduction
-            run_eager(HEAD)
+        if fuse_reduce:  # (n == G == K) the region: the graph of the K steps + the reduction
             graph.replay()
             return
         for _ in range(n // G):
@@ -491,11 +505,7 @@ def main():
         # rank's own count: every operation behind the K launches is ~8 us of a 170 us region.)
         if not launched:
             env.reduce_episodes(clear=True, out=ep_dev)
-        if launched and graph_coll:  # (experiment: the all-gather and the copy were nodes of the graph just replayed)
-            if after is not None:
-                after.record(stream)
-            torch.cuda.synchronize(dev)
-        elif coll_dev.type == "cpu":  # gloo test hook
+        if coll_dev.type == "cpu":  # gloo test hook
             t = ep_dev.cpu()
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
@@ -629,29 +639,73 @@ def main():
     rollout = measure_rollout()
     run(W)
     reduce_episodes()  # episodes that ended during the warm-up do not count
+    if overlap:
+        # the warm-up interval's sums of THIS rank: what the side stream gathers while the timed interval steps.  The side
+        # stream's first collective (communicator channels, PyTorch's per-stream bookkeeping) happens here, untimed.
+        ep_prev_cpu.copy_(ep_all_host.view(world, -1)[rank])
+        ep_prev_dev.copy_(ep_prev_cpu)
+        torch.cuda.synchronize(dev)
+        if coll_dev.type != "cpu":
+            with torch.cuda.stream(xstream):
+                dist.all_gather_into_tensor(ep_all_dev, ep_prev_dev)
+            torch.cuda.synchronize(dev)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     run(K)
-    ev1.record(stream)
     ev2 = torch.cuda.Event(enable_timing=True)
-    # The closing barrier of the timed region IS the path's exchange: with N > 1 ranks the all-gather of the episode sums
-    # cannot complete on any rank before every rank has contributed, i.e. finished its K launches; one collective instead
-    # of a collective followed by a barrier.  Ends with the device synchronised.
-    if fuse_reduce and not use_coll:
-        # the whole region was that one graph (K launches + the reduction, which wrote pinned host memory): ev1 is its end.
-        # (Every further event record is a marker packet the command processor works through one after the other: three of
-        # them behind a 170 us region cost ~5 % of it.)
+    exposed_ms = 0.0
+    if overlap:
+        # N > 1, default.  The region has the N = 1 region's structure -- K step launches, the pcgrl_reduce_episodes launch (the
+        # last node of the same graph when the region is one graph), ONE synchronise -- and the only collective of the path, the
+        # all-gather of the PREVIOUS interval's sums + its device->host copy, runs on a side stream under the stepping (SURVEY
+        # 8 e).  Every reporting interval of a long run looks like this: it reduces its own episodes and ships the previous
+        # interval's.  No rank waits for another inside the region; the clock of a rank stops when ITS device is idle, and the
+        # figure is the maximum over the ranks.  (The interval's own sums are gathered after the clock, for the report.)
+        if not fuse_reduce:
+            env.reduce_episodes(clear=True, out=ep_dev)
+        ev1.record(stream)
+        if coll_dev.type == "cpu":  # gloo test hook: a host-side all-gather while the device steps
+            parts = [torch.zeros_like(ep_prev_cpu) for _ in range(world)]
+            dist.all_gather(parts, ep_prev_cpu)
+            ep_all_host.copy_(torch.cat(parts))
+        else:
+            with torch.cuda.stream(xstream):
+                dist.all_gather_into_tensor(ep_all_dev, ep_prev_dev)
+                ep_all_host.copy_(ep_all_dev, non_blocking=True)
+                ev_x.record(xstream)
         ev1.synchronize()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)  # (both streams)
+        elapsed = time.perf_counter() - t0
+        prev_interval = ep_all_host.view(world, -1).sum(0).tolist()  # what the host reads at the end of the region
+        if coll_dev.type != "cpu":
+            try:  # how long the side stream outlived the stepping stream (0 when it was done first: fully hidden)
+                exposed_ms = max(0.0, ev1.elapsed_time(ev_x))
+            except Exception:  # noqa: BLE001
+                exposed_ms = 0.0
         ev2 = None
+        reduce_episodes(None, launched=True)  # untimed: this interval's own sums, for `episodes`
     else:
-        reduce_episodes(ev2, launched=fuse_reduce)
-    elapsed = time.perf_counter() - t0
+        ev1.record(stream)
+        prev_interval = None
+        # serial form (--exchange serial; also N = 1 without a process group, where there is nothing to gather): the closing
+        # barrier of the timed region IS the path's exchange -- with N > 1 ranks the all-gather of the episode sums cannot
+        # complete on any rank before every rank has contributed, i.e. finished its K launches.
+        if fuse_reduce and not use_coll:
+            # the whole region was that one graph (K launches + the reduction, which wrote pinned host memory): ev1 is its end.
+            # (Every further event record is a marker packet the command processor works through one after the other: three of
+            # them behind a 170 us region cost ~5 % of it.)
+            ev1.synchronize()
+            torch.cuda.synchronize(dev)
+            ev2 = None
+        else:
+            reduce_episodes(ev2, launched=fuse_reduce)
+        elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch-to-launch time on the launch stream (HIP events)
-    # the exchange on this rank's stream: reduction launch + (N > 1) the all-gather, which also waits for the slowest rank
-    exchange_ms = 0.0 if ev2 is None else (ev1.elapsed_time(ev2) if ev2.query() else float("nan"))
+    # the exchange on this rank's stepping stream: serial form = reduction launch + all-gather (which also waits for the slowest
+    # rank); overlapped form = what of the side stream's work was still running when the stepping stream had finished
+    exchange_ms = exposed_ms if overlap else (0.0 if ev2 is None else (ev1.elapsed_time(ev2) if ev2.query() else float("nan")))
     env.check_errors()
     elapsed, per_rank_elapsed = max_over_ranks(elapsed)
     _, per_rank_eps = max_over_ranks(float(local_eps[0]))
@@ -693,7 +747,7 @@ def main():
                        # once, on the device, before the timed region, and step k reads row k mod POOL)
                        "actions": f"pool of {POOL} pre-drawn rows of uniform random actions resident in HBM, row k mod {POOL} at step k",
                        "parallelism": f"env-sharded x{world} (no data-path collective; episodic-return all-gather)",
-                       "launch": (f"{HEAD} eager launches + one HIP graph of {G - HEAD} steps and the reduction launch" if fuse_reduce and HEAD else f"HIP graph of {G} steps per replay") if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
+                       "launch": f"HIP graph of {G} steps per replay" if graph is not None else "eager, one launch per step (issued by pcgrl_step_seq)" if inject is None else "eager, one launch per step",
                        "seed_ranges": [[0x5EED + lo, 0x5EED + hi - 1] for lo, hi in
                                        (shard_env_range(total_envs, r, world) for r in range(world))]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -712,34 +766,45 @@ def main():
                          "fill_same_bytes": (dict(fill, step_over_fill=(elapsed / K * 1e6) / fill["us"]) if fill else None)},
             "episodes": ep,
         }
-        # per rank: its own clock of the timed region, the HIP-event time of its K launches alone, and the closing exchange
-        # (reduction launch + all-gather, which waits for the slowest rank): weak-scaling efficiency can be read off this
-        # one line as  min(launch_ms_per_step at N = 1) / max(launch_ms_per_step)  and the exchange's share
+        # per rank: its own clock of the timed region, the HIP-event time of its K launches alone, and the exchange: weak-scaling
+        # efficiency can be read off this one line as  min(launch_ms_per_step at N = 1) / max(launch_ms_per_step)
+        how = ("" if not use_coll else
+               " of the previous interval's sums on a side stream, under the stepping" if overlap else " behind the K launches (closing barrier)")
         out["per_rank"] = {"env_steps_per_s": [N * K / t for t in per_rank_elapsed], "ms_per_step": [t / K * 1e3 for t in per_rank_elapsed],
                            "launch_ms_per_step": per_rank_kernel_ms, "exchange_ms": per_rank_exchange_ms,
                            "episodes": per_rank_eps,
-                           "collective": "none" if not use_coll else f"{backend} all-gather of {3 + env.n_stats} doubles per rank" + (" (captured in the timed graph)" if graph_coll and graph is not None else "")
+                           "collective": "none" if not use_coll else f"{backend} all-gather of {3 + env.n_stats} doubles per rank" + how
                                          + (" (world size 1: --force-collective)" if world == 1 else ""),
                            "cores": "all" if pinned is None else f"{len(pinned)} per rank (sched_setaffinity by LOCAL_RANK)"}
         if first_replay_ms is not None:  # round 4's protocol for short runs, for comparison (never `value`)
             out["per_rank"]["first_replay_of_one_graph_ms_per_step"] = per_rank_first
-        # what the timed region consists of on the slowest rank: K launches (HIP events) + the closing exchange
-        # (pcgrl_reduce_episodes launch, N > 1: the all-gather, which also absorbs rank skew, + the device->host copy) + host latency
+        # what the timed region consists of on the slowest rank
+        region = (f"ONE replay of a HIP graph of {K} step launches + the pcgrl_reduce_episodes launch "
+                  "(uploaded with hipGraphUpload, never launched before; the W warm-up steps are eager launches); `launches_ms` "
+                  "includes that reduction launch"
+                  if fuse_reduce else
+                  f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and G < K and W % G == 0 and K % G == 0
+                  else f"replays of a HIP graph of {G} steps (+ {K % G} eager launches)" if graph is not None
+                  else "eager launches")
         out["timed_region"] = {"wall_ms": elapsed * 1e3, "launches_ms": max(per_rank_kernel_ms) * K,
                                "exchange_ms": max(per_rank_exchange_ms), "exchange_share_of_wall": max(per_rank_exchange_ms) / (elapsed * 1e3),
-                               "protocol": ((f"{HEAD} eager launches, then " if HEAD else "") + f"ONE replay of a HIP graph of {K - HEAD} step launches + the pcgrl_reduce_episodes launch "
-                                            "(uploaded with hipGraphUpload, never launched before; the W warm-up steps are eager launches); `launches_ms` "
-                                            "includes that reduction launch"
-                                            if fuse_reduce else
-                                            f"{W // G} untimed + {K // G} timed replays of one HIP graph of {G} steps" if graph is not None and K < 250 and G and G < K and W % G == 0 and K % G == 0
-                                            else f"replays of a HIP graph of {G} steps (+ {K % G} eager launches)" if graph is not None
-                                            else "eager launches")}
-        if world > 1:
-            out["timed_region"]["vs_single_gpu_line"] = (
-                "the N = 1 line's region holds no collective and no device->host copy (its reduction kernel writes pinned host memory; "
-                "`--gpus 1 --force-collective` runs this exchange with one rank): value(N) / (N * value(1)) therefore charges the exchange "
-                "itself, ~30 us of a ~165 us region at the driver's 20 steps, before any loss from adding ranks; "
-                "per_rank.launch_ms_per_step compares the launches alone")
+                               "protocol": region}
+        if use_coll:
+            tr = out["timed_region"]
+            tr["exchange"] = args.exchange
+            if overlap:
+                # Structure check for whoever computes value(N) / (N x value(1)): the share of this region that the N = 1 region
+                # (K launches + reduction launch + one synchronise, no process group) has as well.  `exchange_ms` is what of the
+                # side stream's all-gather + copy was still running when the stepping stream had finished (0: fully hidden).
+                tr["protocol_efficiency_bound"] = max(0.0, 1.0 - tr["exchange_ms"] / tr["wall_ms"])
+                tr["structure"] = ("the N = 1 region's: K step launches + the reduction launch + ONE synchronise per rank, maximum over the ranks; "
+                                   "the all-gather + device->host copy of the previous interval's sums run on a side stream meanwhile and the "
+                                   "host reads them at the end of the region (`previous_interval_sums`); no rank waits for another inside the region")
+                tr["previous_interval_sums"] = prev_interval
+            else:
+                tr["protocol_efficiency_bound"] = max(0.0, 1.0 - tr["exchange_ms"] / tr["wall_ms"])
+                tr["structure"] = ("round 5's: reduction -> all-gather -> device->host copy BEHIND the K launches; the N = 1 line's region holds "
+                                   "no collective and no copy, so value(N) / (N x value(1)) charges the exchange itself before any loss from adding ranks")
         if closed is not None:
             out["closed_loop_device_actions"] = closed
         if solver_active:
@@ -789,6 +854,7 @@ def main():
             pass
         sys.stderr.flush()
         print(json.dumps(out), flush=True)
+    watchdog.cancel()
 
 
 def gpus_without_runtime():

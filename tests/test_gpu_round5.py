@@ -38,41 +38,51 @@ def _bench(*argv, env=None, timeout=900):
 
 # ------------------------------------------------------------------------------------- RCCL with one rank (SURVEY 8 e)
 def test_bench_force_collective_runs_rccl_with_one_rank():
-    """bench.py --gpus 1 --force-collective: a world-size-1 "nccl" (= RCCL) process group, the timed region closed by the
-    N > 1 exchange (pcgrl_reduce_episodes launch -> device all-reduce -> device->host copy), step launches replayed from
-    a HIP graph captured while the RCCL watchdog thread is alive.  800 steps of a 770-step episode: the all-reduced
-    episode count is exactly the batch."""
-    out = _bench("--gpus", "1", "--force-collective", "--envs", "256", "--steps", "800", "--warmup", "0", "--no-cpu-baseline",
+    """bench.py --gpus 1 --force-collective: a world-size-1 "nccl" (= RCCL) process group; the timed region is K launches +
+    the pcgrl_reduce_episodes launch + one synchronise while the all-gather + device->host copy of the PREVIOUS interval's
+    sums run on a side stream (round 6); step launches replayed from a HIP graph captured while the RCCL watchdog thread is
+    alive.  800 warm-up + 800 timed steps of a 770-step episode: each interval's gathered episode count is exactly the batch."""
+    out = _bench("--gpus", "1", "--force-collective", "--envs", "256", "--steps", "800", "--warmup", "800", "--no-cpu-baseline",
                  "--rollout-steps", "0", "--closed-loop-steps", "0")
     pr = out["per_rank"]
-    assert pr["collective"].startswith("nccl all-gather"), pr
+    assert pr["collective"].startswith("nccl all-gather") and "side stream" in pr["collective"], pr
     assert out["config"]["launch"].startswith("HIP graph"), out["config"]["launch"]
     assert out["episodes"]["episodes"] == 256.0 and pr["episodes"] == [256.0]
     assert out["episodes"]["mean_length"] == 770.0
-    assert np.isfinite(pr["exchange_ms"][0]) and pr["exchange_ms"][0] > 0
     tr = out["timed_region"]
-    assert tr["wall_ms"] > 0 and 0 < tr["exchange_share_of_wall"] < 1
+    assert tr["exchange"] == "overlap" and tr["previous_interval_sums"][2] == 256.0 and tr["previous_interval_sums"][1] == 256.0 * 770
+    assert np.isfinite(pr["exchange_ms"][0]) and pr["exchange_ms"][0] >= 0
+    assert tr["wall_ms"] > 0 and 0.9 <= tr["protocol_efficiency_bound"] <= 1.0, tr
+    # round 5's region (the exchange behind the launches, as the closing barrier) stays selectable
+    ser = _bench("--gpus", "1", "--force-collective", "--exchange", "serial", "--envs", "256", "--steps", "800", "--warmup", "0",
+                 "--no-cpu-baseline", "--rollout-steps", "0", "--closed-loop-steps", "0")
+    assert ser["episodes"]["episodes"] == 256.0 and ser["per_rank"]["exchange_ms"][0] > 0
+    assert ser["timed_region"]["exchange"] == "serial" and "closing barrier" in ser["per_rank"]["collective"]
 
 
 def test_bench_driver_protocol_with_collective():
     """the driver's own command line (--steps 20 --warmup 5) through the collective path: the whole timed region is one
-    HIP graph (20 step launches + the reduction launch), then the all-reduce; the line carries the exchange cost, the
-    closed-loop figure and the sub-batch figure; the gcd protocol is still selectable"""
+    HIP graph (20 step launches + the reduction launch) with the previous interval's all-gather on a side stream; the
+    region is within a few per cent of the N = 1 region's (today's bar is 5 %; the test allows for
+    run-to-run noise of single 160 us regions); the line carries the closed-loop and sub-batch figures; the gcd protocol
+    is still selectable"""
     out = _bench("--gpus", "1", "--force-collective", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0",
                  "--rllib-adapter", "0", "--closed-loop-steps", "500", "--sub-batches", "2")
     assert out["steps"] == 20 and out["warmup"] == 5
     assert out["config"]["launch"] == "HIP graph of 20 steps per replay"
     assert out["timed_region"]["protocol"].startswith("ONE replay of a HIP graph of 20 step launches + the pcgrl_reduce_episodes")
+    assert out["timed_region"]["protocol_efficiency_bound"] >= 0.95, out["timed_region"]
     sb = out["async_sub_batches"]
     assert "error" not in sb and [r["sub_batches"] for r in sb["rows"]] == [1, 2]
     g = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0", "--rllib-adapter", "0",
                "--closed-loop-steps", "0", "--sub-batches", "", "--short-protocol", "gcd")
     assert g["timed_region"]["protocol"].startswith("1 untimed + 4 timed replays of one HIP graph of 5 steps")
-    # (experiment flag, kept alive: the exchange captured in the timed graph as well)
-    gc = _bench("--gpus", "1", "--force-collective", "--graph-collective", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-                "--rollout-steps", "0", "--rllib-adapter", "0", "--closed-loop-steps", "0", "--sub-batches", "")
-    assert "captured in the timed graph" in gc["per_rank"]["collective"], gc["per_rank"]
-    assert gc["episodes"]["episodes"] == 0.0 and gc["steps"] == 20
+    # the default N = 1 region (no process group) against the same region with the overlapped exchange: best of three each
+    def best(*extra):
+        return min(_bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--rollout-steps", "0", "--rllib-adapter", "0",
+                          "--closed-loop-steps", "0", "--sub-batches", "", *extra)["timed_region"]["wall_ms"] for _ in range(3))
+    plain, coll = best(), best("--force-collective")
+    assert coll <= 1.15 * plain, (plain, coll)
     cl = out["closed_loop_device_actions"]
     assert "error" not in cl, cl
     assert cl["steps"] == 500 and cl["us_per_step"] > 0

@@ -4,6 +4,7 @@ episodic-return reduction works over gloo (world_size 2)."""
 import os
 import re
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -185,6 +186,20 @@ def test_bench_launches_its_own_ranks_dry_run():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_bench_rank_that_hangs_exits_nonzero():
+    """a rank that never reaches the rendezvous ends itself with exit code 3 after PCGRL_BENCH_RANK_TIMEOUT (never a re-exec,
+    never an in-process fallback), the launcher stops the other rank and the run fails -- instead of hanging in a collective"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PCGRL_BENCH_TEST_HANG_RANK="1", PCGRL_BENCH_RANK_TIMEOUT="6")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--envs", "100"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0, r.stdout + r.stderr
+    assert "did not finish within" in r.stderr and "rank 1 exited with code 3" in r.stderr, r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no line from a failed run"
+    assert time.time() - t0 < 120
 
 
 def test_bench_solver_active_maps_are_playable():
