@@ -14,4 +14,4 @@ from .envs import make_env, PcgrlGymEnv  # noqa: F401
 from .rllib_env import PcgrlVectorEnv  # noqa: F401
 from .dist import EpisodeStatsReducer, shard_env_range  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.6.0"  # csrc/pcgrl_engine.hip pcgrl_version() carries the same number

@@ -77,6 +77,11 @@ SYMBOLS = {
     "pcgrl_poll_error": (C.c_int, [C.c_void_p]),
     "pcgrl_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "pcgrl_num_actions": (C.c_int32, [C.c_void_p]),
+    "pcgrl_set_solver_budget": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pcgrl_get_solver_budget": (C.c_int32, [C.c_void_p]),
+    "pcgrl_step_ready": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "pcgrl_env_busy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_reserve_solver_pool": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pcgrl_solver_pool_slots": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pcgrl_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -43,7 +43,8 @@ struct alignas(16) EnvState {
   // second 128-byte line: only touched when an episode ends (same base address as the hot line: no extra address registers
   // in the step kernel, whose occupancy at large batches hangs on a handful of VGPRs)
   EpAcc acc;
-  uint8_t pad_[40];
+  int32_t pend_action;  // asynchronous stepping (ENV_PENDING_STEP): the action of the step that waits for its search
+  uint8_t pad_[36];
 };
 static_assert(sizeof(EnvState) == 256, "EnvState must be two 128-byte lines");
 static_assert(offsetof(EnvState, acc) == 128, "the episode totals start the second line");
@@ -53,6 +54,16 @@ static_assert(offsetof(EnvState, acc) == 128, "the episode totals start the seco
 //                    refreshed: the next CHANGING step recomputes them from scratch, exactly like the reference's
 //                    get_stats (pcgrl_env.py:314-323); cleared by that step, pcgrl_refresh_stats and every reset.
 constexpr int32_t ENV_STATS_DIRTY = 1;
+// Asynchronous stepping (pcgrl_step_ready, sokoban: the device solver works to a per-launch iteration budget and parks an
+// unfinished search in the env's own workspace, pcgrl_sokoban.h "resumable"):
+//   ENV_PENDING_STEP   the env has taken an action (pend_action) whose statistics wait for a parked search.  The record still
+//                      holds the state BEFORE that step; every launch re-plays the step up to the solver call and resumes the
+//                      search there, and the launch in which it ends completes the step and emits its outputs.
+//   ENV_PENDING_STATS  the map is final (a reset, explicit or automatic) but its statistics -- and with them last_loss -- wait
+//                      for a parked search: the env takes no action until a launch has finished them.
+// Either way the env is BUSY: it ignores the actions it is handed and its output rows are not written.
+constexpr int32_t ENV_PENDING_STEP = 2;
+constexpr int32_t ENV_PENDING_STATS = 4;
 
 
 
@@ -88,6 +99,10 @@ struct Params {
   int32_t int_targets;
   int32_t spread;         // sokoban step: one env per wave pair (see step_kernel)
   int32_t sk_helpers;     // sokoban: A* stages run by helper wavefronts (0 or 3; two waves per stage, see pcgrl_sokoban.h)
+  // asynchronous stepping (pcgrl_step_ready): solver iteration units per env and launch (0 = synchronous) and the per-env
+  // status byte of the launch (PCGRL_ENV_EMITTED | PCGRL_ENV_BUSY); the per-env workspaces hang off the SokoPool
+  int32_t sk_budget;
+  uint8_t *ready;
   // per-call I/O
   const int32_t *actions;
   uint8_t *obs;
@@ -104,7 +119,6 @@ struct Params {
   // pcgrl_set_state (reset kernel with init_grids): counters / loss / return to restore, any may be null
   const int32_t *in_counters;   // [N][4] iteration, changes, n_step, (ignored)
   const double *in_ep_return;   // [N]
-  int32_t set_state;
   // get_state outputs
   uint8_t *out_grids;
   int32_t *out_pos;
@@ -123,6 +137,7 @@ struct Params {
   int32_t ext;              // 1 when static tiles or an action patch are configured (selects the general kernels)
   int32_t n_act;            // action entries per env: prod(act_window) or 1
   int32_t lds_pair_bytes;   // LDS bytes of one (simulate, observe) wave pair of the step kernel
+  int32_t set_state;        // pcgrl_set_state (see in_counters; here: it fills the padding, the block stays within 14 lines)
   void *xplanes;            // M[N][1+NB][H]: static mask in map coordinates, then the lagging bordered-map tile planes
   uint32_t *xstate;         // [N][4]: flags (bit 0: bordered map lags behind the map), rep-RNG spare 32 bits: has, value
   const JumpEntry *jump_b;  // [H+3]: skip r*(W+2) draws (rows of the bordered static mask)

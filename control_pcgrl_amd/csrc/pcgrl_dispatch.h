@@ -68,6 +68,26 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
   const unsigned helper_threads = PROB == PCGRL_PROB_SOKOBAN ? 2u * 64u * (unsigned)p.sk_helpers : 0u;  // (heap + expander wave per stage)
   const size_t helper_lds = PROB == PCGRL_PROB_SOKOBAN ? (size_t)p.sk_helpers * SK_HELPER_LDS : 0;  // (their A* heaps)
   hipError_t e = hipSuccess;
+  if constexpr (PROB == PCGRL_PROB_SOKOBAN) {
+    // asynchronous stepping (pcgrl_step_ready / pcgrl_reset with a solver budget): the resumable-solver variants, one env per
+    // workgroup of two waves (simulate, observe), no helper waves
+    if (p.sk_budget > 0 && id == K_STEP) {
+      const dim3 g1(p.n_envs);
+      if constexpr (LPE == 16 && sizeof(M) == 4) {
+        if (fast) {
+          hipLaunchKernelGGL((step_kernel<PROB, LPE, M, true, false, 1, true>), g1, dim3(128), lds, s, p);
+          return hipGetLastError();
+        }
+      }
+      if ((e = allow_lds(step_kernel<PROB, LPE, M, false, false, 1, true>, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((step_kernel<PROB, LPE, M, false, false, 1, true>), g1, dim3(128), lds, s, p);
+      return hipGetLastError();
+    }
+    if (p.sk_budget > 0 && id == K_RESET) {
+      hipLaunchKernelGGL((reset_kernel<PROB, LPE, M, true>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+  }
   switch (id) {
     case K_STEP:
       if constexpr (LPE == 16 && sizeof(M) == 4) {

@@ -48,6 +48,8 @@ struct pcgrl_engine {
   int soko_slots = 0;            // sokoban: workspace slots of the current pool (p.soko)
   int32_t seen_last = 0, spread_left = 0;
   bool soko_lazy = true;         // grow the solver pool by itself the first time the solver has been seen running
+  int sk_budget = 0;             // sokoban, asynchronous stepping: solver iteration units per env and launch (0 = synchronous)
+  void *sk_ws = nullptr, *sk_park = nullptr;  // ... and its per-env stage workspaces / park records (also in the device SokoPool)
   bool soko_grow_failed = false; // the last growth attempt failed (message in soko_grow_msg): not retried by itself
   std::string soko_grow_msg;
   uint8_t *hdr_host = nullptr;   // pinned: the 256-byte header of pcgrl_export_state images (rebuilt by pcgrl_set_static)
@@ -461,6 +463,12 @@ __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, 
   }
 }
 
+// pcgrl_env_busy: 1 = the env waits for a parked search (asynchronous stepping)
+__global__ __launch_bounds__(256) void env_busy_kernel(Params p, uint8_t *out) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env < p.n_envs) out[env] = (p.st[env].flags & (ENV_PENDING_STEP | ENV_PENDING_STATS)) != 0 ? 1 : 0;
+}
+
 // pcgrl_import_state with a mask: rows (envs) of one state array, 4 bytes per thread
 __global__ __launch_bounds__(256) void masked_rows_copy_kernel(uint32_t *dst, const uint32_t *src, int64_t words_per_env, int32_t n_envs,
                                                               const uint8_t *mask) {
@@ -489,7 +497,7 @@ static int soko_pool_for(pcgrl_engine *h, Params &p, int want, hipStream_t strea
   }
   Params grown = h->p;
   int got = 0;
-  const hipError_t e = sokoban_alloc(grown, h->allocs, want, &got);
+  const hipError_t e = sokoban_alloc(grown, h->allocs, want, &got, h->sk_ws, h->sk_park);
   if (e == hipSuccess) {
     h->p.soko = grown.soko;
     p.soko = grown.soko;
@@ -542,7 +550,7 @@ static void choose_spread(pcgrl_engine *h, Params &p) {
 extern "C" {
 
 const char *pcgrl_last_error(void) { return g_err.c_str(); }
-const char *pcgrl_version(void) { return "pcgrl_amd 0.3 (gfx950)"; }
+const char *pcgrl_version(void) { return "pcgrl_amd 0.6.0 (gfx950)"; }
 
 int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_handle *out) {
   if (!cfg || !out || n_envs < 1) return fail(PCGRL_EINVAL, "pcgrl_create: bad arguments");
@@ -745,14 +753,21 @@ int pcgrl_reset(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_init_gri
   p.mask = d_mask;
   p.init_grids = d_init_grids;
   p.init_pos = d_init_pos;
+  p.sk_budget = h->sk_budget;  // (asynchronous stepping: a playable level's search may stay parked, the env busy)
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   if (d_mask == nullptr) h->maybe_stale = false;
   return PCGRL_OK;
 }
 
+#define NOT_WITH_BUDGET(h, what)                                                                                         \
+  if ((h)->sk_budget > 0)                                                                                                \
+  return fail(PCGRL_EINVAL, std::string(what) + ": a solver budget is set (pcgrl_set_solver_budget): envs may be busy, which only " \
+                                                "pcgrl_step_ready can report")
+
 int pcgrl_step(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done,
                int32_t *d_stats, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step: bad arguments");
+  NOT_WITH_BUDGET(h, "pcgrl_step");
   ON_DEVICE(h->device);
   Params p = h->p;
   p.no_fast = h->maybe_stale ? 1 : 0;
@@ -784,6 +799,7 @@ int pcgrl_step_seq(pcgrl_handle h, const int32_t *d_action_rows, int64_t row_str
 int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward,
                   double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_step_ex: bad arguments");
+  NOT_WITH_BUDGET(h, "pcgrl_step_ex");
   ON_DEVICE(h->device);
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_step_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   Params p = h->p;
@@ -823,6 +839,7 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs,
                      void *stream) {
   if (!h || !d_actions || n_steps < 1) return fail(PCGRL_EINVAL, "pcgrl_rollout: bad arguments");
+  NOT_WITH_BUDGET(h, "pcgrl_rollout");
   if (d_ctrl_obs && h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_rollout_ex: d_ctrl_obs needs cfg.n_ctrl > 0");
   if (rollout_as_steps(h)) {
     const size_t N = (size_t)h->p.n_envs;
@@ -864,6 +881,7 @@ int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int
 
 int pcgrl_update(pcgrl_handle h, const int32_t *d_actions, uint8_t *d_obs, void *stream) {
   if (!h || !d_actions) return fail(PCGRL_EINVAL, "pcgrl_update: bad arguments");
+  NOT_WITH_BUDGET(h, "pcgrl_update");
   ON_DEVICE(h->device);
   Params p = h->p;
   p.actions = d_actions;
@@ -880,6 +898,7 @@ int pcgrl_refresh_stats(pcgrl_handle h, int32_t *d_stats, void *stream) {
   Params p = h->p;
   p.refresh_only = 1;
   p.stats_out = d_stats;
+  p.sk_budget = h->sk_budget;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   h->maybe_stale = false;
   return PCGRL_OK;
@@ -1089,6 +1108,7 @@ int pcgrl_set_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_grid
   p.in_counters = d_counters;
   p.in_ep_return = d_ep_return;
   p.set_state = 1;
+  p.sk_budget = h->sk_budget;
   HIPCHK(launch(K_RESET, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   if (d_mask == nullptr) h->maybe_stale = false;
   return PCGRL_OK;
@@ -1246,6 +1266,66 @@ int pcgrl_sample_actions(pcgrl_handle h, int32_t *d_actions, uint64_t seed, void
   const int32_t n = h->p.n_envs * h->p.n_act;
   hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_actions, n,
                      (uint32_t)num_actions_of(h), seed, h->sample);
+  HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_set_solver_budget(pcgrl_handle h, int32_t budget) {
+  if (!h || budget < 0) return fail(PCGRL_EINVAL, "pcgrl_set_solver_budget: bad arguments");
+  if (h->p.cfg.problem != PCGRL_PROB_SOKOBAN || !h->p.soko)
+    return fail(PCGRL_EUNSUPPORTED, "pcgrl_set_solver_budget: only sokoban has a device solver");
+  if (h->p.ext || h->p.cfg.n_ctrl > 0)
+    return fail(PCGRL_EUNSUPPORTED, "pcgrl_set_solver_budget: asynchronous stepping is built for sokoban without static tiles, action "
+                                    "patches or control metrics");
+  ON_DEVICE(h->device);
+  if (budget > 0 && h->sk_ws == nullptr) {  // one stage workspace + one park record per env, once
+    HIPCHK(hipDeviceSynchronize());
+    const hipError_t e = sokoban_alloc_async(h->p, h->allocs, h->p.n_envs, &h->sk_ws, &h->sk_park);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(PCGRL_EHIP, std::string("pcgrl_set_solver_budget: allocating one solver workspace per env: ") + hipGetErrorString(e));
+    }
+  }
+  if (budget == 0 && h->sk_budget > 0) {  // back to synchronous stepping: nobody may be waiting for a parked search
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<EnvState> st(h->p.n_envs);
+    HIPCHK(hipMemcpy(st.data(), h->p.st, st.size() * sizeof(EnvState), hipMemcpyDeviceToHost));
+    for (auto &e : st)
+      if (e.flags & (ENV_PENDING_STEP | ENV_PENDING_STATS))
+        return fail(PCGRL_EINVAL, "pcgrl_set_solver_budget(0): an env is still busy (a parked search): keep stepping with pcgrl_step_ready "
+                                  "or reset the envs first");
+  }
+  h->sk_budget = budget;
+  return PCGRL_OK;
+}
+
+int32_t pcgrl_get_solver_budget(pcgrl_handle h) { return h ? h->sk_budget : -1; }
+
+int pcgrl_step_ready(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done,
+                     int32_t *d_stats, uint8_t *d_status, void *stream) {
+  if (!h || !d_actions || !d_status) return fail(PCGRL_EINVAL, "pcgrl_step_ready: bad arguments");
+  if (h->sk_budget <= 0) return fail(PCGRL_EINVAL, "pcgrl_step_ready: no solver budget set (pcgrl_set_solver_budget)");
+  ON_DEVICE(h->device);
+  Params p = h->p;
+  p.no_fast = h->maybe_stale ? 1 : 0;
+  p.spread = 1;  // one env per workgroup: every search has a wavefront of its own
+  p.sk_helpers = 0;
+  p.sk_budget = h->sk_budget;
+  p.actions = d_actions;
+  p.auto_reset = auto_reset;
+  p.obs = d_obs;
+  p.reward = d_reward;
+  p.done = d_done;
+  p.stats_out = d_stats;
+  p.ready = d_status;
+  HIPCHK(launch(K_STEP, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
+  return PCGRL_OK;
+}
+
+int pcgrl_env_busy(pcgrl_handle h, uint8_t *d_busy, void *stream) {
+  if (!h || !d_busy) return fail(PCGRL_EINVAL, "pcgrl_env_busy: bad arguments");
+  ON_DEVICE(h->device);
+  hipLaunchKernelGGL(env_busy_kernel, dim3((h->p.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->p, d_busy);
   HIPCHK(hipGetLastError());
   return PCGRL_OK;
 }

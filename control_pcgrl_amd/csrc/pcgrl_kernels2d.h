@@ -645,6 +645,10 @@ __device__ __attribute__((always_inline)) inline void touch_kernarg(const Params
 template <int LPE, typename M, bool HUGE>
 __device__ void sokoban_solve(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player, M crate, M target,
                               int &dist_win, int &sol_len);
+// asynchronous stepping: the solver to a per-launch budget, on the env's own workspace (pcgrl_sokoban.h "resumable solver")
+template <int LPE, typename M>
+__device__ bool sokoban_solve_async(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player, M crate, M target,
+                                    const M *planes, int &dist_win, int &sol_len);
 // helper wavefronts of the solver (pcgrl_sokoban.h): kernels launched with Params::sk_helpers carry three of them per
 // workgroup, behind the simulate / observe waves
 __device__ inline void sokoban_helper(const Params &p, int k, uint32_t *lds_heap);
@@ -711,9 +715,11 @@ __device__ inline int regions_update(const Grp<LPE> &g, M x, M w_old, M w_new, i
 
 // regions_known >= 0: the caller already has the region count (incremental update in the step kernel)
 // SK_HUGE (sokoban): also the search for levels with more than 128 crate / target pairs (false in the 16x16 kernels)
-template <int PROB, int LPE, typename M, bool SK_HUGE = true>
+// SKA (sokoban, asynchronous stepping): the solver works to Params::sk_budget and may leave the search parked: *unfinished
+// (uniform over a group) then tells the caller that dist-win / sol-length are not in yet and the statistics must not be used
+template <int PROB, int LPE, typename M, bool SK_HUGE = true, bool SKA = false>
 __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env, bool active, M *b, M colmask, int32_t *st,
-                                     int regions_known = -1) {
+                                     int regions_known = -1, bool *unfinished = nullptr) {
   if constexpr (PROB == PCGRL_PROB_BINARY) {
     // binary_prob.py:152-158: regions and path-length over "empty" (tile 0); b[1], b[2] receive fars / best
     M pass = active ? (~b[0] & colmask) : M(0);
@@ -782,7 +788,13 @@ __device__ inline void compute_stats(const Grp<LPE> &g, const Params &p, int env
     int sol_len = 0;
     bool need = active && n_player == 1 && n_crate == n_target && n_crate > 0 && regions == 1;
     if (__ballot(need) != 0) {
-      sokoban_solve<LPE, M, SK_HUGE>(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
+      if constexpr (SKA) {
+        const M lvl[3] = {b[0] & cm, b[1] & cm, b[2] & cm};
+        const bool u = sokoban_solve_async<LPE, M>(g, p, env, need, solid, player, crate, target, lvl, dist_win, sol_len);
+        if (unfinished != nullptr) *unfinished = u;
+      } else {
+        sokoban_solve<LPE, M, SK_HUGE>(g, p, env, need, solid, player, crate, target, dist_win, sol_len);
+      }
     }
     st[0] = n_player;
     st[1] = n_crate;
@@ -1726,10 +1738,10 @@ __device__ inline void encode_obs_static(const Grp<LPE> &g, const Params &p, int
 //   multi   several cells may have changed at once (representation wrappers); never set in the FAST kernels
 // binary: incremental around the edited cell(s), b[1] / b[2] (fars / best) are maintained;
 // zelda / sokoban: full refresh with the region count updated around the edited cell when it is a one-cell edit.
-template <int PROB, int LPE, typename M, bool FAST>
+template <int PROB, int LPE, typename M, bool FAST, bool SKA = false>
 __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, bool restat, bool multi, M tile0_old,
                                      const M *pre, M *b, M colmask, int32_t *st PHASE_ARG, bool have_pre = false,
-                                     M preflood = M(0)) {
+                                     M preflood = M(0), bool *unfinished = nullptr) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS;
   const bool full = PROB != PCGRL_PROB_BINARY && restat;  // binary: always incremental around the edited cell(s)
   if (__ballot(full) != 0) {
@@ -1748,7 +1760,7 @@ __device__ inline void refresh_stats(const Grp<LPE> &g, const Params &p, int e, 
         regions_known = one ? r : -1;
       }
     }
-    compute_stats<PROB, LPE, M, !FAST>(g, p, e, full, b, colmask, ns, regions_known);
+    compute_stats<PROB, LPE, M, !FAST, SKA>(g, p, e, full, b, colmask, ns, regions_known, unfinished);
     if (full) {
 #pragma unroll
       for (int k = 0; k < NS; k++) st[k] = ns[k];
@@ -1820,14 +1832,17 @@ __device__ inline void accumulate_episode(EnvState *S) {
 // PAIRS (simulate, observe) wave pairs share a workgroup: 2 for the binary 16x16 kernel (512 instead of 1 024
 // workgroups to dispatch at 4096 envs: 6.65 -> 6.57 us per launch; 4 pairs are slower, 7.7 us; zelda, whose launch is
 // bound by its observation stores, is faster with 1).
-template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1>
+// SKA (sokoban): asynchronous stepping (pcgrl_step_ready) -- one env per workgroup (Params::spread), the solver to a budget
+// on the env's own workspace, no helper waves; an env whose search is parked leaves the launch without committing anything
+// but its pending flag (EnvState::flags) and reports itself busy in Params::ready.
+template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1, bool SKA = false>
 #ifndef PCGRL_B64_WAVES
 #define PCGRL_B64_WAVES 6  // waves per SIMD the binary 64-bit-mask step kernel is compiled for (development: A/B builds)
 #endif
 #ifndef PCGRL_STEP_WAVES
 #define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
 #endif
-__global__ __launch_bounds__(PROB == PCGRL_PROB_SOKOBAN ? 512 : 128 * PAIRS,
+__global__ __launch_bounds__((PROB == PCGRL_PROB_SOKOBAN && !SKA) ? 512 : 128 * PAIRS,
                              (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? PCGRL_B64_WAVES : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : ((FAST && PROB == PCGRL_PROB_SOKOBAN && !CTRL) ? 4 : 1))))
 void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
@@ -1843,8 +1858,8 @@ void step_kernel(Params p) {
   const bool observer = (wave & 1) != 0;  // wave-uniform
   uint8_t *lds = lds_all + (size_t)pair * p.lds_pair_bytes;
   // sokoban, launched with p.sk_helpers (while its solver is busy): waves 2.. are the solver's helpers
-  const bool helped = PROB == PCGRL_PROB_SOKOBAN && p.sk_helpers != 0;
-  if constexpr (PROB == PCGRL_PROB_SOKOBAN) {
+  const bool helped = PROB == PCGRL_PROB_SOKOBAN && !SKA && p.sk_helpers != 0;
+  if constexpr (PROB == PCGRL_PROB_SOKOBAN && !SKA) {
     if (wave >= 2 * PAIRS) {
       if (wave == 2 * PAIRS) sokoban_helpers_init();
       __syncthreads();
@@ -1897,7 +1912,17 @@ void step_kernel(Params p) {
   EnvState *S = &p.st[e];
   int pos[2] = {S->pos[0], S->pos[1]};
   int n_step = S->n_step, iteration = S->iteration, changes = S->changes;
-  const int action = active ? p.actions[e] : 0;
+  int action = active ? p.actions[e] : 0;
+  // asynchronous stepping: a pending step is re-played with the action it took; an env whose reset still waits for its
+  // statistics plays no step at all
+  bool pend_step = false, pend_stats = false;
+  if constexpr (SKA) {
+    const int fl = active ? S->flags : 0;
+    pend_step = (fl & ENV_PENDING_STEP) != 0;
+    pend_stats = (fl & ENV_PENDING_STATS) != 0;
+    if (pend_step) action = S->pend_action;
+  }
+  const bool stepping = active && !pend_stats;
   // An auto-reset of this step replays the env's RNG streams in BOTH waves; the simulate wave stores the advanced
   // streams at the end of the launch, so the observe wave takes its copy before the barrier (like every other piece
   // of old state).  The copy waits in LDS (behind the pair's observation rows) so that it costs no registers meanwhile.
@@ -1915,17 +1940,17 @@ void step_kernel(Params p) {
   // envs/pcgrl_env.py:267-342
   bool bad = false;
   const bool upd_only = p.update_only != 0;  // evolution-driver pattern: rep.update() without PcgrlEnv.step()
-  iteration += upd_only ? 0 : 1;
+  iteration += (upd_only || pend_stats) ? 0 : 1;
   bool change, map_changed, multi = false;
   if (ext) {
     change = rep_update_ext<PROB, LPE, M>(g, p, e, active, action, b, pos, n_step, bad, X, map_changed, multi);
   } else {
-    change = rep_update<PROB, LPE, M, FAST>(g, p, active, action, b, pos, n_step, bad);
+    change = rep_update<PROB, LPE, M, FAST>(g, p, SKA ? stepping : active, action, b, pos, n_step, bad);
     map_changed = change;
   }
   changes += (change && !upd_only) ? 1 : 0;
-  bool done = !upd_only && iteration > p.cfg.max_iterations;
-  if (p.cfg.max_changes >= 0) done = done || (!upd_only && changes > p.cfg.max_changes);
+  bool done = !upd_only && !pend_stats && iteration > p.cfg.max_iterations;
+  if (p.cfg.max_changes >= 0) done = done || (!upd_only && !pend_stats && changes > p.cfg.max_changes);
   const bool do_reset = active && done && p.auto_reset != 0;
 
   if (observer) {
@@ -1960,8 +1985,27 @@ void step_kernel(Params p) {
   int32_t st[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) st[k] = S->stats[k];
-  if (bad && g.row == 0 && active) atomicOr(p.err, 1);
+  if (bad && g.row == 0 && (SKA ? stepping : active)) atomicOr(p.err, 1);
   PHASE_MARK(1);  // action + second state loads
+  if constexpr (SKA) {
+    // a reset (explicit or automatic) whose statistics wait for a parked search: the search goes on; the launch in which it
+    // ends gives the env its statistics and loss base, and it takes the NEXT launch's action
+    if (__ballot(pend_stats) != 0) {  // (one env per wave: wave-uniform)
+      int32_t ns[NS];
+      bool unfin = false;
+      compute_stats<PROB, LPE, M, !FAST, true>(g, p, e, pend_stats, b, colmask, ns, -1, &unfin);
+      if (pend_stats && g.row == 0) {
+        if (!unfin) {
+#pragma unroll
+          for (int k = 0; k < NS; k++) S->stats[k] = ns[k];
+          S->last_loss = get_loss<NS>(p, ns);
+          S->flags = flags & ~ENV_PENDING_STATS;
+        }
+        if (p.ready) p.ready[e] = unfin ? (uint8_t)PCGRL_ENV_BUSY : (uint8_t)0;
+      }
+      return;
+    }
+  }
   if (upd_only) {  // grid / position only; the stats (and the binary fars / best masks) go stale: ENV_STATS_DIRTY
     if (change) store_planes<NB, M, FAST>(p, e, g.row, rowok, b);
     if (change && map_changed && active && g.row == 0) S->flags = flags | ENV_STATS_DIRTY;
@@ -1982,7 +2026,7 @@ void step_kernel(Params p) {
   // (Params::no_fast), which also drops the PREFLOOD plane it does not maintain.
   // (stale: whenever the representation reports a change -- also a build that static tiles undid: the reference then calls
   // get_stats on the current map, which the pcgrl_update calls before have edited)
-  const bool stale = !FAST && (flags & ENV_STATS_DIRTY) != 0 && change;
+  const bool stale = !FAST && !SKA && (flags & ENV_STATS_DIRTY) != 0 && change;  // (pcgrl_update is refused in asynchronous mode)
   if constexpr (FAST) {
     // Which kernel runs is a HOST decision (Params::no_fast) that a captured HIP graph freezes: a graph captured before
     // pcgrl_update and replayed after it lands here with stale statistics.  Never silently: the launch raises error
@@ -2001,8 +2045,24 @@ void step_kernel(Params p) {
       flags &= ~ENV_STATS_DIRTY;
     }
   }
-  refresh_stats<PROB, LPE, M, FAST>(g, p, e, change && map_changed && !stale, multi, tile0_old, pre, b, colmask, st PHASE_PASS,
-                                    PRE && g.gany((pre3 & (M)PRE_VALID) != 0), pre3 & colmask);
+  bool unfin = false;
+  refresh_stats<PROB, LPE, M, FAST, SKA>(g, p, e, change && map_changed && !stale, multi, tile0_old, pre, b, colmask, st PHASE_PASS,
+                                         PRE && g.gany((pre3 & (M)PRE_VALID) != 0), pre3 & colmask, SKA ? &unfin : nullptr);
+  if constexpr (SKA) {
+    // the search of this step's level did not end within the launch's budget: it is parked (sokoban_solve_async) and NOTHING
+    // of the step is committed but the action it took -- the next launch re-plays the step from the same state up to here
+    if (__ballot(unfin) != 0) {  // (one env per wave: wave-uniform)
+      if (active && g.row == 0) {
+        if (!pend_step) {
+          S->flags = flags | ENV_PENDING_STEP;
+          S->pend_action = action;
+        }
+        if (p.ready) p.ready[e] = (uint8_t)PCGRL_ENV_BUSY;
+      }
+      return;
+    }
+    flags &= ~ENV_PENDING_STEP;
+  }
   PHASE_MARK(2);  // whole stats refresh
   // control_wrappers.py:216-244
   // CTRL (controllable mode) is a compile-time variant so that the plain kernel carries none of its code
@@ -2033,14 +2093,17 @@ void step_kernel(Params p) {
     if (do_reset && g.row == 0) latch_episode<NS>(p, e, S, ep_return, iteration, st);
     reset_from_rng<PROB, LPE, M>(g, p, e, do_reset, b, pos, /*commit=*/true, ext ? &X : nullptr);
     int32_t ns[NS];
-    compute_stats<PROB, LPE, M, !FAST>(g, p, e, do_reset, b, colmask, ns);
+    bool unfin2 = false;
+    compute_stats<PROB, LPE, M, !FAST, SKA>(g, p, e, do_reset, b, colmask, ns, -1, SKA ? &unfin2 : nullptr);
     if (do_reset) {
 #pragma unroll
       for (int k = 0; k < NS; k++) st[k] = ns[k];
       iteration = 0;
       changes = 0;
       n_step = 0;
-      flags = 0;
+      // (asynchronous stepping: the new map's search is parked -- the step itself is complete and emitted, the env stays
+      // busy until a later launch has the new episode's statistics and loss base)
+      flags = (SKA && unfin2) ? ENV_PENDING_STATS : 0;
       ep_return = 0.0;
       if constexpr (!CTRL) {
         last_loss = get_loss<NS>(p, st);
@@ -2073,6 +2136,9 @@ void step_kernel(Params p) {
 #pragma unroll
     for (int k = 0; k < NS; k++) S->stats[k] = st[k];
     if (do_reset) accumulate_episode<NS>(S);
+    if constexpr (SKA) {
+      if (p.ready) p.ready[e] = (uint8_t)(PCGRL_ENV_EMITTED | ((flags & ENV_PENDING_STATS) ? PCGRL_ENV_BUSY : 0));
+    }
   }
   PHASE_MARK(6);  // loss, outputs, write-back
   PHASE_FLUSH();
@@ -2259,7 +2325,8 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   }
 }
 
-template <int PROB, int LPE, typename M>
+// SKA (sokoban, asynchronous stepping): a level whose search does not end within the budget leaves the env ENV_PENDING_STATS
+template <int PROB, int LPE, typename M, bool SKA = false>
 __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -2307,7 +2374,8 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
     reset_from_rng<PROB, LPE, M>(g, p, e, active, b, pos, /*commit=*/true, ext ? &X : nullptr);
   }
   int32_t st[NS];
-  compute_stats<PROB, LPE, M>(g, p, e, active, b, colmask, st);
+  bool unfin = false;
+  compute_stats<PROB, LPE, M, true, SKA>(g, p, e, active, b, colmask, st, -1, SKA ? &unfin : nullptr);
   store_planes<NW, M>(p, e, g.row, rowok, b);
   if constexpr (PROB == PCGRL_PROB_BINARY) {  // PREFLOOD plane: stale after a reset (map and position changed)
     if (rowok && !p.refresh_only) ((M *)p.planes)[((size_t)e * ROW_WORDS + PRE_PLANE) * H + g.row] = M(0);
@@ -2315,10 +2383,14 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   if (ext && !p.refresh_only) X.store(p, e, g.row, rowok, active && g.row == 0, true);
   if (p.refresh_only) {
     if (active && g.row == 0) {
+      if (SKA && unfin) {  // the statistics arrive with a later pcgrl_step_ready launch
+        S->flags = (S->flags & ~ENV_STATS_DIRTY) | ENV_PENDING_STATS;
+        return;
+      }
       EnvTargets<NS> trg;
       trg.load(p, e, false);
       S->last_loss = trg.loss(p.cfg, st);
-      S->flags &= ~ENV_STATS_DIRTY;
+      S->flags &= ~(ENV_STATS_DIRTY | ENV_PENDING_STATS);
 #pragma unroll
       for (int k = 0; k < NS; k++) {
         S->stats[k] = st[k];
@@ -2334,7 +2406,7 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
     S->n_step = 0;
     S->iteration = 0;
     S->changes = 0;
-    S->flags = 0;
+    S->flags = (SKA && unfin) ? ENV_PENDING_STATS : 0;  // (a step that was pending is abandoned with the old map)
     S->ep_return = 0.0;
     if (p.set_state) {  // pcgrl_set_state: the map was injected above, the counters / return come from the caller
       if (p.in_counters) {

@@ -120,6 +120,9 @@ struct SokoPool {  // lives in Params-reachable global memory
   uint8_t *base;
   int32_t *locks;   // [n_slots] 0 = free
   uint32_t *epochs; // [n_slots][SK_STAGES]
+  // asynchronous stepping (pcgrl_set_solver_budget): one stage workspace and one park record (SkPark) per env, else null
+  uint8_t *async_ws;
+  void *async_park;
 };
 // hand-over between the simulate wave and the helper waves of its workgroup (LDS)
 struct SokoMail {
@@ -644,30 +647,74 @@ __device__ __attribute__((always_inline)) inline void sk_heappush(SokoCtx &c, in
   else sk_heappush_impl<false>(c, tail, item);
 }
 
+// Resumable form of a stage (asynchronous stepping, sokoban_solve_async): the search runs to an iteration budget per launch;
+// everything it needs to continue -- queue / heap, node records, visited table -- already lives in the env's own workspace,
+// so parking a search is saving these few wave-uniform words and resuming is loading them.  The pops, pushes and the visited
+// set are those of the uninterrupted stage: the loop body does not know about the budget.
+struct SkRes {
+  bool resume;   // in: continue the parked stage instead of starting it
+  bool parked;   // out: the stage stopped on the budget (state below saved)
+  int budget;    // in / out: iteration units left in this launch (a BFS iteration costs 1, an A* iteration 2)
+  int head, tail, n_nodes, best, best_h, best_depth, iters;
+  uint32_t epoch;  // the workspace's visited-table epoch counter (kept in the park record instead of SokoPool::epochs)
+};
+
 // `cancel` (helper-wave mode): the stage gives up as soon as *cancel < my_stage (its result is not needed).
-template <int NH>
+// RES: resumable form, `rs` carries the budget and the parked state (the synchronous kernels compile none of it).
+template <int NH, bool RES = false>
 __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const SokoPool &pool, int slot, int b2, int max_iter, int &res_h, int &res_depth,
-                                bool *exhausted = nullptr, const int32_t *cancel = nullptr, int my_stage = 0) {
-  uint32_t *epoch_word = &pool.epochs[slot * SK_STAGES + c.stage];
+                                bool *exhausted = nullptr, const int32_t *cancel = nullptr, int my_stage = 0, SkRes *rs = nullptr) {
   uint32_t ep = 0;
-  if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
-  ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
-  if (ep == 0) {  // wrapped: start over with a clean table
-    for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = sk_u32x4{0u, 0u, 0u, 0u};
+  if constexpr (!RES) {
+    uint32_t *epoch_word = &pool.epochs[slot * SK_STAGES + c.stage];
     if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
     ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+    if (ep == 0) {  // wrapped: start over with a clean table
+      for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = sk_u32x4{0u, 0u, 0u, 0u};
+      if (c.lane == 0) ep = (atomicAdd(epoch_word, 1u) + 1u) & 0x7FFFu;
+      ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+    }
+  } else {
+    (void)pool;
+    (void)slot;
+    if (rs->resume) {
+      ep = rs->epoch;
+    } else {
+      ep = (rs->epoch + 1u) & 0x7FFFu;
+      if (ep == 0) {  // wrapped: start over with a clean table
+        for (int i = c.lane; i < SK_VCAP; i += 64) c.vis[i] = sk_u32x4{0u, 0u, 0u, 0u};
+        ep = 1u;
+      }
+      rs->epoch = ep;
+    }
+    rs->parked = false;
   }
   c.epoch = ep;
   c.n_nodes = 1;
   const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};  // engine.py:3
   int head = 0, tail = 0, best = -1, best_h = 0, best_depth = 0, iters = 0;
-  const int h_root = sk_u(SokoNode::unpack(c.nodes[0]).h);
-  if (b2 < 0) {
-    if (c.lane == 0) c.q[0] = 0u;
-  } else {
-    sk_hq_store<false>(c, 0, (uint32_t)(2 * h_root) << 16, c.lane == 0);
+  bool fresh = true;
+  if constexpr (RES) {
+    if (rs->resume) {
+      fresh = false;
+      head = rs->head;
+      tail = rs->tail;
+      best = rs->best;
+      best_h = rs->best_h;
+      best_depth = rs->best_depth;
+      iters = rs->iters;
+      c.n_nodes = rs->n_nodes;
+    }
   }
-  tail = 1;
+  if (fresh) {
+    const int h_root = sk_u(SokoNode::unpack(c.nodes[0]).h);
+    if (b2 < 0) {
+      if (c.lane == 0) c.q[0] = 0u;
+    } else {
+      sk_hq_store<false>(c, 0, (uint32_t)(2 * h_root) << 16, c.lane == 0);
+    }
+    tail = 1;
+  }
   // BFS: the queue is read 64 entries at a time (lane l holds q[qbase + l]) and the node after the current one is
   // already in it, so its record is requested one iteration ahead
   int qbase = 0, qvalid = 0;
@@ -689,6 +736,10 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
   SK_T_DECL();
   while (iters < max_iter && head < tail) {
     if (cancel != nullptr && sk_u(sk_ld(cancel)) < my_stage) break;
+    if constexpr (RES) {
+      if (rs->budget <= 0) break;
+      rs->budget -= b2 < 0 ? 1 : 2;
+    }
     iters++;
     head = sk_u(head);
     tail = sk_u(tail);
@@ -797,12 +848,39 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
     }
   }
   SK_T_FLUSH(b2 < 0 ? 0 : 1, iters);
+  if constexpr (RES) {
+    if (iters < max_iter && head < tail) {  // stopped on the budget: park
+      rs->parked = true;
+      rs->head = sk_u(head);
+      rs->tail = sk_u(tail);
+      rs->n_nodes = sk_u(c.n_nodes);
+      rs->best = sk_u(best);
+      rs->best_h = sk_u(best_h);
+      rs->best_depth = sk_u(best_depth);
+      rs->iters = sk_u(iters);
+      return false;
+    }
+  }
   res_h = best_h;
   res_depth = best_depth;
   if (exhausted) *exhausted = head >= tail;  // the open list ran dry: every reachable state was expanded
   return false;
 }
 
+// bind the context to the stage workspace at `b` (of pool.stage_bytes bytes)
+__device__ inline void sk_bind_at(SokoCtx &c, const SokoPool &pool, uint8_t *b, int stage) {
+  c.stage = stage;
+  c.max_nodes = pool.max_nodes;
+  c.nodes = (sk_u32x4 SK_GLOBAL *)b;
+  b += SK_NODE_BYTES * (size_t)c.max_nodes;
+  c.crates = (uint16_t SK_GLOBAL *)b;
+  c.region_stride = pool.stage_bytes;
+  c.npr = c.cstride > 0 ? (int)(((size_t)c.max_nodes * SK_MAXC) / (size_t)c.cstride) : c.max_nodes;
+  b += (size_t)c.max_nodes * SK_MAXC * sizeof(uint16_t);
+  c.vis = (sk_u32x4 SK_GLOBAL *)b;
+  b += SK_VIS_BYTES;
+  c.q = (uint32_t SK_GLOBAL *)b;
+}
 // bind the context to stage workspace `stage` of `slot`
 __device__ inline void sk_bind(SokoCtx &c, const SokoPool &pool, int slot, int stage) {
   uint8_t *b = pool.base + ((size_t)slot * SK_STAGES + stage) * pool.stage_bytes;
@@ -1176,6 +1254,61 @@ __device__ inline void sokoban_helpers_release() {
   if ((threadIdx.x & 63) == 0) sk_st(&sk_shared().mail.exit, 1);
 }
 
+// The level of lane group `gi` in LDS (sk_shared().level), built by the whole wave: the group's row masks are broadcast;
+// level coords = map coords + 1 (sokoban_prob.py:107-124: one-tile solid border around the map); crates / targets are listed
+// in row-major order (engine.py:170-188).  Returns the player's cell and the list lengths (wave-uniform).
+template <int LPE, typename M, int MAXC>
+__device__ __attribute__((always_inline)) inline void sk_build_level(const Grp<LPE> &g, int gi, int H, int W, M solid, M player, M crate, M target,
+                                                                     int &px, int &py, int &ncr, int &ntg) {
+  SokoLevel &s_level = sk_shared().level;
+  {
+    // the level: the group's rows are broadcast to the wave; level coords = map coords + 1 (sokoban_prob.py:107-124:
+    // one-tile solid border around the map); crates / targets are listed in row-major order (engine.py:170-188)
+    const uint64_t full = W + 2 >= 64 ? ~0ull : (1ull << (W + 2)) - 1ull;
+    auto row_of = [&](M v, int src) -> uint64_t {  // lane src's row mask, broadcast
+      if constexpr (sizeof(M) == 4) {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, src);
+      } else {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+      }
+    };
+    if (g.lane == 0) {
+      s_level.w = W + 2;
+      s_level.h = H + 2;
+      s_level.solid[0] = full;
+      s_level.solid[H + 1] = full;
+      s_level.tgt[0] = 0;
+      s_level.tgt[H + 1] = 0;
+    }
+    for (int r = 0; r < H; r++) {
+      const int src = gi * LPE + r;
+      const uint64_t sm = row_of(solid, src), pl = row_of(player, src), cr = row_of(crate, src), tg = row_of(target, src);
+      if (g.lane == 0) {
+        s_level.solid[r + 1] = (sm << 1) | 1ull | (1ull << (W + 1));
+        s_level.tgt[r + 1] = tg << 1;
+      }
+      if (pl) {
+        px = __builtin_ctzll(pl) + 1;
+        py = r + 1;
+      }
+      // lane j owns bit j of the row (W <= 62): list entry = count so far + rank of the bit
+      const uint64_t below = (1ull << g.lane) - 1ull;
+      if ((cr >> g.lane) & 1ull) {
+        const int k = ncr + __popcll(cr & below);
+        if (k < MAXC) s_level.root[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
+      }
+      if ((tg >> g.lane) & 1ull) {
+        const int k = ntg + __popcll(tg & below);
+        if (k < MAXC) s_level.target[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
+      }
+      ncr += __popcll(cr);
+      ntg += __popcll(tg);
+    }
+  }
+}
+
 // Called by every lane of the wave in uniform control flow; `need` is uniform per group.  Groups that need the
 // solver are served one after the other by the WHOLE wave, so a wavefront holds at most one workspace slot at a time
 // and never waits for a slot while holding one.
@@ -1217,51 +1350,8 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // tell the host that searches are running: it then launches the step kernel with one env per wavefront
     if (g.lane == 0 && p.solver_seen != nullptr) __hip_atomic_fetch_add(p.solver_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // the level: the group's rows are broadcast to the wave; level coords = map coords + 1 (sokoban_prob.py:107-124:
-    // one-tile solid border around the map); crates / targets are listed in row-major order (engine.py:170-188)
-    const uint64_t full = W + 2 >= 64 ? ~0ull : (1ull << (W + 2)) - 1ull;
-    auto row_of = [&](M v, int src) -> uint64_t {  // lane src's row mask, broadcast
-      if constexpr (sizeof(M) == 4) {
-        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, src);
-      } else {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
-        return (uint64_t)lo | ((uint64_t)hi << 32);
-      }
-    };
     int px = 0, py = 0, ncr = 0, ntg = 0;
-    if (g.lane == 0) {
-      s_level.w = W + 2;
-      s_level.h = H + 2;
-      s_level.solid[0] = full;
-      s_level.solid[H + 1] = full;
-      s_level.tgt[0] = 0;
-      s_level.tgt[H + 1] = 0;
-    }
-    for (int r = 0; r < H; r++) {
-      const int src = gi * LPE + r;
-      const uint64_t sm = row_of(solid, src), pl = row_of(player, src), cr = row_of(crate, src), tg = row_of(target, src);
-      if (g.lane == 0) {
-        s_level.solid[r + 1] = (sm << 1) | 1ull | (1ull << (W + 1));
-        s_level.tgt[r + 1] = tg << 1;
-      }
-      if (pl) {
-        px = __builtin_ctzll(pl) + 1;
-        py = r + 1;
-      }
-      // lane j owns bit j of the row (W <= 62): list entry = count so far + rank of the bit
-      const uint64_t below = (1ull << g.lane) - 1ull;
-      if ((cr >> g.lane) & 1ull) {
-        const int k = ncr + __popcll(cr & below);
-        if (k < (HUGE ? SK_MAXC_HUGE : SK_MAXC)) s_level.root[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
-      }
-      if ((tg >> g.lane) & 1ull) {
-        const int k = ntg + __popcll(tg & below);
-        if (k < (HUGE ? SK_MAXC_HUGE : SK_MAXC)) s_level.target[k] = (uint16_t)((g.lane + 1) | ((r + 1) << 8));
-      }
-      ncr += __popcll(cr);
-      ntg += __popcll(tg);
-    }
+    sk_build_level<LPE, M, (HUGE ? SK_MAXC_HUGE : SK_MAXC)>(g, gi, H, W, solid, player, crate, target, px, py, ncr, ntg);
     int dw = dist_win, sl = sol_len;
     constexpr int MAXC = HUGE ? SK_MAXC_HUGE : SK_MAXC;
     if (ncr > MAXC || ntg > MAXC || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {
@@ -1306,6 +1396,174 @@ __device__ __attribute__((always_inline)) inline void sokoban_solve(const Grp<LP
   }
 }
 
+// ---------------------------------------------------------------------------------------------- resumable solver
+// Asynchronous stepping (pcgrl_step_ready).  In the reference a slow SokobanProblem._run_game (sokoban_prob.py:99-148: up to
+// 4 x solver_power iterations) stalls ONE env -- a Ray worker's handful -- not the fleet (rl/utils.py:412-415).  Here a step
+// launch used to wait for the slowest search of the whole batch (30-40 ms for a level that runs every stage to its cap).
+// In asynchronous mode every env owns one stage workspace (slot = env: no locks) and a park record; a launch gives every
+// search `Params::sk_budget` iteration units, an unfinished search is PARKED (its queue / heap / node records / visited table
+// are in the workspace already; the dozen wave-uniform words of sk_stage go to the record) and the env reports itself busy;
+// the next launch resumes it.  The cascade runs stage after stage on the env's simulate wave (sk_cascade's form): with most
+// envs searching, the machine is full of independent searches and what counts is the work per search, not its latency.
+//
+// The record also carries the level the search belongs to (the map's three tile planes, exact): a search is resumed -- or
+// its finished result reused -- only for exactly that level; for any other level the workspace starts over.  The result is a
+// pure function of the level (and solver_power), so this is exact whatever happened to the env in between (resets,
+// checkpoints restored into another engine, a step abandoned by pcgrl_reset).
+struct SkPark {
+  uint32_t state;   // 0 = empty, 1 = search parked, 2 = finished (res_*)
+  int32_t stage;    // parked: the stage the search is in (0 = BFS, 1..3 = A* with balance 1, 0.5, 0)
+  int32_t iters, head, tail, n_nodes, best, best_h, best_depth;
+  uint32_t epoch;   // visited-table epoch counter of the workspace
+  int32_t res_won, res_h, res_depth;
+  int32_t pad_[3];
+  uint64_t sig[3][SK_MAXDIM];  // tile planes of the level's map rows
+};
+static_assert(sizeof(SkPark) == 64 + 3 * SK_MAXDIM * 8, "SkPark: a 16-word header + the level");
+constexpr int SK_PARK_EMPTY = 0, SK_PARK_RUNNING = 1, SK_PARK_DONE = 2;
+
+// The cascade of sk_cascade on the env's own workspace, to a budget.  Returns true when the search ended in this launch
+// (won / h / depth valid), false when it was parked.
+template <int NH>
+__device__ __attribute__((always_inline)) inline bool sk_cascade_budget(SokoCtx &c, const SokoPool &pool, SkPark *pk, bool resume, int stage0,
+                                                                        SkRes &rs, int power, int px, int py, bool &won, int &h, int &depth) {
+  if (!resume) sk_root<NH>(c, px, py);
+  won = false;
+  bool exhausted = false;
+  for (int st = resume ? stage0 : 0; st < SK_STAGES && !won && !exhausted; st++) {
+    bool ex = false;
+    won = sk_stage<NH, true>(c, pool, 0, st == 0 ? -1 : 3 - st, power, h, depth, &ex, nullptr, 0, &rs);
+    if (rs.parked) {
+      if (c.lane == 0) {
+        pk->stage = st;
+        pk->iters = rs.iters;
+        pk->head = rs.head;
+        pk->tail = rs.tail;
+        pk->n_nodes = rs.n_nodes;
+        pk->best = rs.best;
+        pk->best_h = rs.best_h;
+        pk->best_depth = rs.best_depth;
+        pk->epoch = rs.epoch;
+        pk->state = SK_PARK_RUNNING;
+      }
+      return false;
+    }
+    exhausted = st == 0 && ex;  // (only the BFS stage's flag ends the cascade, see sk_cascade)
+    rs.resume = false;          // the next stage starts from the root
+  }
+  return true;
+}
+
+// sokoban_solve for asynchronous stepping.  Same calling convention; returns (per lane, uniform over a group) whether the
+// group's search is still unfinished -- then dist_win / sol_len are untouched and the caller must not use the statistics.
+// `planes`: the map's tile planes of this lane's row (masked to the map): the level's identity.
+template <int LPE, typename M>
+__device__ __attribute__((always_inline)) inline bool sokoban_solve_async(const Grp<LPE> &g, const Params &p, int env, bool need, M solid, M player,
+                                                                          M crate, M target, const M *planes, int &dist_win, int &sol_len) {
+  const SokoPool &pool = *(const SokoPool *)p.soko;
+  const int H = p.cfg.dims[0], W = p.cfg.dims[1];
+  constexpr int EPW = 64 / LPE;
+  SokoLevel &s_level = sk_shared().level;
+  bool unfinished = false;
+  for (int gi = 0; gi < EPW; gi++) {
+    const bool mine = need && (g.lane / LPE) == gi;
+    if (__ballot(mine) == 0) continue;
+    const int ge = __builtin_amdgcn_readlane(env, gi * LPE);  // the group's env (uniform)
+    SkPark *pk = (SkPark *)pool.async_park + ge;
+    // the record's header, one word per lane, and whether it belongs to this very level
+    const uint32_t hw = g.lane < 16 ? ((const uint32_t *)pk)[g.lane] : 0u;
+    const bool my_row = (g.lane / LPE) == gi && g.row < H;
+    bool diff = false;
+    if (my_row) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) diff = diff || pk->sig[k][g.row] != (uint64_t)planes[k];
+    }
+    const uint32_t state = (uint32_t)__builtin_amdgcn_readlane((int)hw, 0);
+    const bool match = state != SK_PARK_EMPTY && __ballot(diff) == 0;
+    int dw = dist_win, sl = sol_len;
+    if (match && state == SK_PARK_DONE) {  // the same level again (a re-injected map, a replayed step): the result stands
+      const int won = __builtin_amdgcn_readlane((int)hw, 10), rh = __builtin_amdgcn_readlane((int)hw, 11);
+      const int rd = __builtin_amdgcn_readlane((int)hw, 12);
+      dw = won ? 0 : rh;
+      sl = won ? rd : 0;
+      if (mine) {
+        dist_win = dw;
+        sol_len = sl;
+      }
+      continue;
+    }
+    SkRes rs;
+    rs.resume = match;  // (state == SK_PARK_RUNNING)
+    rs.parked = false;
+    rs.budget = p.sk_budget;
+    rs.iters = __builtin_amdgcn_readlane((int)hw, 2);
+    rs.head = __builtin_amdgcn_readlane((int)hw, 3);
+    rs.tail = __builtin_amdgcn_readlane((int)hw, 4);
+    rs.n_nodes = __builtin_amdgcn_readlane((int)hw, 5);
+    rs.best = __builtin_amdgcn_readlane((int)hw, 6);
+    rs.best_h = __builtin_amdgcn_readlane((int)hw, 7);
+    rs.best_depth = __builtin_amdgcn_readlane((int)hw, 8);
+    rs.epoch = (uint32_t)__builtin_amdgcn_readlane((int)hw, 9);
+    const int stage0 = __builtin_amdgcn_readlane((int)hw, 1);
+    if (!match) {  // another level: the workspace starts over (the epoch counter lives on: older table entries are empty)
+      if (my_row) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) pk->sig[k][g.row] = (uint64_t)planes[k];
+      }
+      if (g.lane == 0) pk->state = SK_PARK_EMPTY;
+    }
+    SokoCtx c;
+    c.lv = &s_level;
+    c.lane = g.lane;
+    c.pool_full = false;
+    c.hl = (uint32_t SK_LDS *)nullptr;
+    c.hcap = 0;
+    c.dbg = nullptr;
+    int px = 0, py = 0, ncr = 0, ntg = 0;
+    sk_build_level<LPE, M, SK_MAXC>(g, gi, H, W, solid, player, crate, target, px, py, ncr, ntg);
+    bool finished = true;
+    if (ncr > SK_MAXC || ntg > SK_MAXC || W + 2 > SK_MAXDIM || H + 2 > SK_MAXDIM) {
+      // beyond what one stage workspace holds (more than 128 pairs: maps of >= 258 cells only): reported by pcgrl_poll_error,
+      // the level keeps the solver-less statistics
+      if (g.lane == 0) atomicOr(p.err, 2);
+    } else {
+      c.ncr = ncr;
+      c.cstride = (ncr + 3) & ~3;
+      if (g.lane == 0) {
+        s_level.ncr = ncr;
+        s_level.ntg = ntg;
+      }
+      sk_init_deadlocks(c);
+      sk_bind_at(c, pool, pool.async_ws + (size_t)ge * pool.stage_bytes, 0);
+      bool won = false;
+      int h = 0, depth = 0;
+      if (ncr > 64) finished = sk_cascade_budget<2>(c, pool, pk, rs.resume, stage0, rs, p.cfg.solver_power, px, py, won, h, depth);
+      else finished = sk_cascade_budget<1>(c, pool, pk, rs.resume, stage0, rs, p.cfg.solver_power, px, py, won, h, depth);
+      if (finished) {
+        dw = won ? 0 : h;  // heuristic of the last stage's best node (sokoban_prob.py:147)
+        sl = won ? depth : 0;
+        if (g.lane == 0) {
+          pk->res_won = won ? 1 : 0;
+          pk->res_h = h;
+          pk->res_depth = depth;
+          pk->epoch = rs.epoch;
+          pk->state = SK_PARK_DONE;
+        }
+      }
+      if (c.pool_full && g.lane == 0) atomicOr(p.err, 2);
+    }
+    if (mine) {
+      if (finished) {
+        dist_win = dw;
+        sol_len = sl;
+      } else {
+        unfinished = true;
+      }
+    }
+  }
+  return unfinished;
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 static inline int sokoban_slots_for(int n_levels) {  // one slot per four levels, between 4 and 512
   const int want = (n_levels + 3) / 4;
@@ -1313,8 +1571,11 @@ static inline int sokoban_slots_for(int n_levels) {  // one slot per four levels
 }
 constexpr int SK_SLOTS_AT_CREATE = 64;  // pool of an engine whose solver has not been seen running yet (2.9 GB)
 // A pool of n_slots workspace slots (the engine grows it: pcgrl_engine.hip soko_pool_for).
-static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int n_slots, int *n_slots_out = nullptr) {
+static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, int n_slots, int *n_slots_out = nullptr,
+                                       void *async_ws = nullptr, void *async_park = nullptr) {
   SokoPool pool;
+  pool.async_ws = (uint8_t *)async_ws;  // (a grown pool keeps the per-env workspaces of asynchronous stepping)
+  pool.async_park = async_park;
   // A slot = SK_STAGES stage workspaces (~11 MB each at the default solver_power: 46 MB per slot).  Full size: one slot
   // per four envs of the batch, between 4 (a single-env adapter or an RLlib worker's small engine pins 0.18 GB, not 2.9)
   // and 512 (23 GB in all at 2048 envs); searches beyond the pool wait for a slot.  pcgrl_create allocates at most
@@ -1351,6 +1612,36 @@ static inline hipError_t sokoban_alloc(Params &p, std::vector<void *> &allocs, i
   if ((e = hipDeviceSynchronize()) != hipSuccess) return undo(e);
   for (void *q : {base, locks, epochs, dpool}) allocs.push_back(q);
   p.soko = dpool;
+  return hipSuccess;
+}
+
+// Asynchronous stepping: one stage workspace and one park record per env (pcgrl_set_solver_budget); the device pool record
+// learns where they are.
+static inline hipError_t sokoban_alloc_async(Params &p, std::vector<void *> &allocs, int n_envs, void **ws_out, void **park_out) {
+  SokoPool pool;
+  hipError_t e;
+  if ((e = hipMemcpy(&pool, p.soko, sizeof(pool), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  void *ws = nullptr, *park = nullptr;
+  auto undo = [&](hipError_t err) {
+    (void)hipDeviceSynchronize();
+    for (void *q : {park, ws})
+      if (q) (void)hipFree(q);
+    return err;
+  };
+  if ((e = hipMalloc(&ws, pool.stage_bytes * (size_t)n_envs)) != hipSuccess) return undo(e);
+  const size_t vis_off = SK_NODE_BYTES * (size_t)pool.max_nodes + (size_t)pool.max_nodes * SK_MAXC * sizeof(uint16_t);
+  for (int i = 0; i < n_envs; i++)  // (entries carry the epoch of the stage that wrote them; 0 = empty)
+    if ((e = hipMemsetAsync((uint8_t *)ws + (size_t)i * pool.stage_bytes + vis_off, 0, SK_VIS_BYTES, 0)) != hipSuccess) return undo(e);
+  if ((e = hipMalloc(&park, sizeof(SkPark) * (size_t)n_envs)) != hipSuccess) return undo(e);
+  if ((e = hipMemset(park, 0, sizeof(SkPark) * (size_t)n_envs)) != hipSuccess) return undo(e);
+  pool.async_ws = (uint8_t *)ws;
+  pool.async_park = park;
+  if ((e = hipMemcpy(p.soko, &pool, sizeof(pool), hipMemcpyHostToDevice)) != hipSuccess) return undo(e);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return undo(e);
+  allocs.push_back(ws);
+  allocs.push_back(park);
+  *ws_out = ws;
+  *park_out = park;
   return hipSuccess;
 }
 

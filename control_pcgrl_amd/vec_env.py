@@ -280,6 +280,43 @@ class VecPcgrlEnv:
         n = int(self._L.pcgrl_solver_pool_slots(self._h, C.byref(full), C.byref(failed)))
         return n, int(full.value), bool(failed.value)
 
+    # -- asynchronous stepping (sokoban): resumable device solver behind a per-env status byte -----------------------
+    EMITTED, BUSY = 1, 2  # include/pcgrl_amd.h PCGRL_ENV_EMITTED / PCGRL_ENV_BUSY
+
+    def set_solver_budget(self, budget):
+        """budget > 0: the device solver works to `budget` iteration units per env and launch and parks what it could not
+        finish; step with step_ready() from here on (step() / rollout() / update() are refused).  0: synchronous again.
+        In the reference a slow _run_game (sokoban_prob.py:99-148) stalls one env, not the fleet (rl/utils.py:412-415)."""
+        _lib.check(self._L.pcgrl_set_solver_budget(self._h, int(budget)), "pcgrl_set_solver_budget")
+        if budget > 0 and getattr(self, "_status", None) is None:
+            self._status = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+            info = dict(self._step_out[4], status=self._status)
+            self._ready_out = self._step_out[:4] + (info,)
+
+    def step_ready(self, actions):
+        """pcgrl_step_ready: like step(), plus info["status"] uint8 [N] = EMITTED (this env completed a step in this launch:
+        its reward / done / stats / obs rows are valid) | BUSY (a search of its level is parked: it ignores the NEXT call's
+        action).  An env consumes the action of a call iff it was not busy after the previous one; an emitted transition
+        belongs to the last action the env consumed.  Rows of envs that did not emit keep their previous contents."""
+        self._check_action_shape(actions)
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        rc = self._L.pcgrl_step_ready(self._h, actions.data_ptr(), 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
+                                      self._ptrs[2], self._ptrs[3], self._status.data_ptr(), self._stream())
+        if rc:
+            _lib.check(rc, "pcgrl_step_ready")
+        return self._ready_out
+
+    def step_ready_raw(self, actions_ptr, status_ptr, stream):
+        return self._L.pcgrl_step_ready(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],
+                                        self._ptrs[2], self._ptrs[3], status_ptr, stream)
+
+    def env_busy(self):
+        """uint8 [N]: 1 = the env waits for a parked search (after reset(): which envs will ignore the first action)"""
+        out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.pcgrl_env_busy(self._h, out.data_ptr(), self._stream()), "pcgrl_env_busy")
+        return out
+
     def step_raw(self, actions_ptr, stream):
         """Lowest-overhead launch: device pointer of int32 actions + raw hipStream_t."""
         return self._L.pcgrl_step(self._h, actions_ptr, 1 if self.auto_reset else 0, self._ptrs[0], self._ptrs[1],

@@ -280,6 +280,38 @@ int pcgrl_poll_error(pcgrl_handle h);
 int64_t pcgrl_state_bytes(pcgrl_handle h);
 int pcgrl_export_state(pcgrl_handle h, uint8_t *d_buf, int32_t *maybe_stale_out, void *stream);
 int pcgrl_import_state(pcgrl_handle h, const uint8_t *d_mask, const uint8_t *d_buf, int32_t maybe_stale, void *stream);
+/* Asynchronous stepping (sokoban).  In the reference a slow SokobanProblem._run_game (envs/probs/sokoban/sokoban_prob.py:99-148:
+ * BFS, then A* with balance 1, 0.5, 0, up to solver_power iterations each) stalls ONE env object -- a Ray worker's
+ * num_envs_per_worker at most -- not the fleet (rl/utils.py:412-415: num_rollout_workers x num_envs_per_worker).  pcgrl_step waits
+ * for the slowest search of the whole batch; with a solver budget the searches are RESUMABLE instead:
+ *   pcgrl_set_solver_budget(h, budget)   budget > 0: every env gets a solver workspace of its own (11.5 MB at the default
+ *       solver_power; synchronous allocation on the first call) and a launch gives every search `budget` iteration units (a BFS
+ *       iteration costs 1, an A* iteration 2: roughly the same time).  budget = 0: back to synchronous stepping (allowed when no
+ *       env is busy).  Sokoban without control metrics, static tiles or action patches; PCGRL_EUNSUPPORTED otherwise.
+ *   pcgrl_step_ready(...)                pcgrl_step + d_status uint8 [N], per env a combination of
+ *       PCGRL_ENV_EMITTED  the env completed a step in this launch: its rows of d_reward / d_done / d_stats (and d_obs) are valid
+ *       PCGRL_ENV_BUSY     the env is busy after this launch (a search of its level is parked): it IGNORES the next launch's
+ *                          action, and unless EMITTED is set as well its output rows were not written
+ *     An env that is not busy when a launch starts takes that launch's action; the step completes -- EMITTED -- in the launch in
+ *     which its search ends (usually the same one).  An env whose auto-reset (or pcgrl_reset) drew a playable map is EMITTED |
+ *     BUSY (or just busy) until a launch has finished the new episode's statistics; it then reports 0 once and takes the next
+ *     action.  So: env i consumes the action of launch t  iff  (status[i] of launch t-1 & PCGRL_ENV_BUSY) == 0  (after
+ *     pcgrl_reset: pcgrl_env_busy), and every emitted transition belongs to the last action the env consumed.  Per-env
+ *     trajectories are exactly the reference's; which launch an env advances in depends on the budget alone (deterministic).
+ *     d_obs rows of busy envs hold the observation of the step in flight (it does not depend on the search).
+ *     With a budget set, pcgrl_step / pcgrl_step_ex / pcgrl_rollout / pcgrl_update are refused (PCGRL_EINVAL): they have no way
+ *     to say "busy".  pcgrl_reset / pcgrl_set_state may leave envs busy (their level's search is parked the same way).
+ *   pcgrl_env_busy(h, d_busy, stream)    uint8 [N]: 1 = the env is busy now (what the last launch's PCGRL_ENV_BUSY said, or what
+ *       a pcgrl_reset left behind)
+ * A search is resumed only for exactly the level it was started on (the park record carries the map); anything else -- a reset,
+ * an imported checkpoint, a step abandoned by pcgrl_reset -- restarts it: results never depend on parked state. */
+enum { PCGRL_ENV_EMITTED = 1, PCGRL_ENV_BUSY = 2 };
+int pcgrl_set_solver_budget(pcgrl_handle h, int32_t budget);
+int32_t pcgrl_get_solver_budget(pcgrl_handle h);
+int pcgrl_step_ready(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, uint8_t *d_obs, float *d_reward, uint8_t *d_done,
+                     int32_t *d_stats, uint8_t *d_status, void *stream);
+int pcgrl_env_busy(pcgrl_handle h, uint8_t *d_busy, void *stream);
+
 /* sokoban: the device solver's workspace pool (one 46 MB slot per search in flight at the default solver_power).
  * pcgrl_create allocates min(full, 64) slots (full = clamp(N / 4, 4, 512)); by default the engine grows the pool to full
  * size the first time it has SEEN the solver running -- a synchronous hipMalloc + device synchronise inside whichever

@@ -736,10 +736,19 @@ void orc_reset(orc_engine *e, const uint8_t *mask, const uint8_t *init_grids, co
 
 void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t *obs, double *reward,
               uint8_t *done, int32_t *stats) {
+  orc_step_masked(e, NULL, actions, auto_reset, obs, reward, done, stats);
+}
+
+/* The same for the envs selected by `mask` (NULL = all): the others are not stepped and their rows of the outputs are left
+ * alone.  The reference's envs are independent objects, each stepped when its own worker steps it (rl/utils.py:412-415);
+ * the tests of the engine's asynchronous stepping (ready mask) step an env here exactly when the engine says it stepped. */
+void orc_step_masked(orc_engine *e, const uint8_t *mask, const int32_t *actions, int32_t auto_reset, uint8_t *obs,
+                     double *reward, uint8_t *done, int32_t *stats) {
   const orc_config *cfg = &e->cfg;
   int64_t osz = orc_obs_size(e);
 #pragma omp parallel for schedule(dynamic, 16) num_threads(e->n_threads)
   for (int i = 0; i < e->n_envs; i++) {
+    if (mask != NULL && mask[i] == 0) continue;
     env_t *v = &e->envs[i];
     /* envs/pcgrl_env.py:267-342 */
     v->iteration++;

@@ -72,6 +72,9 @@ void orc_reset(orc_engine *e, const uint8_t *mask, const uint8_t *init_grids, co
  * stats are those of the step itself (RLlib auto-reset convention). */
 void orc_step(orc_engine *e, const int32_t *actions, int32_t auto_reset, uint8_t *obs, double *reward,
               uint8_t *done, int32_t *stats);
+/* ... for the envs selected by mask (NULL = all); the other envs are not stepped, their output rows are untouched */
+void orc_step_masked(orc_engine *e, const uint8_t *mask, const int32_t *actions, int32_t auto_reset, uint8_t *obs,
+                     double *reward, uint8_t *done, int32_t *stats);
 
 /* evolution-driver pattern (evo/evolve.py:1083-1120): rep.update only, then get_stats once */
 void orc_update(orc_engine *e, const int32_t *actions, uint8_t *obs);

@@ -119,6 +119,7 @@ def lib():
         L.orc_seed.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_step_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_observe.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_obs_size.restype = C.c_int64
         L.orc_obs_size.argtypes = [C.c_void_p]
@@ -253,6 +254,18 @@ class OracleVecEnv:
         if obs is not None:
             obs = obs.reshape((self.n,) + self.obs_shape)
         return obs, rew, done.astype(bool), stats
+
+    def step_masked(self, mask, actions, auto_reset=False):
+        """step only the envs with mask != 0; returns (obs, reward, done, stats) with the rows of the other envs zero"""
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        obs = np.zeros((self.n, self.obs_size), np.uint8)
+        rew = np.zeros(self.n, np.float64)
+        done = np.zeros(self.n, np.uint8)
+        stats = np.zeros((self.n, self.n_stats), np.int32)
+        lib().orc_step_masked(self.h, m.ctypes.data, a.ctypes.data, int(auto_reset), obs.ctypes.data, rew.ctypes.data,
+                              done.ctypes.data, stats.ctypes.data)
+        return obs.reshape((self.n,) + self.obs_shape), rew, done.astype(bool), stats
 
     def update(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.int32)
