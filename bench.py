@@ -170,6 +170,13 @@ def main():
                          "launches + the pcgrl_reduce_episodes launch + one synchronise -- while the all-gather + device->host copy of the "
                          "PREVIOUS interval's sums run on a side stream under the stepping (SURVEY 8 e: 'issue it on a side stream so it never "
                          "blocks stepping'); 'serial' = round 5's region: reduction -> all-gather -> copy behind the K launches, as the closing barrier")
+    ap.add_argument("--solver-budget", type=int, default=0,
+                    help="sokoban-wide-solver: asynchronous stepping (pcgrl_set_solver_budget / pcgrl_step_ready) with this many solver "
+                         "iteration units per env and launch; `value` then counts the transitions the launches EMITTED (busy envs do not "
+                         "step); 0 = synchronous pcgrl_step")
+    ap.add_argument("--solver-forms", type=int, default=0,
+                    help="sokoban-wide-solver: also time this many steps of the same workload through pcgrl_rollout (8 steps per launch "
+                         "between re-injections) and through sub_batches = 4 (secondary object `solver_active_forms`); 0 = skip")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own slice of the host cores")
     args = ap.parse_args()
 
@@ -286,9 +293,12 @@ def main():
     env = VecPcgrlEnv(problem, rep, shape, 4096 if sfg else N, device=dev, seeds=shard_seeds(0x5EED, total_envs, rank, world)[:4096 if sfg else N],
                       auto_reset=not bfs_active, **wkw)
     inject = None
+    budget = args.solver_budget if solver_active else 0
     if solver_active:
         sa_maps, sa_cells = solver_active_maps(N, 77 + rank)
         inject = torch.as_tensor(sa_maps, device=dev).contiguous()
+        if budget > 0:  # resumable solver: one workspace per env (synchronous allocation, before anything is timed)
+            env.set_solver_budget(budget)
         env.reset(init_grids=inject)
     elif bfs_active:  # no auto-reset: a reset would draw maps with ~10 players, which switch the searches off
         inject = torch.as_tensor(bfs_active_maps(N, 77 + rank), device=dev).contiguous()
@@ -311,6 +321,16 @@ def main():
     sptr = stream.cuda_stream
     base, stride = actions.data_ptr(), N * env.action_entries * 4
     step_raw = env.step_raw
+    status_rows = None
+    if budget > 0:  # launch k writes its per-env status bytes into row k: the emitted transitions are counted after the clock
+        status_rows = torch.zeros((max(K, W, 1), N), dtype=torch.uint8, device=dev)
+        st_base = status_rows.data_ptr()
+
+        def step_raw(aptr, strm, _k=[0]):  # noqa: B006  (row = launches issued so far since the last rewind)
+            rc = env.step_ready_raw(aptr, st_base + (_k[0] % status_rows.shape[0]) * N, strm)
+            _k[0] += 1
+            return rc
+        step_raw.rewind = lambda: step_raw.__defaults__[0].__setitem__(0, 0)
 
     EVO_K = int(np.prod(shape))  # evo/evolve.py:2054-2066: N_STEPS = max_changes = n_cells for narrow
     sfg_maps = sfg_out = None
@@ -649,6 +669,9 @@ def main():
             with torch.cuda.stream(xstream):
                 dist.all_gather_into_tensor(ep_all_dev, ep_prev_dev)
             torch.cuda.synchronize(dev)
+    if budget > 0:
+        step_raw.rewind()
+        status_rows.zero_()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -707,6 +730,13 @@ def main():
     # rank); overlapped form = what of the side stream's work was still running when the stepping stream had finished
     exchange_ms = exposed_ms if overlap else (0.0 if ev2 is None else (ev1.elapsed_time(ev2) if ev2.query() else float("nan")))
     env.check_errors()
+    emitted_total = None
+    if budget > 0:  # asynchronous stepping: the env-steps of the region are the transitions its launches emitted
+        st_k = status_rows[:K]
+        mine = float((st_k & 1).sum().item())
+        _, per_rank_emitted = max_over_ranks(mine)
+        emitted_total = sum(per_rank_emitted)
+        busy_share = float(((st_k & 2) != 0).float().mean().item())
     elapsed, per_rank_elapsed = max_over_ranks(elapsed)
     _, per_rank_eps = max_over_ranks(float(local_eps[0]))
     _, per_rank_kernel_ms = max_over_ranks(kernel_ms)
@@ -720,8 +750,8 @@ def main():
           "mean_final_stats": [x / n_ep for x in h[3:]]}
 
     if rank == 0:
-        value = total_envs * K / elapsed
-        bytes_per_launch = int(ALGO_BYTES[args.workload] * N)
+        value = total_envs * K / elapsed if emitted_total is None else emitted_total / elapsed
+        bytes_per_launch = int(ALGO_BYTES[args.workload] * N) if emitted_total is None else int(ALGO_BYTES[args.workload] * emitted_total / world / K)
         achieved = bytes_per_launch / (elapsed / K) / 1e9          # same clock as `value`
         achieved_ev = bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # HIP events around the K launches
         traffic, traffic_src = profiled_traffic(args.workload, N)
@@ -733,7 +763,9 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload} {'x'.join(map(str, shape))}, {N} envs/GPU, "
                                    + ("playable levels (one player, 1-3 crates / targets, one room) re-injected every 8 steps, floor / "
-                                      "wall edits in and around the room, no auto-reset, " if solver_active else
+                                      "wall edits in and around the room, no auto-reset, "
+                                      + (f"ASYNCHRONOUS stepping (pcgrl_step_ready, solver budget {budget} per env and launch: a 'step' of "
+                                         "--steps is one launch, value counts emitted transitions), " if budget > 0 else "") if solver_active else
                                       "injected maps with one player / key / door, random moves and empty / solid / enemy "
                                       "placements, no auto-reset, " if bfs_active else
                                       f"evolution-driver pattern (evo/evolve.py:1083-1120): one pcgrl_update launch (rep.update + observation) per "
@@ -807,6 +839,14 @@ def main():
                                    "no collective and no copy, so value(N) / (N x value(1)) charges the exchange itself before any loss from adding ranks")
         if closed is not None:
             out["closed_loop_device_actions"] = closed
+        if solver_active and budget > 0:
+            out["asynchronous_stepping"] = {
+                "solver_budget": budget, "launches": K, "emitted_transitions": emitted_total,
+                "emitted_share_of_env_launches": emitted_total / (total_envs * K), "busy_share_of_env_launches": busy_share,
+                "us_per_launch": elapsed / K * 1e6,
+                "note": "pcgrl_step_ready: every launch gives every env's search `solver_budget` iteration units (BFS 1, A* 2), parks "
+                        "what is unfinished and reports the env busy; `value` = emitted transitions / s (a busy env does not step); "
+                        "per-env trajectories equal the synchronous ones (tests/test_gpu_round6.py)"}
         if solver_active:
             st = env.get_state().stats
             out["solver_active"] = {"reinject_every": REINJECT, "solver_power": int(env.cfg.solver_power),
@@ -817,6 +857,11 @@ def main():
             both = ((st[:, 0] == 1) & (st[:, 1] == 1) & (st[:, 2] == 1)).float().mean().item()
             out["bfs_active"] = {"reinject_every": REINJECT, "envs_with_both_searches_at_end": both,
                                  "envs_with_one_player_at_end": (st[:, 0] == 1).float().mean().item()}
+        if solver_active and args.solver_forms > 0:
+            try:
+                out["solver_active_forms"] = solver_forms(problem, rep, shape, N, dev, inject, actions, args.solver_forms, REINJECT)
+            except Exception as exc:  # noqa: BLE001
+                out["solver_active_forms"] = {"error": repr(exc)}
         if rollout is not None:
             out["open_loop_rollout"] = rollout
     if use_coll:
@@ -915,6 +960,59 @@ def launch_ranks(n):
         sys.stderr.write(f"bench.py launcher: {failed}; the remaining ranks were stopped\n")
         return 1
     return max(abs(rc) for rc in rcs)
+
+
+def solver_forms(problem, rep, shape, n_envs, dev, inject, actions, steps, reinject):
+    """The solver-active workload through the two forms that shrink a launch's synchronisation domain WITHOUT a ready mask
+    (VERDICT r5 Weak 2): pcgrl_rollout (`reinject` steps per launch between re-injections: waves advance independently, a launch
+    waits for the slowest env's SUM over the steps) and sub_batches = 4 (a launch waits for the slowest env of N / 4).
+    Synchronous solver, same maps and action rows as the timed region.  Secondary figures, never `value`."""
+    import numpy as np
+    import torch
+    from control_pcgrl_amd import SubBatchedVecEnv, VecPcgrlEnv
+    out = {"steps": steps, "reinject_every": reinject, "unit": "env-steps/s"}
+    rounds = max(1, steps // reinject)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    env = VecPcgrlEnv(problem, rep, shape, n_envs, device=dev, seeds=0x5EED + np.arange(n_envs), auto_reset=False)
+    rew = torch.empty((reinject, n_envs), dtype=torch.float32, device=dev)
+    done = torch.empty((reinject, n_envs), dtype=torch.uint8, device=dev)
+    stats = torch.empty((reinject, n_envs, env.n_stats), dtype=torch.int32, device=dev)
+    obs = torch.empty((reinject, n_envs) + env.obs_shape, dtype=torch.uint8, device=dev)
+
+    def rollout_rounds(n, first=0):
+        for r in range(first, first + n):
+            env._L.pcgrl_reset(env._h, None, inject.data_ptr(), None, stream)
+            rc = env._L.pcgrl_rollout(env._h, actions[(r * reinject) % (actions.shape[0] - reinject):].data_ptr(), reinject, 0,
+                                      obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr(), stats.data_ptr(), stream)
+            if rc:
+                raise RuntimeError(f"pcgrl_rollout rc={rc}")
+    rollout_rounds(2)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rollout_rounds(rounds, 2)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    env.check_errors()
+    env.close()
+    out["pcgrl_rollout"] = {"value": n_envs * rounds * reinject / dt, "us_per_step": dt / (rounds * reinject) * 1e6,
+                            "steps_per_launch": reinject}
+    sb = SubBatchedVecEnv(problem, rep, shape, n_envs, 4, device=dev, seeds=0x5EED + np.arange(n_envs), auto_reset=False)
+
+    def sb_steps(n, first=0):
+        for k in range(first, first + n):
+            if k % reinject == 0:
+                sb.reset(init_grids=inject)
+            sb.step(actions[k % actions.shape[0]])
+    sb_steps(2 * reinject)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    sb_steps(rounds * reinject, 2 * reinject)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    sb.check_errors()
+    sb.close()
+    out["sub_batches_4"] = {"value": n_envs * rounds * reinject / dt, "us_per_step": dt / (rounds * reinject) * 1e6}
+    return out
 
 
 def sub_batch_bench(workload, problem, rep, shape, n_envs, dev, ks, graph_steps=50, replays=20, one_batch_us=None):

@@ -53,6 +53,7 @@ SYMBOLS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_queue_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_ctrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcgrl_set_target_resampling": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pcgrl_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_refresh_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -77,6 +77,17 @@ struct alignas(16) JumpEntry {
   uint64_t a_hi, a_lo, g_hi, g_lo;
 };
 
+// Controllable mode, device-side target resampling (pcgrl_set_target_resampling; the reference's UniformNoiseyTargets.reset,
+// control_wrappers.py:453-471: every control target ~ U(cond_bounds) at every reset).  The record sits in device memory
+// IMMEDIATELY BEFORE Params::trg (one 256-byte section: the kernel-argument block has no room for another pointer), is read
+// by a kernel when an env resets, and is engine-wide run-time state like the static-tile parameters.
+struct alignas(256) TrgResample {
+  int32_t enable, pad_;
+  uint64_t seed;
+  double lo[PCGRL_MAX_STATS], hi[PCGRL_MAX_STATS];  // cond_bounds of control j (cfg.controls order)
+};
+static_assert(sizeof(TrgResample) == 256, "TrgResample: one 256-byte section in front of the targets");
+
 struct Params {
   pcgrl_config cfg;
   int32_t n_envs;
@@ -130,7 +141,7 @@ struct Params {
   // controllable mode (cfg.n_ctrl > 0): per-env target intervals, [N][PCGRL_MAX_STATS][2] = (lo, hi)
   double *trg;            // active targets (null in plain mode: cfg.trg_lo/hi apply to every env)
   double *trg_pending;    // queued by pcgrl_queue_targets, applied at the env's next reset
-  int32_t *trg_flag;      // [N] 1 = pending targets waiting
+  int32_t *trg_flag;      // [N] bit 0 = pending targets waiting; bits 1.. = resets that resampled this env's targets so far (draw counter)
   double *reward64;       // per-call outputs of pcgrl_step_ex
   float *ctrl_obs;
   // representation wrappers (cfg.static_tiles / cfg.act_window), see "ext" in pcgrl_kernels2d.h

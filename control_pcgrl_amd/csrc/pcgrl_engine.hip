@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void queue_targets_kernel(Params p, const doubl
     q[2 * k] = lo[(size_t)env * p.cfg.n_stats + k];
     q[2 * k + 1] = hi[(size_t)env * p.cfg.n_stats + k];
   }
-  p.trg_flag[env] = 1;
+  p.trg_flag[env] |= 1;  // (bits 1..: the env's resampling draw counter)
 }
 
 // pcgrl_reduce_episodes: sum of the per-env episode totals in a FIXED order (block b owns envs [b*chunk, (b+1)*chunk),
@@ -683,7 +683,10 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
         init[((size_t)i * PCGRL_MAX_STATS + k) * 2] = cfg->trg_lo[k];
         init[((size_t)i * PCGRL_MAX_STATS + k) * 2 + 1] = cfg->trg_hi[k];
       }
-    CREATE_CHK(dalloc((void **)&p.trg, init.size() * sizeof(double)));
+    // (the engine-wide resampling record sits right in front of the targets: TrgResample, pcgrl_common.h)
+    uint8_t *trg_block = nullptr;
+    CREATE_CHK(dalloc((void **)&trg_block, sizeof(TrgResample) + init.size() * sizeof(double)));
+    p.trg = (double *)(trg_block + sizeof(TrgResample));
     CREATE_CHK(dalloc((void **)&p.trg_pending, init.size() * sizeof(double)));
     CREATE_CHK(dalloc((void **)&p.trg_flag, (size_t)n_envs * sizeof(int32_t)));
     CREATE_CHK(hipMemcpy(p.trg, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -912,6 +915,25 @@ int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_t
   p.mask = d_mask;
   hipLaunchKernelGGL(queue_targets_kernel, dim3((p.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, d_trg_lo, d_trg_hi);
   HIPCHK(hipGetLastError());
+  return PCGRL_OK;
+}
+
+int pcgrl_set_target_resampling(pcgrl_handle h, int32_t enable, uint64_t seed, const double *lo, const double *hi) {
+  if (!h) return fail(PCGRL_EINVAL, "pcgrl_set_target_resampling: null handle");
+  if (h->p.cfg.n_ctrl == 0) return fail(PCGRL_EINVAL, "pcgrl_set_target_resampling: the engine was created without control metrics");
+  if (enable && (!lo || !hi)) return fail(PCGRL_EINVAL, "pcgrl_set_target_resampling: bounds missing");
+  ON_DEVICE(h->device);
+  TrgResample r;
+  memset(&r, 0, sizeof(r));
+  r.enable = enable ? 1 : 0;
+  r.seed = seed;
+  for (int j = 0; j < h->p.cfg.n_ctrl && enable; j++) {
+    if (!(lo[j] <= hi[j])) return fail(PCGRL_EINVAL, "pcgrl_set_target_resampling: need lo <= hi for every control metric");
+    r.lo[j] = lo[j];
+    r.hi[j] = hi[j];
+  }
+  HIPCHK(hipDeviceSynchronize());  // (launches in flight keep the parameters they were issued under)
+  HIPCHK(hipMemcpy((TrgResample *)h->p.trg - 1, &r, sizeof(r), hipMemcpyHostToDevice));
   return PCGRL_OK;
 }
 

@@ -834,15 +834,34 @@ __device__ inline double get_loss(const Params &p, const int32_t *st) {
   return loss;
 }
 
+// The c-th resampled target of env `env`'s control j under `seed` (pcgrl_set_target_resampling): a pure function of its
+// arguments -- counter-based, so a captured launch re-targets at every replay with no host call -- uniform in [lo, hi):
+// u * (hi - lo) + lo with u a 53-bit double, exactly numpy's  random() * (ub - lb) + lb  (control_wrappers.py:456-459).
+__host__ __device__ inline uint64_t trg_mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline double trg_resampled(uint64_t seed, int env, uint32_t c, int j, double lo, double hi) {
+  const uint64_t r = trg_mix64(trg_mix64(seed + (uint64_t)c * 0x9e3779b97f4a7c15ull) ^
+                               ((uint64_t)(uint32_t)env * 0xd1b54a32d192ed03ull + (uint64_t)(j + 1) * 0x8cb92ba72f3d8dd7ull));
+  const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0);
+  return u * (hi - lo) + lo;
+}
+
 // Target intervals of one env.  Plain mode: the config's static targets.  Controllable mode (control_wrappers.py:27-121):
 // per-env targets in HBM; targets queued by pcgrl_queue_targets replace the control metrics' targets at the env's next
-// reset (:174-178), which is when `take_pending` is set.
+// reset (:174-178), which is when `take_pending` is set.  With target resampling switched on (TrgResample) every reset
+// draws new control targets instead -- the reference's UniformNoiseyTargets.reset overwrites the queue with its draw
+// (:453-471) -- from the env's own counter-based stream; the env's draw counter lives in bits 1.. of its trg_flag word.
 template <int NS>
 struct EnvTargets {
   double lo[NS], hi[NS];
   bool took_pending;
+  int32_t new_flag;
   __device__ inline void load(const Params &p, int env, bool at_reset) {
     took_pending = false;
+    new_flag = 0;
     if (p.trg == nullptr) {
 #pragma unroll
       for (int k = 0; k < NS; k++) {
@@ -853,17 +872,37 @@ struct EnvTargets {
     }
     const double *a = p.trg + (size_t)env * PCGRL_MAX_STATS * 2;
     const double *q = p.trg_pending + (size_t)env * PCGRL_MAX_STATS * 2;
-    took_pending = at_reset && p.trg_flag[env] != 0;
+    // (at a reset the flag word and the active targets may have been written by this very launch -- an earlier reset of the
+    // same env inside a rollout: read past the vector L1)
+    auto ld = [&](const double *x) -> double {
+      if (!at_reset) return *x;
+      const uint64_t v = __hip_atomic_load((const uint64_t *)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return __longlong_as_double((long long)v);
+    };
+    const int32_t flag = at_reset ? __hip_atomic_load(&p.trg_flag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const TrgResample *rs = (const TrgResample *)p.trg - 1;
+    const bool resample = at_reset && rs->enable != 0;
+    took_pending = at_reset && ((flag & 1) != 0 || resample);
+    new_flag = resample ? (int32_t)(((uint32_t)flag >> 1) + 1u) << 1 : (flag & ~1);
     uint32_t ctrl_mask = 0;
     for (int j = 0; j < p.cfg.n_ctrl; j++) ctrl_mask |= 1u << p.cfg.ctrl_idx[j];
 #pragma unroll
     for (int k = 0; k < NS; k++) {
-      const bool pend = took_pending && ((ctrl_mask >> k) & 1u);
-      lo[k] = pend ? q[2 * k] : a[2 * k];
-      hi[k] = pend ? q[2 * k + 1] : a[2 * k + 1];
+      const bool pend = took_pending && !resample && ((ctrl_mask >> k) & 1u);
+      lo[k] = pend ? q[2 * k] : ld(a + 2 * k);
+      hi[k] = pend ? q[2 * k + 1] : ld(a + 2 * k + 1);
+    }
+    if (resample) {
+      const uint32_t c = (uint32_t)flag >> 1;
+      for (int j = 0; j < p.cfg.n_ctrl; j++) {
+        const double t = trg_resampled(rs->seed, env, c, j, rs->lo[j], rs->hi[j]);
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+          if (k == p.cfg.ctrl_idx[j]) lo[k] = hi[k] = t;
+      }
     }
   }
-  // one lane per env makes the queued targets the active ones
+  // one lane per env makes the queued (or resampled) targets the active ones
   __device__ inline void commit(const Params &p, int env) const {
     if (p.trg == nullptr || !took_pending) return;
     double *a = p.trg + (size_t)env * PCGRL_MAX_STATS * 2;
@@ -872,7 +911,7 @@ struct EnvTargets {
       a[2 * k] = lo[k];
       a[2 * k + 1] = hi[k];
     }
-    p.trg_flag[env] = 0;
+    p.trg_flag[env] = new_flag;
   }
   // control_wrappers.py:318-345 get_loss
   __device__ inline double loss(const pcgrl_config &c, const int32_t *st) const {

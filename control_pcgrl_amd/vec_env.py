@@ -256,6 +256,18 @@ class VecPcgrlEnv:
         self.queue_targets(trgs, mask=mask)
         return trgs
 
+    def set_target_resampling(self, enable=True, seed=0):
+        """UniformNoiseyTargets on the device (control_wrappers.py:442-471): from each env's next reset on -- explicit or
+        automatic, also inside a captured HIP graph -- every control target is drawn ~ U(cond_bounds) from the env's own
+        counter-based stream (pcgrl_set_target_resampling) and replaces whatever was queued.  `resampled_target` below
+        restates the draw on the host."""
+        if not self.controls:
+            raise ValueError("this env was built without `controls`")
+        lo = np.array([self.spec.cond_bounds[k][0] for k in self.controls], dtype=np.float64)
+        hi = np.array([self.spec.cond_bounds[k][1] for k in self.controls], dtype=np.float64)
+        _lib.check(self._L.pcgrl_set_target_resampling(self._h, 1 if enable else 0, int(seed) & (2 ** 64 - 1),
+                                                       lo.ctypes.data, hi.ctypes.data), "pcgrl_set_target_resampling")
+
     def sample_actions(self, seed=0, out=None):
         """action_space.sample() for every env, drawn on the device (pcgrl_sample_actions: the reference's random-action
         loops, profile_env.py:134-139): int32 [N] (or [N, prod(act_window)]), fresh at every call and at every replay of a

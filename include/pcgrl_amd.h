@@ -181,6 +181,16 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
  * control metrics' columns are used.  d_mask NULL = every env.  Requires cfg.n_ctrl > 0. */
 int pcgrl_queue_targets(pcgrl_handle h, const uint8_t *d_mask, const double *d_trg_lo, const double *d_trg_hi,
                         void *stream);
+/* UniformNoiseyTargets (control_wrappers.py:442-471): at every reset each control target is drawn ~ U(cond_bounds[k]) and
+ * replaces whatever was queued (its reset() overwrites the queue with the draw, :453-471).  The reference draws from numpy's
+ * GLOBAL generator (no seed of its own); the engine draws on the device, inside the reset path of every kernel that resets an env
+ * (pcgrl_reset, the auto-resets of pcgrl_step[_ex] / pcgrl_rollout[_ex]), from a counter-based stream per env: the c-th draw
+ * of env i's control j under `seed` is  u * (hi[j] - lo[j]) + lo[j]  with u = (mix(seed, c, i, j) >> 11) * 2^-53  (trg_resampled,
+ * csrc/pcgrl_kernels2d.h; the draw counter c is part of the env's checkpointed state).  A closed loop captured in a HIP graph
+ * therefore re-targets at every episode end with no host call.  lo / hi: HOST arrays [n_ctrl], cfg.controls order
+ * (Problem.cond_bounds).  Engine-wide run-time parameters like pcgrl_set_static's: synchronous, in force from each env's next
+ * reset on, not part of pcgrl_export_state.  enable = 0 switches back to queued targets. */
+int pcgrl_set_target_resampling(pcgrl_handle h, int32_t enable, uint64_t seed, const double *lo, const double *hi);
 /* the control observation of the current state (after reset): float [N][2*n_ctrl] */
 int pcgrl_ctrl_observe(pcgrl_handle h, float *d_ctrl_obs, void *stream);
 

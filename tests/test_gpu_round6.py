@@ -196,3 +196,83 @@ def test_step_ready_auto_reset_on_small_maps_vs_oracle():
     assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"])
     assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"])
     env.check_errors()
+
+
+# ------------------------------------------------------------------------------------- device-side target resampling
+M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M64
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M64
+    return z ^ (z >> 31)
+
+
+def _resampled(seed, env, c, j, lo, hi):
+    """host restatement of trg_resampled (csrc/pcgrl_kernels2d.h)"""
+    r = _mix64(_mix64((seed + c * 0x9e3779b97f4a7c15) & M64) ^ ((env * 0xd1b54a32d192ed03 + (j + 1) * 0x8cb92ba72f3d8dd7) & M64))
+    return float(r >> 11) * (1.0 / 9007199254740992.0) * (hi - lo) + lo
+
+
+@pytest.mark.parametrize("problem,rep,shape,controls", [("binary", "narrow", (16, 16), ["regions", "path-length"]),
+                                                        ("zelda", "turtle", (16, 16), ["nearest-enemy", "path-length"]),
+                                                        ("minecraft_3D_maze", "narrow", (7, 7, 7), ["n_jump", "path-length"])])
+def test_target_resampling_in_a_captured_graph_vs_oracle(problem, rep, shape, controls):
+    """pcgrl_set_target_resampling: a HIP graph of T step launches spanning several episodes re-targets every env at every
+    auto-reset with no host call; rewards (float64), control observations and stats equal the oracle's, which is handed the
+    same draws through its target queue (the reference's UniformNoiseyTargets.reset, control_wrappers.py:453-471)."""
+    n, T, seed = 192, 150, 12345
+    kw = dict(controls=controls, change_percentage=0.05)
+    env = _vec(problem, rep, shape, n, seeds=np.arange(n), auto_reset=True, reward_dtype=torch.float64, **kw)
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=np.arange(n), **kw)
+    env.set_target_resampling(True, seed)
+    bounds = [env.spec.cond_bounds[k] for k in controls]
+    cnt = np.zeros(n, int)
+
+    def draws():
+        return {k: np.array([_resampled(seed, i, int(cnt[i]), j, bounds[j][0], bounds[j][1]) for i in range(n)]) for j, k in enumerate(controls)}
+
+    orc.queue_targets(draws())
+    cnt += 1
+    env.reset()
+    orc.reset()
+    assert np.allclose(env.ctrl_obs.cpu().numpy(), orc.ctrl_obs(), rtol=0, atol=1e-6)
+    g = torch.Generator().manual_seed(3)
+    acts = torch.randint(0, env.num_actions, (T, n), generator=g, dtype=torch.int32).cuda()
+    rew = torch.zeros((T, n), dtype=torch.float64, device="cuda")
+    done = torch.zeros((T, n), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros((T, n, env.n_stats), dtype=torch.int32, device="cuda")
+    cobs = torch.zeros((T, n, 2 * len(controls)), dtype=torch.float32, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            cap = torch.cuda.current_stream().cuda_stream
+            for t in range(T):
+                rc = env._L.pcgrl_step_ex(env._h, acts[t].data_ptr(), 1, None, None, rew[t].data_ptr(), done[t].data_ptr(),
+                                          stats[t].data_ptr(), cobs[t].data_ptr(), cap)
+                assert rc == 0
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    env.check_errors()
+    rew, done, stats, cobs, a_np = rew.cpu().numpy(), done.cpu().numpy().astype(bool), stats.cpu().numpy(), cobs.cpu().numpy(), acts.cpu().numpy()
+    for t in range(T):
+        orc.queue_targets(draws())  # what the next reset of each env will draw
+        _, orew, odone, ostats = orc.step(a_np[t], auto_reset=True, want_obs=False)
+        assert np.array_equal(done[t], odone), t
+        assert np.array_equal(stats[t], ostats), t
+        assert np.abs(rew[t] - orew).max() <= 1e-9, (t, np.abs(rew[t] - orew).max())
+        assert np.allclose(cobs[t], orc.ctrl_obs(), rtol=0, atol=1e-6), t
+        cnt += odone
+    assert done.sum(0).min() >= 2, "every env re-targeted at least twice inside the graph"
+    # the same through pcgrl_rollout_ex (several resets of an env inside ONE launch) on a twin engine
+    twin = _vec(problem, rep, shape, n, seeds=np.arange(n), auto_reset=True, reward_dtype=torch.float64, **kw)
+    twin.set_target_resampling(True, seed)
+    twin.reset()
+    _, r2, d2, s2 = twin.rollout(acts, want_obs="none")
+    assert np.array_equal(d2.cpu().numpy(), done) and np.array_equal(s2.cpu().numpy(), stats)
+    assert np.abs(r2.cpu().numpy() - rew).max() <= 1e-9
+    assert np.allclose(twin.ctrl_obs.cpu().numpy(), cobs[-1], rtol=0, atol=1e-6)
+    twin.check_errors()
