@@ -49,6 +49,7 @@ SYMBOLS = {
     "pcgrl_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_rollout_is_one_launch": (C.c_int32, [C.c_void_p]),
+    "pcgrl_set_rollout_form": (C.c_int, [C.c_void_p, C.c_int32]),
     "pcgrl_rollout_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcgrl_queue_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -53,6 +53,12 @@ struct pcgrl_engine {
   bool soko_grow_failed = false; // the last growth attempt failed (message in soko_grow_msg): not retried by itself
   std::string soko_grow_msg;
   uint8_t *hdr_host = nullptr;   // pinned: the 256-byte header of pcgrl_export_state images (rebuilt by pcgrl_set_static)
+  // development switches, read ONCE at pcgrl_create (never getenv() in a stepping call: not thread-safe against a host's
+  // putenv, and a stray variable must not steer a running engine): PCGRL_ROLLOUT_KERNEL 1 = always the one-launch rollout
+  // kernel, 0 = always step launches, unset = by shape; PCGRL_OBS_NT_MB = observation bytes per launch (MB) from which the
+  // stores are non-temporal (default 384, 0 = never)
+  int rollout_form = -1;
+  long obs_nt_mb = 384;
   bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
   int obs_ndim = 0;
@@ -242,10 +248,9 @@ static std::vector<JumpEntry> make_jump_table(int H, int W, int last = -1) {
   return t;
 }
 
-// observation bytes of one launch from which the 16x16 kernels store non-temporally (profiles/r05_dev_traces.md)
-static bool obs_nt_for(int64_t bytes_per_launch) {
-  static const long nt_mb = getenv("PCGRL_OBS_NT_MB") ? atol(getenv("PCGRL_OBS_NT_MB")) : 384;  // (development: A/B; 0 = never)
-  return nt_mb > 0 && bytes_per_launch >= (int64_t)nt_mb * 1000000;
+// observation bytes of one launch from which the 16x16 / 3-D kernels store non-temporally (profiles/r05_dev_traces.md)
+static bool obs_nt_for(const pcgrl_engine *e, int64_t bytes_per_launch) {
+  return e->obs_nt_mb > 0 && bytes_per_launch >= (int64_t)e->obs_nt_mb * 1000000;
 }
 
 // ---------------------------------------------------------------------------------------------- dispatch
@@ -561,6 +566,11 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
   if (rc) return rc;
   ON_DEVICE(device);
   pcgrl_engine *e = new pcgrl_engine();
+  {
+    const char *f = getenv("PCGRL_ROLLOUT_KERNEL");
+    if (f != nullptr && (f[0] == '0' || f[0] == '1')) e->rollout_form = f[0] - '0';
+    if (getenv("PCGRL_OBS_NT_MB")) e->obs_nt_mb = atol(getenv("PCGRL_OBS_NT_MB"));
+  }
   e->device = device;
   e->lpe = lpe;
   e->obs_bytes = obs_bytes;
@@ -612,7 +622,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     const bool fast_cfg = Hc == 16 && Wc == 16 && cfg->obs_window[0] == 32 && OWc == 32;
     p.obs16 = (!is3d && fast_cfg) ? 1 : 0;
     // non-temporal observation stores where a launch writes far more than the 256 MB last-level cache holds (store_obs16_nt)
-    if ((p.obs16 || is3d) && obs_nt_for((int64_t)n_envs * obs_bytes)) p.obs16 |= 2;  // (3-D: bit 1 alone)
+    if ((p.obs16 || is3d) && obs_nt_for(e, (int64_t)n_envs * obs_bytes)) p.obs16 |= 2;  // (3-D: bit 1 alone)
     // (only where the one-hot rows are what limits occupancy: at 13 KB per workgroup -- binary 32 x 32 -- the rows are
     // cheaper: 14.0 vs 15.6 us per launch; at 26 KB -- binary 64 x 64 -- 67 vs 47.5; at 38 KB -- zelda 32 x 32 -- 44 vs 27.6)
     if (!is3d && cfg->representation != PCGRL_REP_WIDE && !cfg->static_tiles && !fast_cfg && (OWc * Cc) % 16 == 0 &&
@@ -715,6 +725,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
       pcgrl_destroy(e);
       return fail(PCGRL_EHIP, std::string("hipHostMalloc (state header): ") + hipGetErrorString(he));
     }
+    memset(e->hdr_host, 0, 256);
     state_header_build(e);
   }
   *out = e;
@@ -829,14 +840,20 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
 // zelda_bigger 217 vs 126, binary_bigger 60 vs 51, binary_big 16.7 vs 15.5 (bench lines of rounds 4 / 5).  There the call
 // issues its n_steps as step launches: same results by the entry point's own definition.
 static bool rollout_as_steps(const pcgrl_engine *h) {
-  const char *f = getenv("PCGRL_ROLLOUT_KERNEL");  // development / tests: 1 = always the rollout kernel, 0 = always step launches
-  if (f != nullptr && (f[0] == '0' || f[0] == '1')) return f[0] == '0';
+  if (h->rollout_form >= 0) return h->rollout_form == 0;  // (development / tests, read at pcgrl_create)
   // (maps of more than 16 rows without tile codes, e.g. binary_big 32 x 32: 16.7 us per step in one launch -- its kernel sits at
   // 256 VGPRs -- against 15.0-15.5 as step launches)
+  // lpe > 16: a 2-D map of more than 16 rows OR more than 32 columns (64-bit row masks run on 32 / 64 lanes per env)
   return h->p.cfg.problem != PCGRL_PROB_MC3DMAZE && (h->p.obs_codes > 0 || h->lpe > 16);
 }
 
 int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h) { return h ? (rollout_as_steps(h) ? 0 : 1) : -1; }
+
+int pcgrl_set_rollout_form(pcgrl_handle h, int32_t form) {
+  if (!h || form < -1 || form > 1) return fail(PCGRL_EINVAL, "pcgrl_set_rollout_form: form must be -1 (by shape), 0 (step launches) or 1 (one launch)");
+  h->rollout_form = form;
+  return PCGRL_OK;
+}
 
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats, float *d_ctrl_obs,
@@ -867,7 +884,7 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
   p.obs_last_only = obs_last_only;
   p.obs_env_bytes = h->obs_bytes;
   // (a rollout that keeps every step's observation writes n_steps times a step launch's bytes: 805 MB for 64 steps of 4096 binary envs)
-  if ((p.obs16 || h->p.cfg.problem == PCGRL_PROB_MC3DMAZE) && d_obs && !obs_last_only && obs_nt_for((int64_t)n_steps * h->p.n_envs * h->obs_bytes)) p.obs16 |= 2;
+  if ((p.obs16 || h->p.cfg.problem == PCGRL_PROB_MC3DMAZE) && d_obs && !obs_last_only && obs_nt_for(h, (int64_t)n_steps * h->p.n_envs * h->obs_bytes)) p.obs16 |= 2;
   p.reward = d_reward;
   p.reward64 = d_reward64;
   p.done = d_done;
@@ -985,7 +1002,7 @@ int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls,
     return fail(PCGRL_EINVAL, "pcgrl_set_static: static walls need a map of at least 3x3");
   if (static_prob >= 0.0) h->p.cfg.static_prob = static_prob;
   if (n_static_walls >= 0) h->p.cfg.n_static_walls = n_static_walls;
-  h->p.cfg.static_eval = eval_mode ? 1 : 0;
+  if (eval_mode >= 0) h->p.cfg.static_eval = eval_mode ? 1 : 0;
   state_header_build(h);
   return PCGRL_OK;
 }
@@ -1187,7 +1204,10 @@ static void state_header_build(pcgrl_handle h) {
   hdr.static_prob = h->p.cfg.static_prob;
   hdr.n_static_walls = h->p.cfg.n_static_walls;
   hdr.static_eval = h->p.cfg.static_eval;
-  memset(h->hdr_host, 0, STATE_HDR_BYTES);
+  // (no memset: the bytes behind the struct were zeroed once at create, and an export issued earlier may still be copying
+  // from this pinned block -- magic / fingerprint / sizes are rewritten with the values they already hold, only the three
+  // static-tile fields really change.  pcgrl_set_static must still be ordered after exports that are to carry the OLD
+  // parameters: include/pcgrl_amd.h)
   memcpy(h->hdr_host, &hdr, sizeof(hdr));
 }
 

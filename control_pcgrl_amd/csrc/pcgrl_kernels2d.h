@@ -902,8 +902,8 @@ struct EnvTargets {
       }
     }
   }
-  // one lane per env makes the queued (or resampled) targets the active ones
-  __device__ inline void commit(const Params &p, int env) const {
+  // one lane per env makes the queued (or resampled) targets the active ones (once per load: a second call is a no-op)
+  __device__ inline void commit(const Params &p, int env) {
     if (p.trg == nullptr || !took_pending) return;
     double *a = p.trg + (size_t)env * PCGRL_MAX_STATS * 2;
 #pragma unroll
@@ -911,7 +911,8 @@ struct EnvTargets {
       a[2 * k] = lo[k];
       a[2 * k + 1] = hi[k];
     }
-    p.trg_flag[env] = new_flag;
+    __hip_atomic_store(&p.trg_flag[env], new_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    took_pending = false;
   }
   // control_wrappers.py:318-345 get_loss
   __device__ inline double loss(const pcgrl_config &c, const int32_t *st) const {
@@ -1878,11 +1879,14 @@ template <int PROB, int LPE, typename M, bool FAST, bool CTRL, int PAIRS = 1, bo
 #ifndef PCGRL_B64_WAVES
 #define PCGRL_B64_WAVES 6  // waves per SIMD the binary 64-bit-mask step kernel is compiled for (development: A/B builds)
 #endif
+#ifndef PCGRL_SKA_WAVES
+#define PCGRL_SKA_WAVES 2  // min waves per SIMD of the asynchronous sokoban 16x16 step kernel (169 VGPRs, no scratch; 3 and 4 -- 128 VGPRs + 188 B of scratch -- measure the same: 1.13-1.14 x 10^7 env-steps/s at budget 16)
+#endif
 #ifndef PCGRL_STEP_WAVES
 #define PCGRL_STEP_WAVES 1  // minimum waves per SIMD the binary 16x16 step kernel is compiled for (register budget)
 #endif
 __global__ __launch_bounds__((PROB == PCGRL_PROB_SOKOBAN && !SKA) ? 512 : 128 * PAIRS,
-                             (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? PCGRL_B64_WAVES : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : ((FAST && PROB == PCGRL_PROB_SOKOBAN && !CTRL) ? 4 : 1))))
+                             (FAST && PROB == PCGRL_PROB_BINARY) ? PCGRL_STEP_WAVES : ((!FAST && PROB == PCGRL_PROB_BINARY && sizeof(M) == 8) ? PCGRL_B64_WAVES : ((FAST && PROB == PCGRL_PROB_ZELDA && !CTRL) ? 6 : ((FAST && PROB == PCGRL_PROB_SOKOBAN && !CTRL) ? (SKA ? PCGRL_SKA_WAVES : 4) : 1))))
 void step_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;  // tile planes + incremental-stats masks

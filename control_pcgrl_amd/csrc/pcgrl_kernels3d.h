@@ -1650,6 +1650,7 @@ void m3_kernel(Params p, int cpl) {
         ep_return = 0.0;
         trg.load(p, env, true);
         last_loss = trg.loss(p.cfg, st);
+        if (c.lane == 0) trg.commit(p, env);  // (a rollout may reset the env again: the next reset draws / pops anew)
         if (want_obs) m3_encode_obs<2 * DIM>(c.dirt, c.over, c, p, env, pos, false, (uint2 *)W.info, M3C<SC>::CELLS / 2, obs_k);
       }
     }

@@ -403,13 +403,11 @@ class VecPcgrlEnv:
         return out
 
     def set_static(self, static_prob=None, n_static_walls=None, eval_mode=None):
-        """set_static_prob / set_n_static_walls / set_eval_mode (:256-263; rl/evaluate.py:128-129); next reset on."""
-        if eval_mode is not None:
-            self._static_eval = bool(eval_mode)
+        """set_static_prob / set_n_static_walls / set_eval_mode (:256-263; rl/evaluate.py:128-129); next reset on.  None
+        leaves a value as the engine holds it (also after load_state_dict of a checkpoint taken in another mode)."""
         _lib.check(self._L.pcgrl_set_static(self._h, -1.0 if static_prob is None else float(static_prob),
                                             -1 if n_static_walls is None else int(n_static_walls),
-                                            int(getattr(self, "_static_eval", bool(self.cfg.static_eval)))),
-                   "pcgrl_set_static")
+                                            -1 if eval_mode is None else int(bool(eval_mode))), "pcgrl_set_static")
 
     def check_errors(self):
         """Synchronises; raises ValueError if a kernel saw an action outside the action space."""
@@ -590,6 +588,11 @@ class SubBatchedVecEnv:
         """sub-batch i alone, on its own stream (ordered after the work already queued on the current stream); returns
         the sub-batch's step tuple -- valid once wait(i) has been called (or its stream synchronised)"""
         self._fork(i)
+        # `actions` was allocated on the caller's stream and is read on streams[i]: a temporary (policy(obs).argmax().int())
+        # freed right after this call must not be handed out again before that read has happened (not while capturing:
+        # a captured graph keeps its buffers alive itself)
+        if isinstance(actions, torch.Tensor) and actions.is_cuda and not torch.cuda.is_current_stream_capturing():
+            actions.record_stream(self.streams[i])
         with torch.cuda.stream(self.streams[i]):
             return self.envs[i].step(actions)
 
@@ -636,16 +639,64 @@ class SubBatchedVecEnv:
         self.wait()
         return {"sub_batches": [e.state_dict() for e in self.envs]}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, mask=None):
         if len(sd.get("sub_batches", ())) != self.k:
             raise ValueError(f"state_dict of {len(sd.get('sub_batches', ()))} sub-batches, this env has {self.k}")
         self.wait()
-        for e, part in zip(self.envs, sd["sub_batches"]):
-            e.load_state_dict(part)
+        for i, (e, part) in enumerate(zip(self.envs, sd["sub_batches"])):
+            e.load_state_dict(part, mask=self._rows(mask, i))
 
     def check_errors(self):
         for e in self.envs:
             e.check_errors()
+
+    # -- the rest of VecPcgrlEnv's surface, fanned out over the sub-batches ---------------------------------------------
+    def _rows(self, v, i):
+        n = self.n_sub
+        return None if v is None else torch.as_tensor(v)[i * n:(i + 1) * n]
+
+    def seed(self, seeds):
+        s = np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.num_envs,))
+        for i, e in enumerate(self.envs):
+            e.seed(s[i * self.n_sub:(i + 1) * self.n_sub])
+
+    def set_static(self, static_prob=None, n_static_walls=None, eval_mode=None):
+        for e in self.envs:
+            e.set_static(static_prob, n_static_walls, eval_mode)
+
+    def get_static(self):
+        self.wait()
+        return torch.cat([e.get_static() for e in self.envs])
+
+    def queue_targets(self, trgs, mask=None):
+        for i, e in enumerate(self.envs):
+            e.queue_targets({k: (v if isinstance(v, tuple) or not hasattr(v, "__len__") else self._rows(v, i)) for k, v in trgs.items()},
+                            mask=self._rows(mask, i))
+
+    def set_target_resampling(self, enable=True, seed=0):
+        raise NotImplementedError("target resampling draws from (seed, env index): per sub-batch the env indices restart at 0 -- use one "
+                                  "VecPcgrlEnv, or call envs[i].set_target_resampling with distinct seeds")
+
+    @property
+    def ctrl_obs(self):
+        self.wait()
+        return None if self.envs[0].ctrl_obs is None else torch.cat([e.ctrl_obs for e in self.envs])
+
+    def get_rng_state(self):
+        self.wait()
+        return torch.cat([e.get_rng_state() for e in self.envs])
+
+    def set_rng_state(self, rng, mask=None):
+        for i, e in enumerate(self.envs):
+            e.set_rng_state(self._rows(rng, i), mask=self._rows(mask, i))
+
+    def solver_pool_slots(self):
+        """(slots, full size, failed) summed over the sub-batches' engines (each keeps a pool of its own)"""
+        parts = [e.solver_pool_slots() for e in self.envs]
+        return sum(p[0] for p in parts), sum(p[1] for p in parts), any(p[2] for p in parts)
+
+    def rollout(self, actions, want_obs="all"):
+        raise NotImplementedError("open-loop rollouts: use VecPcgrlEnv (a rollout's waves advance independently already)")
 
 
 def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True, sub_batches=1):
@@ -660,6 +711,9 @@ def make_vec_env(cfg, num_envs, device="cuda:0", seeds=None, auto_reset=True, su
     bad = {k: v for k, v in unsupported.items() if v not in (None, 0, False)}
     if bad:
         raise NotImplementedError(f"outside the accelerated hot path (SURVEY.md section 8f 'next'): {bad}")
+    if int(sub_batches) > 1 and _cfg_get(cfg, "controls"):
+        raise NotImplementedError("sub_batches > 1 with cfg.controls: SubBatchedVecEnv.step() has no float64 rewards / control "
+                                  "observation of the whole batch (use sub_batches=1, or step_async per sub-batch)")
     ctor = VecPcgrlEnv if int(sub_batches) <= 1 else (lambda **kw: SubBatchedVecEnv(sub_batches=sub_batches, **kw))
     return ctor(
         problem=_cfg_get(cfg, "task.problem"), representation=_cfg_get(cfg, "representation"),

@@ -158,9 +158,9 @@ int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles +
 /* Open-loop rollout: n_steps consecutive pcgrl_step()s of every env in ONE launch, for action sequences that do not
  * depend on the observations (random-action rollouts as in the reference's own env tests, replays, evaluation of stored
  * action sequences).  Results are identical to n_steps calls of pcgrl_step; there is no kernel boundary between steps.
- * (One launch where that is the faster form: 2-D maps of up to 16 rows and the 3-D mazes -- 1.7 x / 2 x the stepping rate
- * for binary-narrow / the 7^3 maze.  On 2-D maps of more than 16 rows the observation wants a wavefront of its own next to
- * the statistics and the call issues its n_steps as step launches instead: same results.)
+ * (One launch where that is the faster form: 2-D maps of up to 16 rows and 32 columns and the 3-D mazes -- 1.7 x / 2 x the
+ * stepping rate for binary-narrow / the 7^3 maze.  On 2-D maps of more than 16 rows or more than 32 columns the observation
+ * wants a wavefront of its own next to the statistics and the call issues its n_steps as step launches instead: same results.)
  *   d_actions int32 [n_steps][N]          d_reward float [n_steps][N]      d_done uint8 [n_steps][N]
  *   d_stats   int32 [n_steps][N][n_stats] d_obs uint8 [n_steps][N][obs_bytes], or [N][obs_bytes] (the observation
  *             after the last step only) when obs_last_only != 0.  Any output pointer may be NULL.
@@ -170,7 +170,11 @@ int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles +
  * launch exactly as with pcgrl_step_ex. */
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
-int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h); /* 1: one launch per call; 0: n_steps step launches (2-D maps of more than 16 rows) */
+int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h); /* 1: one launch per call; 0: n_steps step launches (2-D maps of more than 16 rows or 32 columns) */
+/* which form pcgrl_rollout[_ex] takes on this engine: -1 = chosen by shape (default), 1 = always the one-launch kernel, 0 = always
+ * n_steps step launches.  Same results either way (tests and the fuzzer exercise both on every shape).  The environment variable
+ * PCGRL_ROLLOUT_KERNEL=0|1 sets the engine's initial value at pcgrl_create (development). */
+int pcgrl_set_rollout_form(pcgrl_handle h, int32_t form);
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats,
                      float *d_ctrl_obs, void *stream);
@@ -219,7 +223,9 @@ int pcgrl_get_last_episode(pcgrl_handle h, double *d_ep_return, int32_t *d_ep_le
  * bordered layout (entry (r+1, c+1) protects map cell (r, c); the border ring is always 1).  Requires cfg.static_tiles. */
 int pcgrl_get_static(pcgrl_handle h, uint8_t *d_static, void *stream);
 /* set_static_prob / set_n_static_walls / set_eval_mode (:256-263; used by rl/evaluate.py:128-129): take effect at each
- * env's next reset.  n_static_walls < 0 or static_prob < 0 leave that value unchanged. */
+ * env's next reset.  n_static_walls < 0, static_prob < 0 or eval_mode < 0 leave that value unchanged.  Host-side and
+ * immediate: a pcgrl_export_state issued earlier on a stream that has not run yet (or a captured one replayed later) carries
+ * the parameters in force when its copy EXECUTES -- order the call after exports that are to keep the old ones. */
 int pcgrl_set_static(pcgrl_handle h, double static_prob, int32_t n_static_walls, int32_t eval_mode);
 
 /* Problem.get_stats on n caller-provided maps (evo/evolve.py:1083-1120 calls it once per individual):

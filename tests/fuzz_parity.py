@@ -283,12 +283,11 @@ def run_case(case, seed, verbose=False):
             a = draw_actions(t, lead=(K,))
             # pcgrl_rollout picks its form by map size (one launch / n step launches); both forms stay under test on every shape
             form = str(rng.choice(["auto", "1", "0"]))
-            if form != "auto":
-                os.environ["PCGRL_ROLLOUT_KERNEL"] = form
+            env._L.pcgrl_set_rollout_form(env._h, -1 if form == "auto" else int(form))
             try:
                 obs, rew, done, stats = env.rollout(a.to(env.device), want_obs=want)
             finally:
-                os.environ.pop("PCGRL_ROLLOUT_KERNEL", None)
+                env._L.pcgrl_set_rollout_form(env._h, -1)
             case.setdefault("_trace", []).append(f"rollout_form={form}")
             rew, done, stats = rew.cpu().numpy().astype(np.float64), done.cpu().numpy(), stats.cpu().numpy()
             obs = None if obs is None else obs.cpu().numpy()

@@ -276,3 +276,81 @@ def test_target_resampling_in_a_captured_graph_vs_oracle(problem, rep, shape, co
     assert np.abs(r2.cpu().numpy() - rew).max() <= 1e-9
     assert np.allclose(twin.ctrl_obs.cpu().numpy(), cobs[-1], rtol=0, atol=1e-6)
     twin.check_errors()
+
+
+# ------------------------------------------------------------------------------------- round-5 advisor findings
+def test_set_static_after_a_checkpoint_keeps_the_imported_eval_mode():
+    """a checkpoint taken in evaluation mode, loaded into an engine created in training mode; set_static(static_prob=x)
+    afterwards must not switch the engine back (the wrapper used to pass its construction-time flag)"""
+    n = 48
+    kw = dict(static_prob=0.4, n_static_walls=2)
+    src = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), static_eval=True, **kw)
+    dst = _vec("binary", "narrow", (16, 16), n, seeds=100 + np.arange(n), static_eval=False, **kw)
+    src.reset()
+    dst.reset()
+    dst.load_state_dict(src.state_dict())
+    for e in (src, dst):
+        e.set_static(static_prob=0.25)  # eval_mode=None: keep what the engine holds
+        e.reset()
+    assert torch.equal(src.get_static(), dst.get_static())
+    orc = po.OracleVecEnv("binary", "narrow", (16, 16), n, seeds=np.arange(n), static_eval=True, **kw)
+    orc.reset()
+    orc.set_static(static_prob=0.25, eval_mode=True)
+    orc.reset()
+    assert np.array_equal(dst.get_static().cpu().numpy(), orc.static_tiles())
+    src.check_errors(); dst.check_errors()
+
+
+def test_3d_non_temporal_observation_stores_vs_oracle(monkeypatch):
+    """the 3-D observe waves' non-temporal store path (launches beyond the threshold, 384 MB by default): the threshold is read
+    at pcgrl_create, so an engine created under PCGRL_OBS_NT_MB=1 takes that path at a testable batch size"""
+    monkeypatch.setenv("PCGRL_OBS_NT_MB", "1")
+    n = 160  # 160 x 10 976 B = 1.76 MB per launch
+    env = _vec("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), auto_reset=True)
+    monkeypatch.delenv("PCGRL_OBS_NT_MB")
+    orc = po.OracleVecEnv("minecraft_3D_maze", "narrow", (7, 7, 7), n, seeds=np.arange(n), threads=8)
+    obs, _ = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.reset())
+    g = torch.Generator().manual_seed(1)
+    for t in range(60):
+        a = torch.randint(0, 2, (n,), generator=g, dtype=torch.int32)
+        obs, rew, done, _, info = env.step(a.cuda())
+        oobs, orew, odone, ostats = orc.step(a.numpy(), auto_reset=True)
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(info["stats"].cpu().numpy(), ostats), t
+    K = 40
+    a = torch.randint(0, 2, (K, n), generator=g, dtype=torch.int32)
+    robs, _, _, _ = env.rollout(a.cuda(), want_obs="all")
+    for t in range(K):
+        oobs, _, _, _ = orc.step(a[t].numpy(), auto_reset=True)
+        assert np.array_equal(robs[t].cpu().numpy(), oobs), t
+    env.check_errors()
+
+
+def test_sub_batched_env_forwards_the_rest_of_the_surface():
+    from control_pcgrl_amd import SubBatchedVecEnv, make_vec_env
+    n = 64
+    kw = dict(static_prob=0.3, n_static_walls=2)
+    sb = SubBatchedVecEnv("binary", "narrow", (16, 16), n, 2, seeds=np.arange(n), **kw)
+    one = _vec("binary", "narrow", (16, 16), n, seeds=np.arange(n), **kw)
+    for e in (sb, one):
+        e.set_static(static_prob=0.2, eval_mode=True)
+        e.reset()
+    assert torch.equal(sb.get_static(), one.get_static())
+    assert torch.equal(sb.get_rng_state(), one.get_rng_state())
+    sb.seed(500 + np.arange(n)); one.seed(500 + np.arange(n))
+    sb.reset(); one.reset()
+    assert torch.equal(sb.get_static(), one.get_static())
+    # a temporary handed to step_async (freed as soon as the call returns) is kept alive for the sub-stream's read
+    for t in range(20):
+        for i in range(2):
+            sb.step_async(i, torch.full((n // 2,), t % 2, dtype=torch.int64, device="cuda").int())
+        sb.wait()
+        one.step(torch.full((n,), t % 2, dtype=torch.int32, device="cuda"))
+    assert torch.equal(sb.get_state().grids, one.get_state().grids)
+    mask = torch.zeros(n, dtype=torch.uint8); mask[::3] = 1
+    sb.load_state_dict(sb.state_dict(), mask=mask)
+    assert sb.solver_pool_slots() == (0, 0, False)
+    with pytest.raises(NotImplementedError):
+        make_vec_env({"task": {"problem": "binary", "map_shape": [16, 16]}, "representation": "narrow", "controls": ["regions"]}, 8, sub_batches=2)
+    sb.check_errors(); one.check_errors()
