@@ -754,7 +754,7 @@ def main():
         bytes_per_launch = int(ALGO_BYTES[args.workload] * N) if emitted_total is None else int(ALGO_BYTES[args.workload] * emitted_total / world / K)
         achieved = bytes_per_launch / (elapsed / K) / 1e9          # same clock as `value`
         achieved_ev = bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # HIP events around the K launches
-        traffic, traffic_src = profiled_traffic(args.workload, N)
+        traffic, traffic_src, profiled_head = profiled_traffic(args.workload, N)
         k_mean_us = profiled_kernel_mean_us(args.workload, N)
         out = {
             "metric": "env-steps/sec at N envs/GPU (binary 16x16), 1/2/4/8 MI355X",
@@ -784,6 +784,9 @@ def main():
                                        (shard_env_range(total_envs, r, world) for r in range(world))]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # `traffic` and `kernel_mean_us` are echoes of committed profile files, never measurements of this run:
+                         # the commit they were profiled at and the identity of the kernels running now
+                         "profiled_at_head": profiled_head, "kernel_sources_sha16": kernel_sources_sha16(),
                          "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel (update_only)" if evo
                          else "pcgrl::stats_for_grids_kernel" if sfg else "pcgrl::step_kernel",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -1114,35 +1117,66 @@ def rllib_adapter_bench(problem, rep, shape, dev, sizes=(20, 2000, 4096), second
             "of a call are never rewritten (a pinned block of their own, recycled when they are garbage)", "rows": rows}
 
 
-def profiled_traffic(workload, n_envs):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r*_summary.json: WRITE_SIZE + 2 x FETCH_SIZE, see DESIGN.md section 5) and where the number comes from;
-    (None, None) when that workload / batch was not profiled.  Counters cannot be collected inside a timing run."""
+def kernel_sources_sha16():
+    """identity of the kernels a measurement belongs to: sha256 over the library's sources (csrc/*.h, *.hip and the C ABI header)"""
     import glob
-    best = (None, None)
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "control_pcgrl_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "control_pcgrl_amd", "csrc", "*.hip"))
+                   + [os.path.join(ROOT, "include", "pcgrl_amd.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _profile_summaries():
+    """committed rocprofv3 summaries, oldest first, each with whether it was taken on THESE kernels"""
+    import glob
+    cur = kernel_sources_sha16()
+    out = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
         try:
             s = json.load(open(f))
-            rec = s.get("hbm_traffic_per_launch_by_workload", {}).get(f"{workload}@{n_envs}")
-            if rec is None and workload == "binary-narrow" and n_envs == 4096:
-                rec = s.get("hbm_traffic_per_launch")
-            if rec is not None:
-                best = (rec["traffic_bytes"], os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)")
         except Exception:
-            pass
+            continue
+        out.append((f, s, s.get("kernel_sources_sha16") == cur))
+    return out, cur
+
+
+def profiled_traffic(workload, n_envs):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*_summary.json: WRITE_SIZE + 2 x FETCH_SIZE), where the number comes from and the
+    commit it was profiled at.  Counters cannot be collected inside a timing run, so this is an ECHO of a committed file -- and
+    only of one taken on the kernels that are running: a summary whose `kernel_sources_sha16` differs from the sources of this
+    checkout is refused (None, with the reason)."""
+    sums, cur = _profile_summaries()
+    best, stale = (None, None, None), None
+    for f, s, same in sums:
+        rec = s.get("hbm_traffic_per_launch_by_workload", {}).get(f"{workload}@{n_envs}")
+        if rec is None:
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if same:
+            best = (rec["traffic_bytes"], rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)", s.get("profiled_at_head"))
+        else:
+            stale = rel
+    if best[0] is None and stale is not None:
+        return None, f"{stale} was taken on other kernels (kernel_sources_sha16 != {cur}): not echoed", None
     return best
 
 
 def profiled_kernel_mean_us(workload, n_envs):
-    """mean begin-to-end duration of the dominant kernel in the newest committed rocprofv3 kernel trace of this workload at its
-    default batch (profiles/r*_summary.json), or None"""
-    import glob
+    """mean begin-to-end duration of the dominant kernel in the committed rocprofv3 kernel trace of this workload at its
+    default batch, taken on the kernels of this checkout (see profiled_traffic), or None"""
     best = None
     if n_envs != WORKLOADS[workload][3]:
         return None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+    for f, s, same in _profile_summaries()[0]:
+        if not same:
+            continue
         try:
-            d = json.load(open(f))["workloads"].get(workload, {}).get("dominant_kernel_launch")
+            d = s["workloads"].get(workload, {}).get("dominant_kernel_launch")
             if d:
                 best = d["duration_ns"]["mean"] / 1e3
         except Exception:

@@ -123,6 +123,7 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
       break;
     case K_ROLLOUT: {
       const bool ctrl = p.trg || p.reward64;
+      if (p.spread > 0) grid = dim3((p.n_envs + p.spread - 1) / p.spread);  // (envs per wavefront chosen by the host)
       if constexpr (LPE == 16 && sizeof(M) == 4) {
         if (fast) {
           if (ctrl)

@@ -58,6 +58,7 @@ struct pcgrl_engine {
   // kernel, 0 = always step launches, unset = by shape; PCGRL_OBS_NT_MB = observation bytes per launch (MB) from which the
   // stores are non-temporal (default 384, 0 = never)
   int rollout_form = -1;
+  int rollout_epw = -1;  // PCGRL_ROLLOUT_EPW (development): envs per wavefront of the rollout kernel, -1 = chosen by batch size
   long obs_nt_mb = 384;
   bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
@@ -570,6 +571,7 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
     const char *f = getenv("PCGRL_ROLLOUT_KERNEL");
     if (f != nullptr && (f[0] == '0' || f[0] == '1')) e->rollout_form = f[0] - '0';
     if (getenv("PCGRL_OBS_NT_MB")) e->obs_nt_mb = atol(getenv("PCGRL_OBS_NT_MB"));
+    if (getenv("PCGRL_ROLLOUT_EPW")) e->rollout_epw = atoi(getenv("PCGRL_ROLLOUT_EPW"));
   }
   e->device = device;
   e->lpe = lpe;
@@ -879,6 +881,13 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
   soko_pool_lazy(h, p, (hipStream_t)stream);
   p.actions = d_actions;
   p.n_steps = n_steps;
+  p.spread = 0;
+  if (h->p.cfg.problem != PCGRL_PROB_MC3DMAZE) {
+    const int full = 64 / h->lpe;
+    int epw = h->rollout_epw;
+    if (epw > full) epw = full;
+    p.spread = epw > 0 ? epw : 0;
+  }
   p.auto_reset = auto_reset;
   p.obs = d_obs;
   p.obs_last_only = obs_last_only;

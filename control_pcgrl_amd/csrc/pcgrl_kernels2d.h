@@ -1380,6 +1380,9 @@ __device__ inline void encode_obs_codes(const Grp<LPE> &g, const Params &p, int 
   if (k < total) store_obs16(base + (size_t)k * 16, chunk(k));
 }
 
+#ifndef PCGRL_OBS_ROT
+#define PCGRL_OBS_ROT 1  // (development: 0 = the byte scatter of rounds 1-5, every env of a wave at the same cell: A/B builds)
+#endif
 // FAST: map 16x16 with a 32x32 window (the reference's default obs_window = 2 * map_shape): every map row is
 // visible, every map cell lands inside the window, each lane writes exactly one map row and one all-OOB row,
 // and every loop bound is a compile-time constant.
@@ -1395,8 +1398,18 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     const int row_bytes = W * NT, chunks = (row_bytes + 15) >> 4;
     uint8_t *row = lds + g.lane * lds_row_stride(row_bytes);
     for (int q = 0; q < chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
-    if (active && g.row < H)
-      for (int x = 0; x < W; x++) row[x * NT + tile_at<NB, M>(b, x)] = 1;
+    if (active && g.row < H) {
+      if constexpr (FAST && PCGRL_OBS_ROT) {  // (see the cropped encoder below: the wave's envs start at different cells)
+        const int rot = 4 * (g.lane >> 4);
+#pragma unroll
+        for (int x = 0; x < 16; x++) {
+          const int xx = (x + rot) & 15;
+          row[xx * NT + tile_at<NB, M>(b, xx)] = 1;
+        }
+      } else {
+        for (int x = 0; x < W; x++) row[x * NT + tile_at<NB, M>(b, x)] = 1;
+      }
+    }
     if (row_bytes & 15) {  // rows of odd size: the group streams the env's observation as one byte string
       const int gb = g.gbase, stride = lds_row_stride(row_bytes);
       if (active)
@@ -1443,11 +1456,19 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
       *(uint4 *)(row + q * 16) = oob_chunk<C>(q % C);
       if (g.lane < 1) *(uint4 *)(oob_row + q * 16) = oob_chunk<C>(q % C);
     }
+    // Byte scatter, one cell per trip.  The LDS rows of the wave's 64 lanes lie STRIDE = 16 * odd bytes apart: the 16 lanes of
+    // an env hit 16 different banks (every fourth), but lanes l, l + 16, l + 32, l + 48 -- the same row of the wave's four envs --
+    // hit the SAME bank whenever the envs write the same cell (narrow: always; the scan position is shared): a 4-way conflict
+    // on every byte (bank-conflict rate 0.48 in rounds 1-5).  So env g of the wave starts at cell 4 g: four cells are 4 C bytes
+    // = C dwords on, and C is odd for every problem here (3, 9; wide: NT = 5), so the four envs land in the four different
+    // residues mod 4 and the 64 lanes in 64 different banks.
+    const int rot = PCGRL_OBS_ROT ? 4 * (g.lane >> 4) : 0;
 #pragma unroll
     for (int x = 0; x < FW; x++) {
-      int o = (x - left) * C;  // always inside the window when OW = 2 * W
+      const int xx = (x + rot) & (FW - 1);
+      int o = (xx - left) * C;  // always inside the window when OW = 2 * W
       row[o] = 0;
-      row[o + 1 + tile_at<NB, M>(b, x)] = 1;
+      row[o + 1 + tile_at<NB, M>(b, xx)] = 1;
     }
   } else {
     for (int q = 0; q < CH; q++) {
@@ -2205,8 +2226,12 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   if (observer && p.obs == nullptr) return;
   PHASE_DECL();  // (development builds: the shared helpers take the phase counters; nothing is flushed here)
   const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
-  const int env = blockIdx.x * EPW + (g.lane / LPE);
-  const bool active = env < p.n_envs;
+  // p.spread (1 .. 64 / LPE): envs per wavefront.  Fewer than a wave holds leaves lanes idle but gives every env's chain of
+  // searches a wave (nearly) of its own: a wave advances at the pace of the slowest of ITS envs at every step, and at the
+  // BASELINE batch sizes the machine has wave slots to spare (4096 envs / 4 = 1024 wave pairs on 1024 SIMDs)
+  const int epw = p.spread > 0 ? p.spread : EPW;
+  const int env = blockIdx.x * epw + (g.lane / LPE);
+  const bool active = env < p.n_envs && (g.lane / LPE) < epw;
   const bool rowok = active && g.row < H;
   const M colmask = rowok ? (W >= (int)(8 * sizeof(M)) ? ~M(0) : ((M(1) << W) - M(1))) : M(0);
   const int e = active ? env : 0;

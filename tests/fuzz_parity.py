@@ -41,6 +41,8 @@ def draw_case(rng):
     if rng.random() < 0.25:
         kw["max_board_scans"] = int(rng.integers(1, 4))
     case["auto_reset"] = bool(rng.random() < 0.8)
+    if kw.get("controls") and rng.random() < 0.35:  # device-side target resampling at every reset (pcgrl_set_target_resampling)
+        case["resample"] = int(rng.integers(0, 1 << 40))
     r = rng.random()
     if r < 0.1:
         case["mode"] = "adapter"
@@ -48,6 +50,11 @@ def draw_case(rng):
         case["mode"] = "gym"
     r = rng.random()
     case["seed_kind"] = "same" if r < 0.05 else ("huge" if r < 0.1 else "range")
+    # asynchronous stepping (pcgrl_step_ready): sokoban without wrappers / controls, maps whose levels fit one stage workspace
+    if (case["problem"] == "sokoban" and not any(k in kw for k in ("controls", "static_prob", "n_static_walls", "act_window"))
+            and case["shape"][0] * case["shape"][1] <= 256 and rng.random() < 0.45):
+        case["mode"] = "ready"
+        case["budget"] = int(rng.choice([1, 3, 8, 16, 64, 400, 100000]))
     return case
 
 
@@ -190,6 +197,37 @@ def run_case(case, seed, verbose=False):
         env.queue_targets({k: torch.as_tensor(v) for k, v in trg.items()})
         orc.queue_targets(trg)
 
+    # device-side target resampling: the engine draws every env's control targets at each of its resets from a counter-based
+    # stream (trg_resampled, csrc/pcgrl_kernels2d.h); the oracle is handed the same values through its queue before every call
+    # that may reset an env, and `draws` counts each env's resets
+    resample = case.get("resample") if controls and case.get("mode") not in ("adapter", "gym") else None
+    draws = np.zeros(n, np.int64)
+    M64 = (1 << 64) - 1
+
+    def _mix(z):
+        z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M64
+        z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M64
+        return z ^ (z >> 31)
+
+    def next_draws():
+        out = {}
+        for j, k in enumerate(controls):
+            lo, hi = bounds[k]
+            vals = np.empty(n)
+            for i in range(n):
+                r_ = _mix(_mix((resample + int(draws[i]) * 0x9e3779b97f4a7c15) & M64) ^ ((i * 0xd1b54a32d192ed03 + (j + 1) * 0x8cb92ba72f3d8dd7) & M64))
+                vals[i] = float(r_ >> 11) * (1.0 / 9007199254740992.0) * (hi - lo) + lo
+            out[k] = vals
+        return out
+
+    def before_resets():
+        if resample is not None:
+            orc.queue_targets(next_draws())
+
+    def after_resets(which):
+        if resample is not None:
+            draws[np.asarray(which, dtype=bool)] += 1
+
     def draw_actions(t, lead=()):
         size = tuple(lead) + ((n, env.action_entries) if env.action_entries > 1 else (n,))
         if case.get("bias"):
@@ -230,8 +268,11 @@ def run_case(case, seed, verbose=False):
     totals = np.zeros(3 + len(STAT_KEYS[problem]))
 
     def orc_step(a, want_obs):
+        before_resets()
         r = orc.step(a, auto_reset=auto, want_obs=want_obs)
         d = r[2]
+        if auto:
+            after_resets(d)
         if auto and d.any():  # what pcgrl_reduce_episodes sums: the episodes that ended by auto-reset
             le = orc.last_episode()
             totals[0] += le["ep_return"][d].sum()
@@ -242,8 +283,12 @@ def run_case(case, seed, verbose=False):
 
     if controls:
         queue()
+    if resample is not None:
+        env.set_target_resampling(True, resample)
+    before_resets()
     obs, info = env.reset()
     assert np.array_equal(obs.cpu().numpy(), orc.reset()), "reset observation"
+    after_resets(np.ones(n, bool))
     check_ctrl("after reset")
     full_every = int(rng.integers(3, 30))
     mixed = case.get("mode") == "mixed"
@@ -317,6 +362,8 @@ def run_case(case, seed, verbose=False):
             env2 = make_engine()
             if cur_static is not None:  # (host-side settings are the caller's to carry over, like the constructor's)
                 env2.set_static(static_prob=cur_static[0], n_static_walls=cur_static[1], eval_mode=cur_static[2])
+            if resample is not None:  # (engine-wide run-time parameters are the caller's to carry over, too)
+                env2.set_target_resampling(True, resample)
             env2.load_state_dict(sd)
             env.check_errors()
             env.close()
@@ -326,8 +373,10 @@ def run_case(case, seed, verbose=False):
             t += 1
         elif ev == "masked_reset":
             mask = (rng.random(n) < rng.random()).astype(np.uint8)
+            before_resets()
             obs, _ = env.reset(mask=mask)
             assert np.array_equal(obs.cpu().numpy(), orc.reset(mask=mask)), f"obs {what}"
+            after_resets(mask)
             check_ctrl(what)
             check_state(what)
             t += 1
@@ -335,8 +384,10 @@ def run_case(case, seed, verbose=False):
             mask = (rng.random(n) < rng.random()).astype(np.uint8)
             grids = random_grids(rng, problem, n, shape)
             pos = np.stack([rng.integers(0, s, size=n) for s in shape], axis=1).astype(np.int32)
+            before_resets()
             obs, _ = env.reset(mask=mask, init_grids=grids, init_pos=pos)
             assert np.array_equal(obs.cpu().numpy(), orc.reset(mask=mask, init_grids=grids, init_pos=pos)), f"obs {what}"
+            after_resets(mask)
             if not check_stats(env.get_state().stats.cpu().numpy(), orc.get_state()["stats"], None, what):
                 return -2
             check_state(what)
@@ -407,6 +458,102 @@ def run_case(case, seed, verbose=False):
             return -2
         raise
     return int(ole["n_episodes"].sum())
+
+
+def run_ready_case(case, seed):
+    """sokoban through pcgrl_set_solver_budget / pcgrl_step_ready: the device solver works to a budget per launch and parks
+    what it could not finish; busy envs ignore their actions.  The oracle steps an env exactly when the engine reports an
+    emitted transition, with the action the env consumed; resets (masked, injected playable levels) abandon steps in flight;
+    a checkpoint into a fresh engine loses the parked searches (they restart) but not the pending steps."""
+    import torch
+    import pcgrl_oracle as po  # (checker)
+    from control_pcgrl_amd import VecPcgrlEnv
+
+    problem, rep, shape, n, T = case["problem"], case["rep"], tuple(case["shape"]), case["n_envs"], case["steps"]
+    kw = {k: (tuple(v) if k == "obs_window" else v) for k, v in case["kw"].items()}
+    auto, budget = bool(case.get("auto_reset", True)), int(case["budget"])
+    seeds = seed + np.arange(n)
+
+    def make_engine():
+        e = VecPcgrlEnv(problem, rep, shape, n, seeds=seeds, auto_reset=auto, **kw)
+        e.set_solver_budget(budget)
+        return e
+
+    env = make_engine()
+    orc = po.OracleVecEnv(problem, rep, shape, n, seeds=seeds, threads=8, **kw)
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    obs, _ = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.reset()), "reset observation"
+    busy = env.env_busy().cpu().numpy().astype(bool)
+    pend, has_pend = np.zeros(n, np.int32), np.zeros(n, bool)
+    trace = case.setdefault("_trace", [])
+    emitted_total, t = 0, 0
+    while t < T:
+        ev = str(rng.choice(["step", "inject", "masked_reset", "swap"], p=[0.8, 0.1, 0.05, 0.05]))
+        what = f"@ {t} ({ev})"
+        trace.append(f"{t}:{ev}")
+        if ev == "step":
+            for _ in range(int(rng.integers(1, 12))):
+                a = torch.randint(0, env.num_actions, (n,), generator=g, dtype=torch.int32).numpy()
+                if rng.random() < 0.5:  # mostly floor / wall edits: playable levels stay playable for a while
+                    a = (a // 5) * 5 + (a % 2)
+                consume = ~busy
+                pend[consume] = a[consume]
+                has_pend[consume] = True
+                obs, rew, done, _, info = env.step_ready(torch.as_tensor(a).to(env.device))
+                status = info["status"].cpu().numpy()
+                emitted = (status & 1) != 0
+                assert not (emitted & ~has_pend).any(), f"a transition without a consumed action {what}"
+                oobs, orew, odone, ostats = orc.step_masked(emitted, pend, auto_reset=auto)
+                if emitted.any():
+                    got = info["stats"].cpu().numpy()
+                    if not np.array_equal(got[emitted], ostats[emitted]):
+                        e = int(np.nonzero(emitted & (got != ostats).any(axis=1))[0][0])
+                        raise AssertionError(f"stats {what}: env {e} got {got[e].tolist()} want {ostats[e].tolist()} (budget {budget})")
+                    assert np.abs(rew.cpu().numpy()[emitted] - orew[emitted]).max() <= 1e-6, f"reward {what}"
+                    assert np.array_equal(done.cpu().numpy()[emitted], odone[emitted]), f"done {what}"
+                    assert np.array_equal(obs.cpu().numpy()[emitted], oobs[emitted]), f"obs {what}"
+                has_pend[emitted] = False
+                busy = (status & 2) != 0
+                assert not (~busy & has_pend).any(), f"an idle env still owes a transition {what}"
+                emitted_total += int(emitted.sum())
+                t += 1
+        elif ev in ("inject", "masked_reset"):
+            mask = (rng.random(n) < rng.random()).astype(np.uint8)
+            if ev == "inject":
+                grids = random_grids(rng, problem, n, shape)
+                pos = np.stack([rng.integers(0, s_, size=n) for s_ in shape], axis=1).astype(np.int32)
+                obs, _ = env.reset(mask=mask, init_grids=grids, init_pos=pos)
+                want = orc.reset(mask=mask, init_grids=grids, init_pos=pos)
+            else:
+                obs, _ = env.reset(mask=mask)
+                want = orc.reset(mask=mask)
+            assert np.array_equal(obs.cpu().numpy(), want), f"obs {what}"
+            has_pend[mask != 0] = False  # steps in flight are abandoned with the old map
+            busy = env.env_busy().cpu().numpy().astype(bool)
+            t += 1
+        else:  # checkpoint into a fresh engine: pending steps travel, parked searches do not (they restart: same results)
+            sd = env.state_dict()
+            env2 = make_engine()
+            env2.load_state_dict(sd)
+            env.check_errors()
+            env.close()
+            env = env2
+            assert np.array_equal(env.env_busy().cpu().numpy().astype(bool), busy), f"busy flags {what}"
+            assert np.array_equal(env.observe().cpu().numpy(), orc.observe()), f"obs {what}"
+            t += 1
+        st, ost = env.get_state(), orc.get_state()
+        assert np.array_equal(st.grids.cpu().numpy().reshape(n, -1), ost["grids"]), f"grids {what}"
+        idle = ~busy
+        assert np.array_equal(st.stats.cpu().numpy()[idle], ost["stats"][idle]), f"state stats of idle envs {what}"
+        assert np.array_equal(st.iteration.cpu().numpy(), ost["iteration"]), f"iteration {what}"
+    le, ole = env.last_episode(), orc.last_episode()
+    assert np.array_equal(le.n_episodes.cpu().numpy(), ole["n_episodes"]), "episode counts"
+    assert np.array_equal(le.final_stats.cpu().numpy(), ole["final_stats"]), "final stats"
+    env.check_errors()
+    env.close()
+    return emitted_total
 
 
 def _final_check(vec, problem):
@@ -582,7 +729,7 @@ def sweep(n_cases, seed, verbose=True, stop_on_fail=True, budget_s=None, only=No
         line = json.dumps(dict(case, seed=cs))
         t1 = time.time()
         try:
-            eps = {"adapter": run_adapter_case, "gym": run_gym_case}.get(case.get("mode"), run_case)(case, cs)
+            eps = {"adapter": run_adapter_case, "gym": run_gym_case, "ready": run_ready_case}.get(case.get("mode"), run_case)(case, cs)
             case.pop("_trace", None)
             if verbose:
                 print(f"ok   {i:4d} {time.time() - t1:6.1f}s eps={eps:5d} {line}", flush=True)
@@ -628,7 +775,7 @@ if __name__ == "__main__":
         c = json.loads(a.case)
         s = c.pop("seed")
         try:
-            print("episodes:", {"adapter": run_adapter_case, "gym": run_gym_case}.get(c.get("mode"), run_case)(c, s))
+            print("episodes:", {"adapter": run_adapter_case, "gym": run_gym_case, "ready": run_ready_case}.get(c.get("mode"), run_case)(c, s))
         finally:
             print("events:", " ".join(c.get("_trace", [])))
         sys.exit(0)

@@ -27,6 +27,15 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_bench_lines.json"), "w") as fh:
 for f in glob.glob(os.path.join(G, "summary", f"{tag}_*")):
     shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
 summ = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_summary.json")))
+# the commit the passes belong to: HEAD, if the kernels of this checkout are the ones that were profiled
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import subprocess  # noqa: E402
+if summ.get("kernel_sources_sha16") == bench.kernel_sources_sha16() and not summ.get("profiled_at_head"):
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "control_pcgrl_amd/csrc", "include"], capture_output=True, text=True).stdout.strip()
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    summ["profiled_at_head"] = head + (" + uncommitted kernel changes" if dirty else "")
+    json.dump(summ, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
 
 
 def fmt(x, d=2):

@@ -11,6 +11,8 @@ for p in parts:
     if out is None:
         out = dict(d, tag=tag, batches=parts)
     else:
+        if d.get("kernel_sources_sha16") != out.get("kernel_sources_sha16"):
+            sys.exit(f"{p}: profiled on other kernels ({d.get('kernel_sources_sha16')} vs {out.get('kernel_sources_sha16')}): not merged")
         out["workloads"].update(d["workloads"])
         out["hbm_traffic_per_launch_by_workload"].update(d["hbm_traffic_per_launch_by_workload"])
     f = os.path.join(S, f"{p}_kernel_stats.csv")

@@ -157,7 +157,10 @@ def summarize(ent, stats_rows, resources):
 def main(tag, outdir=None):
     outdir = outdir or os.path.join(ROOT, "profiles")
     os.makedirs(outdir, exist_ok=True)
+    # kernel_sources_sha16: the kernels these passes ran on (bench.py echoes `traffic` / `kernel_mean_us` only from a summary
+    # whose hash equals the checkout's); profiled_at_head: filled in by tools/finish_round.py, where the git history is
     out = {"tag": tag, "source": "rocprofv3 on python3 bench.py --workload W (BASELINE.json batch sizes, 1 MI355X); tools/profile_all.sh",
+           "kernel_sources_sha16": bench.kernel_sources_sha16(), "profiled_at_head": None,
            "workloads": {}, "hbm_traffic_per_launch_by_workload": {}}
     stats_rows = []
     resources = compiler_resources()
