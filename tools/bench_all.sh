@@ -10,12 +10,23 @@ if [ "$WHAT" = "base" ] || [ "$WHAT" = "all" ]; then
   for W in zelda-turtle sokoban-wide minecraft_3D_maze-narrow zelda-turtle-bfs binary-narrow-static binary-narrow-patch3x3; do
     python bench.py --workload $W > $O/bench_${T}_$W.log 2>&1
   done
-  python bench.py --workload sokoban-wide-solver --steps 40 --warmup 8 > $O/bench_${T}_sokoban-wide-solver.log 2>&1
+  # solver-active sokoban: synchronous pcgrl_step (+ the rollout / sub-batch forms of the same workload), then asynchronous
+  # stepping (pcgrl_step_ready) over a sweep of solver budgets; the budget-16 line carries the CPU baseline
+  python bench.py --workload sokoban-wide-solver --steps 40 --warmup 8 --solver-forms 48 > $O/bench_${T}_sokoban-wide-solver.log 2>&1
+  for B in 4 8 32 64 256; do
+    python bench.py --workload sokoban-wide-solver --solver-budget $B --steps 3000 --warmup 300 --no-cpu-baseline > $O/bench_${T}_sokoban-wide-solver-async$B.log 2>&1
+  done
+  python bench.py --workload sokoban-wide-solver --solver-budget 16 --steps 3000 --warmup 300 > $O/bench_${T}_sokoban-wide-solver-async16.log 2>&1
   python bench.py --envs 65536 --no-cpu-baseline > $O/bench_${T}_binary-narrow-65536.log 2>&1
   python bench.py --graph-steps 0 --no-cpu-baseline > $O/bench_${T}_binary-narrow-eager.log 2>&1
   python bench.py --steps 20 --warmup 5 > $O/bench_${T}_driver_20_5.log 2>&1
   # the driver's command line through the N > 1 exchange (a world-size-1 RCCL group), and the older short-run protocols
   python bench.py --steps 20 --warmup 5 --force-collective --no-cpu-baseline --rllib-adapter 0 > $O/bench_${T}_driver_20_5_nccl1.log 2>&1
+  python bench.py --steps 20 --warmup 5 --force-collective --exchange serial --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_nccl1_serial.log 2>&1
+  for i in 2 3; do  # (single 160 us regions move by a few us from run to run: two more of each)
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rllib-adapter 0 --sub-batches "" --closed-loop-steps 0 > $O/bench_${T}_driver_20_5_run$i.log 2>&1
+    python bench.py --steps 20 --warmup 5 --force-collective --no-cpu-baseline --rllib-adapter 0 --sub-batches "" --closed-loop-steps 0 > $O/bench_${T}_driver_20_5_nccl1_run$i.log 2>&1
+  done
   python bench.py --steps 20 --warmup 5 --short-protocol gcd --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_gcd.log 2>&1
   python bench.py --steps 20 --warmup 5 --short-protocol one --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_one.log 2>&1
   python bench.py --steps 20 --warmup 5 --graph-steps 0 --no-cpu-baseline --rllib-adapter 0 --sub-batches "" > $O/bench_${T}_driver_20_5_eager.log 2>&1

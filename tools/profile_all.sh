@@ -10,7 +10,8 @@ ENTRIES=${2:-"binary-narrow zelda-turtle sokoban-wide minecraft_3D_maze-narrow"}
 R=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --rllib-adapter 0 --closed-loop-steps 0 --sub-batches="
+# PROFILE_EXTRA: more bench.py arguments for every entry of the call (e.g. "--solver-budget 16" for sokoban-wide-solver)
+COMMON="--no-cpu-baseline --rllib-adapter 0 --closed-loop-steps 0 --sub-batches= $PROFILE_EXTRA"
 for ENT in $ENTRIES; do
   RO=0; case "$ENT" in *+rollout) RO=1;; esac
   WE=${ENT%+rollout}
