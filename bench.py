@@ -786,7 +786,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # `traffic` and `kernel_mean_us` are echoes of committed profile files, never measurements of this run:
                          # the commit they were profiled at and the identity of the kernels running now
-                         "profiled_at_head": profiled_head, "kernel_sources_sha16": kernel_sources_sha16(),
+                         "profiled_at_head": profiled_head, "kernel_sources_sha16": kernel_sources_sha16(_family(args.workload)),
                          "kernel": "pcgrl::m3_kernel" if problem == "minecraft_3D_maze" else "pcgrl::step_kernel (update_only)" if evo
                          else "pcgrl::stats_for_grids_kernel" if sfg else "pcgrl::step_kernel",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -1117,30 +1117,42 @@ def rllib_adapter_bench(problem, rep, shape, dev, sizes=(20, 2000, 4096), second
             "of a call are never rewritten (a pinned block of their own, recycled when they are garbage)", "rows": rows}
 
 
-def kernel_sources_sha16():
-    """identity of the kernels a measurement belongs to: sha256 over the library's sources (csrc/*.h, *.hip and the C ABI header)"""
+def kernel_sources_sha16(family=None):
+    """identity of the kernels a measurement belongs to: sha256 over the sources they are built from.  family "2d": the 2-D
+    problems' kernels (everything but the 3-D translation unit and header); "3d": everything (the 3-D kernels include the 2-D
+    header); None: {"2d": ..., "3d": ...}"""
     import glob
     import hashlib
+    if family is None:
+        return {"2d": kernel_sources_sha16("2d"), "3d": kernel_sources_sha16("3d")}
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "control_pcgrl_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "control_pcgrl_amd", "csrc", "*.hip"))
                    + [os.path.join(ROOT, "include", "pcgrl_amd.h")])
     for f in files:
+        if family == "2d" and os.path.basename(f) in ("pcgrl_kernels3d.h", "pcgrl_k_3d.hip"):
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
-def _profile_summaries():
-    """committed rocprofv3 summaries, oldest first, each with whether it was taken on THESE kernels"""
+def _family(workload):
+    return "3d" if "3D" in workload else "2d"
+
+
+def _profile_summaries(workload):
+    """committed rocprofv3 summaries, oldest first, each with whether it was taken on THESE kernels (of the workload's family)"""
     import glob
-    cur = kernel_sources_sha16()
+    fam = _family(workload)
+    cur = kernel_sources_sha16(fam)
     out = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
         try:
             s = json.load(open(f))
         except Exception:
             continue
-        out.append((f, s, s.get("kernel_sources_sha16") == cur))
+        h = s.get("kernel_sources_sha16")
+        out.append((f, s, isinstance(h, dict) and h.get(fam) == cur))
     return out, cur
 
 
@@ -1150,7 +1162,7 @@ def profiled_traffic(workload, n_envs):
     commit it was profiled at.  Counters cannot be collected inside a timing run, so this is an ECHO of a committed file -- and
     only of one taken on the kernels that are running: a summary whose `kernel_sources_sha16` differs from the sources of this
     checkout is refused (None, with the reason)."""
-    sums, cur = _profile_summaries()
+    sums, cur = _profile_summaries(workload)
     best, stale = (None, None, None), None
     for f, s, same in sums:
         rec = s.get("hbm_traffic_per_launch_by_workload", {}).get(f"{workload}@{n_envs}")
@@ -1172,7 +1184,7 @@ def profiled_kernel_mean_us(workload, n_envs):
     best = None
     if n_envs != WORKLOADS[workload][3]:
         return None
-    for f, s, same in _profile_summaries()[0]:
+    for f, s, same in _profile_summaries(workload)[0]:
         if not same:
             continue
         try:

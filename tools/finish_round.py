@@ -31,7 +31,7 @@ summ = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_summary.json")))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import subprocess  # noqa: E402
-if summ.get("kernel_sources_sha16") == bench.kernel_sources_sha16() and not summ.get("profiled_at_head"):
+if summ.get("kernel_sources_sha16") == bench.kernel_sources_sha16() and not summ.get("profiled_at_head"):  # (both families)
     dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "control_pcgrl_amd/csrc", "include"], capture_output=True, text=True).stdout.strip()
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     summ["profiled_at_head"] = head + (" + uncommitted kernel changes" if dirty else "")
@@ -125,6 +125,25 @@ if sa:
                      f"{100 * sa['solver_active']['envs_with_solver_result_at_end']:.0f} % of the envs with a solver result at the end, "
                      f"{100 * sa['solver_active']['envs_solved_at_end']:.0f} % solved); CPU oracle: {sci(cb.get('value', 0))} on {cb.get('cores', '?')} threads.")
 
+# asynchronous stepping on the solver-active workload: one row per solver budget
+async_rows = ["| solver budget (units per env and launch) | µs per launch | emitted env-steps/s | env-launches that emitted | env-launches busy | vs synchronous `pcgrl_step` | vs the CPU oracle |", "|---|---|---|---|---|---|---|"]
+cpu_sa = ((lines.get("sokoban-wide-solver-async16") or {}).get("cpu_baseline") or (sa or {}).get("cpu_baseline") or {}).get("value")
+for B in (4, 8, 16, 32, 64, 256):
+    l = lines.get(f"sokoban-wide-solver-async{B}")
+    if not l or "asynchronous_stepping" not in l:
+        continue
+    a_ = l["asynchronous_stepping"]
+    async_rows.append(f"| {B} | {a_['us_per_launch']:.1f} | {sci(l['value'])} | {a_['emitted_share_of_env_launches']:.3f} | {a_['busy_share_of_env_launches']:.3f} | "
+                      + (f"{l['value'] / sa['value']:.0f} ×" if sa else "–") + " | " + (f"{l['value'] / cpu_sa:.1f} ×" if cpu_sa else "–") + " |")
+async_table = "\n".join(async_rows)
+forms = (sa or {}).get("solver_active_forms") or {}
+if forms.get("pcgrl_rollout"):
+    solver_active += (f"  The same workload through the forms that shrink a launch's synchronisation domain without a ready mask: `pcgrl_rollout` "
+                      f"({forms['pcgrl_rollout']['steps_per_launch']} steps per launch between re-injections) {sci(forms['pcgrl_rollout']['value'])} env-steps/s "
+                      f"({forms['pcgrl_rollout']['us_per_step'] / 1e3:.0f} ms per step), `sub_batches = 4` {sci(forms['sub_batches_4']['value'])} "
+                      f"({forms['sub_batches_4']['us_per_step'] / 1e3:.0f} ms per step): both SLOWER than plain stepping — a rollout wave pays the sum of its env's "
+                      f"searches over the steps, and four engines split the solver's workspace pool and the helper waves' LDS.")
+
 # saturation sweeps: the BASELINE batch x1 / x4 / x16
 sweep_rows = ["| workload | envs/GPU | env-steps/s | µs per step launch | roofline frac | same-size fill µs (step ÷ fill) | kernel mean / median µs (rocprofv3) |", "|---|---|---|---|---|---|---|"]
 for w, sizes in (("binary-narrow", ("", "-16384", "-65536", "-262144")), ("zelda-turtle", ("", "-16384", "-65536")), ("sokoban-wide", ("", "-8192", "-32768")),
@@ -170,7 +189,10 @@ adapter_table = "\n".join(ad_rows)
 # the driver's --steps 20 --warmup 5 under the short-run protocols, and through the collective path
 drv_rows = ["| protocol | µs per step (wall = `value`'s clock) | timed region µs | K launches by HIP events µs | closing exchange µs | env-steps/s |", "|---|---|---|---|---|---|"]
 for key, what in (("driver_20_5", "fused (default): one graph = 20 step launches + the reduction launch"),
-                  ("driver_20_5_nccl1", "the same through the N > 1 exchange: world-size-1 RCCL all-gather + device→host copy (`--force-collective`)"),
+                  ("driver_20_5_run2", "the same, second run"), ("driver_20_5_run3", "the same, third run"),
+                  ("driver_20_5_nccl1", "N > 1 region with one rank (`--force-collective`): the same graph; the previous interval's RCCL all-gather + device→host copy on a side stream (round 6)"),
+                  ("driver_20_5_nccl1_run2", "the same, second run"), ("driver_20_5_nccl1_run3", "the same, third run"),
+                  ("driver_20_5_nccl1_serial", "round 5's N > 1 region (`--exchange serial`): reduction → all-gather → copy behind the launches"),
                   ("driver_20_5_one", "round 4: one graph of 20 steps, reduction launched separately"),
                   ("driver_20_5_gcd", "graph of gcd(5, 20) = 5 steps: 1 untimed + 4 timed replays"),
                   ("driver_20_5_eager", "20 eager launches (`pcgrl_step_seq`)")):
@@ -199,7 +221,7 @@ cl = (lines.get("binary-narrow") or {}).get("closed_loop_device_actions") or {}
 closed_loop = (f"{cl['us_per_step']:.2f} µs per step = {sci(cl['value'])} env-steps/s, {cl['roofline_frac']:.3f} of the roofline "
                f"({cl['us_per_step'] - b['ms_per_step'] * 1e3:.2f} µs more than the pool figure: the sampler kernel and one more kernel boundary per step)") if cl.get("us_per_step") else "n/a"
 
-blocks = {"DRIVER_TABLE": driver_table, "SUBBATCH_TABLE": subbatch_table, "CLOSED_LOOP": closed_loop, "HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active,
+blocks = {"ASYNC_TABLE": async_table, "DRIVER_TABLE": driver_table, "SUBBATCH_TABLE": subbatch_table, "CLOSED_LOOP": closed_loop, "HEADLINE_TABLE": headline, "DRIVER20": driver20, "WORKLOAD_TABLE": workload_table, "SOLVER_ACTIVE": solver_active,
           "SWEEP_TABLE": sweep_table, "EVO_TABLE": evo_table, "ADAPTER_TABLE": adapter_table}
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
