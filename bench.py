@@ -873,19 +873,20 @@ def main():
     if rank == 0:
         # The CPU baseline runs on rank 0 AFTER the process group is gone: the other ranks have left (none of them sits in a
         # barrier, spinning, while the OpenMP threads are timed) and rank 0 may use every host core again.
-        if args.rllib_adapter > 0 or (args.rllib_adapter < 0 and args.workload == "binary-narrow" and args.envs == 0):
+        # (secondary figures and the CPU baseline belong to the N = 1 line: "on rank 0 at N = 1 only")
+        if world == 1 and (args.rllib_adapter > 0 or (args.rllib_adapter < 0 and args.workload == "binary-narrow" and args.envs == 0)):
             try:  # (a secondary figure must never cost the run its line)
                 out["rllib_adapter"] = rllib_adapter_bench(problem, rep, shape, dev)
             except Exception as exc:  # noqa: BLE001
                 out["rllib_adapter"] = {"error": repr(exc)}
-        if args.sub_batches and inject is None and not evo and not sfg and not wkw:
+        if world == 1 and args.sub_batches and inject is None and not evo and not sfg and not wkw:
             try:
                 out["async_sub_batches"] = sub_batch_bench(args.workload, problem, rep, shape, N, dev,
                                                            [int(x) for x in args.sub_batches.split(",") if int(x) > 1 and N % int(x) == 0],
                                                            one_batch_us=(out["roofline"]["avg_launch_us"] if K >= 250 else None))
             except Exception as exc:  # noqa: BLE001
                 out["async_sub_batches"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             if pinned is not None:
                 try:
                     os.sched_setaffinity(0, all_cores)

@@ -84,7 +84,7 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
       return hipGetLastError();
     }
     if (p.sk_budget > 0 && id == K_RESET) {
-      hipLaunchKernelGGL((reset_kernel<PROB, LPE, M, true>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((reset_kernel<PROB, LPE, M, true>), dim3(p.n_envs), block, 0, s, p);
       return hipGetLastError();
     }
   }

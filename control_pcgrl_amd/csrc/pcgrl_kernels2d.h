@@ -1386,7 +1386,7 @@ __device__ inline void encode_obs_codes(const Grp<LPE> &g, const Params &p, int 
 // FAST: map 16x16 with a 32x32 window (the reference's default obs_window = 2 * map_shape): every map row is
 // visible, every map cell lands inside the window, each lane writes exactly one map row and one all-OOB row,
 // and every loop bound is a compile-time constant.
-template <int PROB, int LPE, bool FAST, typename M>
+template <int PROB, int LPE, bool FAST, typename M, bool ROT = true>
 __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
                                   uint8_t *lds, uint8_t *obs_base = nullptr) {
   constexpr int NT = ProbTraits<PROB>::NT, NB = ProbTraits<PROB>::NB;
@@ -1399,7 +1399,7 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     uint8_t *row = lds + g.lane * lds_row_stride(row_bytes);
     for (int q = 0; q < chunks; q++) *(uint4 *)(row + q * 16) = make_uint4(0, 0, 0, 0);
     if (active && g.row < H) {
-      if constexpr (FAST && PCGRL_OBS_ROT) {  // (see the cropped encoder below: the wave's envs start at different cells)
+      if constexpr (FAST && ROT && PCGRL_OBS_ROT && PROB == PCGRL_PROB_BINARY) {  // (see the cropped encoder below; no problem with a wide FAST kernel qualifies today)
         const int rot = 4 * (g.lane >> 4);
 #pragma unroll
         for (int x = 0; x < 16; x++) {
@@ -1462,7 +1462,11 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
     // on every byte (bank-conflict rate 0.48 in rounds 1-5).  So env g of the wave starts at cell 4 g: four cells are 4 C bytes
     // = C dwords on, and C is odd for every problem here (3, 9; wide: NT = 5), so the four envs land in the four different
     // residues mod 4 and the 64 lanes in 64 different banks.
-    const int rot = PCGRL_OBS_ROT ? 4 * (g.lane >> 4) : 0;
+    // (ROT = false: the rollout kernel -- there the sixteen lane-dependent offsets become loop invariants of the step loop and
+    // cost it its second wave per SIMD: 226 -> 257 VGPRs, 3.19 -> 5.76 us per step, measured)
+    // (binary only: zelda's envs rarely share a position -- turtle -- and its 80-VGPR kernel paid 16 B of scratch for nothing:
+    // conflict rate 0.328 either way; sokoban-wide 0.684 -> 0.659, no time)
+    const int rot = (ROT && PCGRL_OBS_ROT && PROB == PCGRL_PROB_BINARY) ? 4 * (g.lane >> 4) : 0;
 #pragma unroll
     for (int x = 0; x < FW; x++) {
       const int xx = (x + rot) & (FW - 1);
@@ -1531,16 +1535,16 @@ __device__ inline void encode_obs(const Grp<LPE> &g, const Params &p, int env, b
 
 // The general kernels on a 16x16 map with a 32x32 window (after pcgrl_update, or with an action patch) still take the
 // compile-time encoder: same LDS rows, constant loop bounds (observe wave 4.7 -> 3.6 us at 4096 envs).
-template <int PROB, int LPE, bool FAST, typename M>
+template <int PROB, int LPE, bool FAST, typename M, bool ROT = true>
 __device__ inline void encode_obs_any(const Grp<LPE> &g, const Params &p, int env, bool active, const M *b, const int *pos,
                                       uint8_t *lds, uint8_t *obs_base = nullptr) {
   if constexpr (!FAST && LPE == 16 && sizeof(M) == 4) {
     if (p.obs16 & 1) {
-      encode_obs<PROB, LPE, true, M>(g, p, env, active, b, pos, lds, obs_base);
+      encode_obs<PROB, LPE, true, M, ROT>(g, p, env, active, b, pos, lds, obs_base);
       return;
     }
   }
-  encode_obs<PROB, LPE, FAST, M>(g, p, env, active, b, pos, lds, obs_base);
+  encode_obs<PROB, LPE, FAST, M, ROT>(g, p, env, active, b, pos, lds, obs_base);
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -2299,7 +2303,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
         if (ext && p.cfg.static_tiles)
           encode_obs_static<PROB, LPE, M>(g, p, e, active, b, pos, X.prot, lds, obs_k);
         else
-          encode_obs_any<PROB, LPE, FAST, M>(g, p, e, active, b, pos, lds, obs_k);
+          encode_obs_any<PROB, LPE, FAST, M, false>(g, p, e, active, b, pos, lds, obs_k);
       }
     } else {
       const bool restat = change && map_changed;
@@ -2401,8 +2405,10 @@ __global__ __launch_bounds__(64) void reset_kernel(Params p) {
   Grp<LPE> g;
   g.init();
   const int H = p.cfg.dims[0], W = p.cfg.dims[1];
-  const int env = blockIdx.x * EPW + (g.lane / LPE);
-  const bool inb = env < p.n_envs;
+  // (SKA: one env per wavefront -- a wave serves the searches of its envs one after the other, each to the full budget, so with
+  // 64 / LPE envs per wave a reset launch of playable levels takes 64 / LPE budgets)
+  const int env = SKA ? (int)blockIdx.x : blockIdx.x * EPW + (g.lane / LPE);
+  const bool inb = env < p.n_envs && (!SKA || g.lane < LPE);
   const int e = inb ? env : 0;
   const bool active = inb && (p.mask == nullptr || p.mask[e] != 0);
   const bool rowok = active && g.row < H;

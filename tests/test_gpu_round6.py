@@ -354,3 +354,44 @@ def test_sub_batched_env_forwards_the_rest_of_the_surface():
     with pytest.raises(NotImplementedError):
         make_vec_env({"task": {"problem": "binary", "map_shape": [16, 16]}, "representation": "narrow", "controls": ["regions"]}, 8, sub_batches=2)
     sb.check_errors(); one.check_errors()
+
+
+def test_step_ready_captured_in_a_hip_graph_equals_eager_launches():
+    """pcgrl_step_ready takes no host-side decision per launch: a captured chain of T launches (each with its own status row)
+    replays to exactly what T eager launches of a twin engine produce -- statuses, stats, rewards"""
+    bench = _bench_module()
+    n, T = 128, 48
+    maps, cells = bench.solver_active_maps(n, 11)
+    acts = torch.as_tensor(bench.solver_active_actions(cells, T, 12)).cuda()
+    out = []
+    for captured in (True, False):
+        env = _vec("sokoban", "wide", (16, 16), n, seeds=np.arange(n), auto_reset=False, solver_power=300)
+        env.set_solver_budget(20)
+        env.reset(init_grids=torch.as_tensor(maps))
+        status = torch.zeros((T, n), dtype=torch.uint8, device="cuda")
+        stats = torch.zeros((T, n, env.n_stats), dtype=torch.int32, device="cuda")
+        rew = torch.zeros((T, n), dtype=torch.float32, device="cuda")
+
+        def launches(stream):
+            for t in range(T):
+                rc = env._L.pcgrl_step_ready(env._h, acts[t].data_ptr(), 0, None, rew[t].data_ptr(), None, stats[t].data_ptr(),
+                                             status[t].data_ptr(), stream)
+                assert rc == 0
+        if captured:
+            graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    launches(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay()
+        else:
+            launches(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        env.check_errors()
+        emitted = (status & 1).bool()
+        out.append((status.cpu(), torch.where(emitted[..., None], stats, torch.zeros_like(stats)).cpu(),
+                    torch.where(emitted, rew, torch.zeros_like(rew)).cpu(), env.get_state().grids.cpu()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert int((out[0][0] & 2).sum()) > 0 and int((out[0][0] & 1).sum()) > 0

@@ -71,7 +71,24 @@ def summarize(ent, stats_rows, resources):
     is_dom = (lambda name: dom in name and ((("m3_kernel<5" in name or "M3Mode)5" in name) if rollout else is_m3_step(name)) or dom != "m3_kernel"))
     cls = None
     out["entry"] = {"workload": w0, "envs": n_envs, "kernel_profiled": "open-loop rollout (pcgrl_rollout, 64 steps per launch)" if rollout else "step"}
-    ks = first(f"prof_{w}_kt/**/*kernel_stats.csv")
+    # three kernel traces per step entry (tools/profile_all.sh): the one whose dominant-kernel mean is the median is reported
+    kt_dirs, run_means = [f"prof_{w}_kt"], {}
+    for extra in (f"prof_{w}_ktrep2", f"prof_{w}_ktrep3"):
+        if glob.glob(os.path.join(G, extra)):
+            kt_dirs.append(extra)
+    for d_ in kt_dirs:
+        f_ = first(f"{d_}/**/*kernel_trace.csv")
+        if f_:
+            durs_ = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f_)) if is_dom(r["Kernel_Name"])]
+            if durs_:
+                run_means[d_] = statistics.mean(durs_)
+    kt_dir = f"prof_{w}_kt"
+    if len(run_means) >= 3:
+        kt_dir = sorted(run_means, key=run_means.get)[len(run_means) // 2]
+    out["kernel_trace_runs"] = {"dominant_kernel_mean_ns_per_run": [run_means[k] for k in sorted(run_means)], "reported_run": kt_dir,
+                                "note": "rocprofv3's per-dispatch overhead differs from run to run (two modes, ~0.4 us apart on a 6 us kernel): "
+                                        "all runs' means are listed, durations / stats below are those of the median run"}
+    ks = first(f"{kt_dir}/**/*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
         keep = [r for r in rows if "pcgrl" in r["Name"]]
@@ -80,7 +97,7 @@ def summarize(ent, stats_rows, resources):
         out["kernel_stats"] = [{"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                 "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                 "pct": float(r["Percentage"])} for r in keep]
-    kt = first(f"prof_{w}_kt/**/*kernel_trace.csv")
+    kt = first(f"{kt_dir}/**/*kernel_trace.csv")
     if kt:
         rows = [r for r in csv.DictReader(open(kt)) if is_dom(r["Kernel_Name"])]
         # one launch class: sokoban launches a workgroup per env ("spread") while its solver is busy, a different kernel
