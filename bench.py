@@ -223,6 +223,8 @@ def main():
     # stops the other ranks and the run fails visibly instead of sitting in a collective for ever.
     import threading
     rank_timeout = float(os.environ.get("PCGRL_BENCH_RANK_TIMEOUT", "1500"))
+    if os.environ.get("PCGRL_BENCH_TEST_HANG_RANK") == str(rank) and os.environ.get("PCGRL_BENCH_TEST_HANG_TIMEOUT"):
+        rank_timeout = float(os.environ["PCGRL_BENCH_TEST_HANG_TIMEOUT"])  # (test hook: only the rank that hangs is in a hurry)
 
     def _rank_timed_out():
         sys.stderr.write(f"bench.py: rank {rank} did not finish within {rank_timeout:.0f} s (PCGRL_BENCH_RANK_TIMEOUT): exit code 3\n")

@@ -1328,6 +1328,9 @@ int pcgrl_set_solver_budget(pcgrl_handle h, int32_t budget) {
   if (h->p.ext || h->p.cfg.n_ctrl > 0)
     return fail(PCGRL_EUNSUPPORTED, "pcgrl_set_solver_budget: asynchronous stepping is built for sokoban without static tiles, action "
                                     "patches or control metrics");
+  if (budget > 0 && h->maybe_stale)
+    return fail(PCGRL_EINVAL, "pcgrl_set_solver_budget: statistics left stale by pcgrl_update may exist (the asynchronous kernels carry no "
+                              "code for them): call pcgrl_refresh_stats or reset the envs first");
   ON_DEVICE(h->device);
   if (budget > 0 && h->sk_ws == nullptr) {  // one stage workspace + one park record per env, once
     HIPCHK(hipDeviceSynchronize());

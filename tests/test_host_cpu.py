@@ -64,7 +64,20 @@ def test_round5_entry_points_check_their_arguments_without_gpu():
     assert L.pcgrl_solver_pool_slots(None, None, None) == 0
     assert L.pcgrl_copy_to_host(None, None, 16, None) == 1
     assert L.pcgrl_graph_upload(None, None) == 1
-    assert b"0.3" in L.pcgrl_version()
+    import control_pcgrl_amd
+    assert control_pcgrl_amd.__version__.encode() in L.pcgrl_version()  # one version number, two places
+
+
+def test_round6_entry_points_check_their_arguments_without_gpu():
+    """asynchronous stepping / target resampling / rollout form: null handles and pointers are errors, not crashes"""
+    from control_pcgrl_amd import _lib
+    L = _lib.lib()
+    assert L.pcgrl_set_solver_budget(None, 16) == 1 and b"pcgrl_set_solver_budget" in L.pcgrl_last_error()
+    assert L.pcgrl_get_solver_budget(None) == -1
+    assert L.pcgrl_step_ready(None, None, 1, None, None, None, None, None, None) == 1
+    assert L.pcgrl_env_busy(None, None, None) == 1
+    assert L.pcgrl_set_target_resampling(None, 1, 0, None, None) == 1
+    assert L.pcgrl_set_rollout_form(None, 0) == 1
 
 
 def test_sub_batched_env_validates_the_split():
@@ -192,12 +205,12 @@ def test_bench_rank_that_hangs_exits_nonzero():
     """a rank that never reaches the rendezvous ends itself with exit code 3 after PCGRL_BENCH_RANK_TIMEOUT (never a re-exec,
     never an in-process fallback), the launcher stops the other rank and the run fails -- instead of hanging in a collective"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(PCGRL_BENCH_TEST_HANG_RANK="1", PCGRL_BENCH_RANK_TIMEOUT="6")
+    env.update(PCGRL_BENCH_TEST_HANG_RANK="1", PCGRL_BENCH_TEST_HANG_TIMEOUT="4", PCGRL_BENCH_RANK_TIMEOUT="120")
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--envs", "100"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0, r.stdout + r.stderr
-    assert "did not finish within" in r.stderr and "rank 1 exited with code 3" in r.stderr, r.stderr
+    assert "rank 1 did not finish within" in r.stderr and "rank 1 exited with code 3" in r.stderr, r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no line from a failed run"
     assert time.time() - t0 < 120
 
