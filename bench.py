@@ -1121,8 +1121,9 @@ def rllib_adapter_bench(problem, rep, shape, dev, sizes=(20, 2000, 4096), second
 
 
 def kernel_sources_sha16(family=None):
-    """identity of the kernels a measurement belongs to: sha256 over the sources they are built from.  family "2d": the 2-D
-    problems' kernels (everything but the 3-D translation unit and header); "3d": everything (the 3-D kernels include the 2-D
+    """identity of the kernels a measurement belongs to: sha256 over the sources they are built from (kernel headers, the
+    per-problem translation units, the C ABI header with the config struct; not the host side, pcgrl_engine.hip).  family "2d":
+    the 2-D problems' kernels (without the 3-D translation unit and header); "3d": everything (the 3-D kernels include the 2-D
     header); None: {"2d": ..., "3d": ...}"""
     import glob
     import hashlib
@@ -1133,6 +1134,8 @@ def kernel_sources_sha16(family=None):
                    + [os.path.join(ROOT, "include", "pcgrl_amd.h")])
     for f in files:
         if family == "2d" and os.path.basename(f) in ("pcgrl_kernels3d.h", "pcgrl_k_3d.hip"):
+            continue
+        if os.path.basename(f) == "pcgrl_engine.hip":  # (host side: argument checks, allocation, launches -- not the profiled kernels)
             continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

@@ -38,7 +38,7 @@ for ENT in $ENTRIES; do
   D=$R/gpurun_out/prof_${ENT}
   rocprofv3 --kernel-trace --stats --output-format csv -d ${D}_kt -- python3 $R/bench.py $KT > ${D}_kt.log 2>&1
   # (the profiler's per-dispatch overhead has two modes from run to run -- six traces of the same binary: means 6.00 / 6.05 / 6.05 /
-  # 6.09 / 6.38 / 6.54 us --, so the trace is taken three times; the summary keeps all three means and reports the median run)
+  # 6.09 / 6.38 / 6.54 us --, so the trace is taken three times; the summary keeps all three means and reports the least disturbed run)
   if [ $RO = 0 ]; then
     for REP in 2 3; do
       rocprofv3 --kernel-trace --stats --output-format csv -d ${D}_ktrep$REP -- python3 $R/bench.py $KT > ${D}_ktrep$REP.log 2>&1

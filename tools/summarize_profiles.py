@@ -71,7 +71,7 @@ def summarize(ent, stats_rows, resources):
     is_dom = (lambda name: dom in name and ((("m3_kernel<5" in name or "M3Mode)5" in name) if rollout else is_m3_step(name)) or dom != "m3_kernel"))
     cls = None
     out["entry"] = {"workload": w0, "envs": n_envs, "kernel_profiled": "open-loop rollout (pcgrl_rollout, 64 steps per launch)" if rollout else "step"}
-    # three kernel traces per step entry (tools/profile_all.sh): the one whose dominant-kernel mean is the median is reported
+    # three kernel traces per step entry (tools/profile_all.sh): the least disturbed one is reported, all three means are kept
     kt_dirs, run_means = [f"prof_{w}_kt"], {}
     for extra in (f"prof_{w}_ktrep2", f"prof_{w}_ktrep3"):
         if glob.glob(os.path.join(G, extra)):
@@ -83,11 +83,12 @@ def summarize(ent, stats_rows, resources):
             if durs_:
                 run_means[d_] = statistics.mean(durs_)
     kt_dir = f"prof_{w}_kt"
-    if len(run_means) >= 3:
-        kt_dir = sorted(run_means, key=run_means.get)[len(run_means) // 2]
+    if len(run_means) >= 2:  # the run the profiler disturbed least: its per-dispatch overhead only ever adds
+        kt_dir = min(run_means, key=run_means.get)
     out["kernel_trace_runs"] = {"dominant_kernel_mean_ns_per_run": [run_means[k] for k in sorted(run_means)], "reported_run": kt_dir,
                                 "note": "rocprofv3's per-dispatch overhead differs from run to run (two modes, ~0.4 us apart on a 6 us kernel): "
-                                        "all runs' means are listed, durations / stats below are those of the median run"}
+                                        "all runs' means are listed; durations / stats below are those of the run with the smallest mean (the overhead only adds; "
+                                        "bench.py's wall clock of the same launches, no profiler attached, reads 5.96-6.04 us where these read 6.0-6.5)"}
     ks = first(f"{kt_dir}/**/*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
