@@ -47,8 +47,27 @@ def sci(x):
     return f"{x / 10 ** e:.2f} × 10{str(e).translate(str.maketrans('0123456789-', '⁰¹²³⁴⁵⁶⁷⁸⁹⁻'))}"
 
 
+# workloads whose kernels were not re-profiled this round (they did not change): the previous round's summary, marked with a dagger
+prev = {}
+try:
+    prev = json.load(open(os.path.join(ROOT, "profiles", f"r{int(tag[1:]) - 1:02d}_summary.json")))["workloads"]
+except Exception:
+    pass
+daggers = []
+
+
+def wl(w):
+    if w in summ["workloads"]:
+        return summ["workloads"][w]
+    if w in prev:
+        if w not in daggers:
+            daggers.append(w)
+        return prev[w]
+    return {}
+
+
 def kernel_us(w):
-    d = summ["workloads"].get(w, {}).get("dominant_kernel_launch")
+    d = wl(w).get("dominant_kernel_launch")
     return d["duration_ns"] if d else None
 
 
@@ -96,8 +115,8 @@ for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-na
     if w not in lines:
         continue
     l = lines[w]
-    k = kernel_us(w)
-    ks = f"{k['mean'] / 1e3:.2f} / {k['median'] / 1e3:.2f}" if k else "–"
+    k = kernel_us(w) if w != "sokoban-wide-solver" else None  # (the profiled solver-active entry is the ASYNCHRONOUS kernel: next row)
+    ks = (f"{k['mean'] / 1e3:.2f} / {k['median'] / 1e3:.2f}" + (" †" if w in daggers else "")) if k else "–"
     ro = l.get("open_loop_rollout")
     cb = l.get("cpu_baseline")
     kf = (l['roofline']['algorithmic_bytes_per_launch'] / (k['mean'] * 1e-9) / 8e12) if k else None
@@ -106,16 +125,24 @@ for w in ("binary-narrow", "zelda-turtle", "sokoban-wide", "minecraft_3D_maze-na
                 + (f"{ro['us_per_step']:.2f}" if ro else "–") + " | "
                 + (f"{l['closed_loop_device_actions']['us_per_step']:.2f}" if (l.get('closed_loop_device_actions') or {}).get('us_per_step') else "–") + " | "
                 + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + f" | {NOTES.get(w, '')} |")
+la = lines.get("sokoban-wide-solver-async16")
+if la:
+    k = kernel_us("sokoban-wide-solver")
+    cb = la.get("cpu_baseline")
+    rows.append(f"| sokoban-wide-solver, asynchronous stepping (budget 16) | {la['config']['envs_per_gpu']} | {sci(la['value'])} emitted | {la['ms_per_step'] * 1e3:.2f} per launch | "
+                + (f"{k['mean'] / 1e3:.2f} / {k['median'] / 1e3:.2f}" if k else "–") + f" | {la['roofline']['frac']:.3f} | – | – | – | "
+                + (f"{sci(cb['value'])} ({cb['cores']})" if cb else "–") + " | `pcgrl_step_ready`, §4.1a: busy envs do not step; the HBM roof is the wrong ruler for a search-bound launch |")
 extra = []
 for w in ("zelda-turtle", "sokoban-wide", "minecraft_3D_maze-narrow", "binary_big-narrow", "binary_bigger-narrow", "zelda_big-turtle", "zelda_bigger-turtle",
           "minecraft_3D_maze-narrow-15", "binary-narrow-static", "binary-narrow-patch3x3", "zelda-turtle-bfs", "binary-narrow-evo", "binary-stats-for-grids",
           "zelda-stats-for-grids", "binary-narrow+rollout", "binary-narrow@16384", "binary-narrow@65536", "zelda-turtle@16384", "zelda-turtle@65536",
           "sokoban-wide@8192", "sokoban-wide@32768", "minecraft_3D_maze-narrow@4096", "minecraft_3D_maze-narrow@16384"):
-    s_ = summ["workloads"].get(w, {})
+    s_ = wl(w)
     if "hbm_traffic_per_launch" in s_ and "lds" in s_:
-        extra.append(f"{w}: traffic {s_['hbm_traffic_per_launch']['traffic_bytes'] / 1e6:.1f} MB / launch = {s_['hbm_traffic_per_launch']['traffic_over_algorithmic']:.2f} × algorithmic, "
+        extra.append(f"{w}{' †' if w in daggers else ''}: traffic {s_['hbm_traffic_per_launch']['traffic_bytes'] / 1e6:.1f} MB / launch = {s_['hbm_traffic_per_launch']['traffic_over_algorithmic']:.2f} × algorithmic, "
                      f"{s_['occupancy']['waves_per_cu']:.0f} waves per CU, LDS bank-conflict rate {s_['lds']['bank_conflict_rate']:.2f}")
-workload_table = "\n".join(rows) + "\n\nCounters (`profiles/" + tag + "_summary.json`): " + "; ".join(extra) + "."
+workload_table = ("\n".join(rows) + "\n\nCounters (`profiles/" + tag + "_summary.json`): " + "; ".join(extra) + "."
+                  + ("\n\n† kernel unchanged since the previous round and not re-profiled: figures of `profiles/r%02d_summary.json`." % (int(tag[1:]) - 1) if daggers else ""))
 
 sa = lines.get("sokoban-wide-solver")
 solver_active = ""
@@ -154,8 +181,9 @@ for w, sizes in (("binary-narrow", ("", "-16384", "-65536", "-262144")), ("zelda
             continue
         f_ = l["roofline"].get("fill_same_bytes")
         kk = kernel_us(w + ("@" + sfx[1:] if sfx else ""))
+        dg = " †" if (w + ("@" + sfx[1:] if sfx else "")) in daggers else ""
         sweep_rows.append(f"| {w} | {l['config']['envs_per_gpu']} | {sci(l['value'])} | {l['ms_per_step'] * 1e3:.2f} | {l['roofline']['frac']:.3f} | "
-                          + (f"{f_['us']:.2f} ({f_['step_over_fill']:.2f} ×)" if f_ else "–") + " | " + (f"{kk['mean'] / 1e3:.2f} / {kk['median'] / 1e3:.2f}" if kk else "–") + " |")
+                          + (f"{f_['us']:.2f} ({f_['step_over_fill']:.2f} ×)" if f_ else "–") + " | " + (f"{kk['mean'] / 1e3:.2f} / {kk['median'] / 1e3:.2f}{dg}" if kk else "–") + " |")
 sweep_table = "\n".join(sweep_rows)
 
 # evolution-driver pattern
