@@ -10,7 +10,11 @@
 
 namespace pcgrl {
 
-enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS, K_ROLLOUT };
+// K_ROLLOUT_SIM / K_ROLLOUT_OBS: the two roles of a rollout as kernels of their own (16x16 compile-time kernels, plain mode)
+// K_ROLLOUT_RESIDENT launches nothing: it asks the runtime how many workgroups of the two-role rollout kernel one CU holds
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor) and leaves the answer in rollout_resident_per_cu
+enum KernelId { K_STEP, K_RESET, K_OBSERVE, K_GET_STATE, K_LAST_EPISODE, K_STATS_FOR_GRIDS, K_ROLLOUT, K_ROLLOUT_SIM, K_ROLLOUT_OBS, K_ROLLOUT_RESIDENT };
+inline thread_local int rollout_resident_per_cu = 0;
 
 // one per translation unit (M = row-mask type: 32-bit for W <= 32, 64-bit for W <= 64)
 hipError_t launch_binary32(KernelId id, int lpe, const Params &p, size_t lds, hipStream_t s);
@@ -142,6 +146,26 @@ static hipError_t launch_pl(KernelId id, const Params &p, size_t lds, hipStream_
       }
       break;
     }
+    case K_ROLLOUT_SIM:
+    case K_ROLLOUT_OBS:
+    case K_ROLLOUT_RESIDENT:
+      if constexpr (LPE == 16 && sizeof(M) == 4) {
+        if (fast && !(p.trg || p.reward64)) {
+          if (id == K_ROLLOUT_RESIDENT) {
+            int nb = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<PROB, LPE, M, true, false, 0>, 128, lds);
+            rollout_resident_per_cu = nb;
+            return e;
+          } else if (id == K_ROLLOUT_SIM) {
+            const int epw = p.spread > 0 ? p.spread : 64 / LPE;
+            hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true, false, 1>), dim3((p.n_envs + epw - 1) / epw), dim3(64), 0, s, p);
+          } else {
+            hipLaunchKernelGGL((rollout_kernel<PROB, LPE, M, true, false, 2>), grid, dim3(64), lds, s, p);
+          }
+          break;
+        }
+      }
+      return hipErrorInvalidValue;  // (the engine only asks for the split form where these kernels exist)
     case K_RESET: hipLaunchKernelGGL((reset_kernel<PROB, LPE, M>), grid, block, 0, s, p); break;
     case K_OBSERVE:
       if constexpr (LPE == 16 && sizeof(M) == 4) {

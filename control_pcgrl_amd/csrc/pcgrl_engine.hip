@@ -58,7 +58,16 @@ struct pcgrl_engine {
   // kernel, 0 = always step launches, unset = by shape; PCGRL_OBS_NT_MB = observation bytes per launch (MB) from which the
   // stores are non-temporal (default 384, 0 = never)
   int rollout_form = -1;
-  int rollout_epw = -1;  // PCGRL_ROLLOUT_EPW (development): envs per wavefront of the rollout kernel, -1 = chosen by batch size
+  int rollout_epw = -1;  // PCGRL_ROLLOUT_EPW (development): envs per wavefront of the rollout's simulate role, -1 = chosen by batch size
+  // pcgrl_rollout as two kernels (16x16 compile-time kernels, plain mode): the observe role runs on this stream from a
+  // snapshot of the pre-call state (tile planes, the scalars of the hot state line, both RNG streams)
+  bool split_ok = false;
+  int64_t two_role_resident = 0;  // workgroups of the two-role rollout kernel the device holds at once (occupancy x CUs)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void *snap_planes = nullptr;
+  EnvState *snap_st = nullptr;
+  RngState *snap_rng = nullptr;
   long obs_nt_mb = 384;
   bool maybe_stale = false;  // pcgrl_update ran since the last refresh / full reset: some env may carry ENV_STATS_DIRTY
   int64_t obs_bytes = 0;
@@ -469,6 +478,23 @@ __global__ __launch_bounds__(64) void rng_state_kernel(Params p, uint64_t *out, 
   }
 }
 
+// pcgrl_rollout in its two-kernel form: what the observe kernel needs of the state as it is BEFORE the call -- the tile planes,
+// the first 32 bytes of the hot state line (position, counters, flags) and both RNG streams -- copied in 16-byte pieces
+__global__ __launch_bounds__(256) void rollout_snapshot_kernel(const uint4 *planes, uint4 *s_planes, int64_t plane_q, const uint4 *st, uint4 *s_st,
+                                                               const uint4 *rng, uint4 *s_rng, int32_t n_envs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_st = (int64_t)n_envs * 2, n_rng = (int64_t)n_envs * (int64_t)(sizeof(RngState) / 16);
+  if (i < plane_q) {
+    s_planes[i] = planes[i];
+  } else if (i < plane_q + n_st) {
+    const int64_t j = i - plane_q, e = j >> 1, q = j & 1;
+    s_st[e * (int64_t)(sizeof(EnvState) / 16) + q] = st[e * (int64_t)(sizeof(EnvState) / 16) + q];
+  } else if (i < plane_q + n_st + n_rng) {
+    const int64_t j = i - plane_q - n_st;
+    s_rng[j] = rng[j];
+  }
+}
+
 // pcgrl_env_busy: 1 = the env waits for a parked search (asynchronous stepping)
 __global__ __launch_bounds__(256) void env_busy_kernel(Params p, uint8_t *out) {
   const int env = blockIdx.x * 256 + threadIdx.x;
@@ -721,6 +747,30 @@ int pcgrl_create(const pcgrl_config *cfg, int32_t n_envs, int32_t device, pcgrl_
       e->state_arrays.push_back({p.trg_flag, sizeof(int32_t)});
     }
   }
+  // the two-kernel rollout exists for the compile-time 16x16 kernels in plain mode (no wrappers, no control metrics)
+  if (!is3d && H == 16 && W == 16 && !p.ext && cfg->n_ctrl == 0 &&
+      (cfg->representation == PCGRL_REP_WIDE || (cfg->obs_window[0] == 32 && cfg->obs_window[1] == 32))) {
+    hipError_t he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+    if (he == hipSuccess) he = dalloc(&e->snap_planes, (size_t)n_envs * ROW_WORDS * H * sizeof(uint32_t));
+    if (he == hipSuccess) he = dalloc((void **)&e->snap_st, (size_t)n_envs * sizeof(EnvState));
+    if (he == hipSuccess) he = dalloc((void **)&e->snap_rng, (size_t)n_envs * sizeof(RngState));
+    if (he != hipSuccess) {
+      pcgrl_destroy(e);
+      return fail(PCGRL_EHIP, std::string("pcgrl_create (rollout side stream / snapshot): ") + hipGetErrorString(he));
+    }
+    e->split_ok = true;
+    int cus = 0;
+    rollout_resident_per_cu = 0;
+    if (launch(K_ROLLOUT_RESIDENT, e->lpe, e->p, e->lds_bytes, nullptr, e->cpl) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess)
+      e->two_role_resident = (int64_t)rollout_resident_per_cu * cus;
+    // (development / tests: PCGRL_ROLLOUT_RESIDENT=<workgroups> stands in for the device's figure, so that small batches take
+    // the forms of large ones)
+    if (getenv("PCGRL_ROLLOUT_RESIDENT")) e->two_role_resident = atol(getenv("PCGRL_ROLLOUT_RESIDENT"));
+    (void)hipGetLastError();
+  }
   {
     const hipError_t he = hipHostMalloc((void **)&e->hdr_host, 256, hipHostMallocDefault);
     if (he != hipSuccess) {
@@ -742,6 +792,9 @@ void pcgrl_destroy(pcgrl_handle h) {
   DeviceGuard guard(h->device);
   if (h->seen_host) (void)hipHostFree(h->seen_host);
   if (h->hdr_host) (void)hipHostFree(h->hdr_host);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   for (void *a : h->allocs) (void)hipFree(a);
   delete h;
 }
@@ -842,17 +895,20 @@ int pcgrl_step_ex(pcgrl_handle h, const int32_t *d_actions, int32_t auto_reset, 
 // zelda_bigger 217 vs 126, binary_bigger 60 vs 51, binary_big 16.7 vs 15.5 (bench lines of rounds 4 / 5).  There the call
 // issues its n_steps as step launches: same results by the entry point's own definition.
 static bool rollout_as_steps(const pcgrl_engine *h) {
-  if (h->rollout_form >= 0) return h->rollout_form == 0;  // (development / tests, read at pcgrl_create)
+  if (h->rollout_form >= 0) return h->rollout_form == 0;  // (pcgrl_set_rollout_form; PCGRL_ROLLOUT_KERNEL at pcgrl_create)
   // (maps of more than 16 rows without tile codes, e.g. binary_big 32 x 32: 16.7 us per step in one launch -- its kernel sits at
   // 256 VGPRs -- against 15.0-15.5 as step launches)
   // lpe > 16: a 2-D map of more than 16 rows OR more than 32 columns (64-bit row masks run on 32 / 64 lanes per env)
   return h->p.cfg.problem != PCGRL_PROB_MC3DMAZE && (h->p.obs_codes > 0 || h->lpe > 16);
 }
 
-int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h) { return h ? (rollout_as_steps(h) ? 0 : 1) : -1; }
+int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h) { return h ? (rollout_as_steps(h) ? 0 : 1) : -1; }  // (1 also for the two-kernel form)
 
 int pcgrl_set_rollout_form(pcgrl_handle h, int32_t form) {
-  if (!h || form < -1 || form > 1) return fail(PCGRL_EINVAL, "pcgrl_set_rollout_form: form must be -1 (by shape), 0 (step launches) or 1 (one launch)");
+  if (!h || form < -1 || form > 2)
+    return fail(PCGRL_EINVAL, "pcgrl_set_rollout_form: form must be -1 (by shape), 0 (step launches), 1 (one kernel) or 2 (two kernels)");
+  if (form == 2 && !h->split_ok)
+    return fail(PCGRL_EUNSUPPORTED, "pcgrl_set_rollout_form(2): the two-kernel rollout exists for 16 x 16 maps with the default window, plain mode");
   h->rollout_form = form;
   return PCGRL_OK;
 }
@@ -882,6 +938,29 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
   p.actions = d_actions;
   p.n_steps = n_steps;
   p.spread = 0;
+  // The roles as kernels of their own (16 x 16 compile-time kernels, plain mode; not while statistics may be stale and not in the
+  // controllable-output form), see rollout_kernel's ROLE.  The simulate kernel takes 103 / 114 / 157 VGPRs (binary / zelda /
+  // sokoban) against the two-role kernel's 224 / 323 / 335, whose workgroups are all resident at once only up to
+  // two_role_resident of them (binary 1024 = 4096 envs, zelda and sokoban 512 = 2048 envs); beyond that it runs in rounds and the
+  // roles are better off apart.  By shape (form -1), measured in profiles/r06_dev_traces.md section 3:
+  //   no observation asked for    the simulate kernel alone, always (never slower; binary-narrow 16 384 envs 9.3 -> 6.1 us per
+  //                               step, zelda-turtle 4096 envs 4.4 -> 2.1)
+  //   only the last observation   when the two-role kernel would run in rounds: the simulate kernel, then pcgrl_observe's kernel
+  //                               on the state it left, same stream (zelda-turtle 4096 envs 4.2 -> 2.2; one launch more per call,
+  //                               which costs binary-narrow at 4096 envs 4.04 -> 4.32 at 8 steps per call: not below the bound)
+  //   every observation           when the two-role kernel would run in rounds and the call has >= 16 steps: both kernels, the
+  //                               observe one on the engine's side stream from a snapshot of the pre-call state (form 2).
+  //                               Snapshot + fork + join cost 15-25 us per CALL (binary-narrow 4096 envs, 8 steps: 5.97 vs 4.10 us
+  //                               per step; 64 steps: 3.42 vs 3.21), the gain is the simulate role's occupancy (binary-narrow
+  //                               8192 envs 7.86 -> 5.87, zelda-turtle 4096 envs 8.64 -> 7.51, 16 384 envs 33.4 -> 28.4).
+  // Fewer envs per simulate wave (PCGRL_ROLLOUT_EPW) do NOT pay: a wave64 instruction occupies its SIMD for four cycles whatever
+  // the number of active lanes, and two waves per SIMD already issue back to back (binary-narrow, 1 / 2 envs per wave: 4.59 / 3.54).
+  const bool roles_ok = h->split_ok && !h->maybe_stale && d_reward64 == nullptr && d_ctrl_obs == nullptr && h->rollout_form != 1;
+  const int64_t two_role_wgs = ((int64_t)h->p.n_envs + 64 / h->lpe - 1) / (64 / h->lpe);
+  const bool in_rounds = h->two_role_resident > 0 && two_role_wgs > h->two_role_resident;
+  const bool split = roles_ok && d_obs != nullptr && (h->rollout_form == 2 || (in_rounds && !obs_last_only && n_steps >= 16));
+  const bool sim_then_observe = roles_ok && !split && d_obs != nullptr && obs_last_only && in_rounds;
+  const bool sim_only = (roles_ok && d_obs == nullptr) || sim_then_observe;
   if (h->p.cfg.problem != PCGRL_PROB_MC3DMAZE) {
     const int full = 64 / h->lpe;
     int epw = h->rollout_epw;
@@ -899,6 +978,41 @@ int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, 
   p.done = d_done;
   p.stats_out = d_stats;
   p.ctrl_obs = d_ctrl_obs;
+  if (split || sim_only) {
+    hipStream_t s0 = (hipStream_t)stream;
+    if (split) {  // the observe kernel: from a snapshot of the pre-call state, on the side stream
+      const int64_t plane_q = (int64_t)h->p.n_envs * ROW_WORDS * h->p.cfg.dims[0] * (int64_t)sizeof(uint32_t) / 16;
+      const int64_t total = plane_q + (int64_t)h->p.n_envs * 2 + (int64_t)h->p.n_envs * (int64_t)(sizeof(RngState) / 16);
+      hipLaunchKernelGGL(rollout_snapshot_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s0, (const uint4 *)h->p.planes,
+                         (uint4 *)h->snap_planes, plane_q, (const uint4 *)h->p.st, (uint4 *)h->snap_st, (const uint4 *)h->p.rng, (uint4 *)h->snap_rng,
+                         h->p.n_envs);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(h->ev_fork, s0));
+      HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      Params po = p;
+      po.planes = h->snap_planes;
+      po.st = h->snap_st;
+      po.rng = h->snap_rng;
+      po.spread = 0;
+      po.reward = nullptr;
+      po.done = nullptr;
+      po.stats_out = nullptr;
+      HIPCHK(launch(K_ROLLOUT_OBS, h->lpe, po, h->lds_bytes, h->side, h->cpl));
+    }
+    Params ps = p;
+    ps.obs = nullptr;
+    HIPCHK(launch(K_ROLLOUT_SIM, h->lpe, ps, 0, s0, h->cpl));
+    if (split) {
+      HIPCHK(hipEventRecord(h->ev_join, h->side));
+      HIPCHK(hipStreamWaitEvent(s0, h->ev_join, 0));
+    }
+    if (sim_then_observe) {
+      Params po = h->p;
+      po.obs = d_obs;
+      HIPCHK(launch(K_OBSERVE, h->lpe, po, h->lds_bytes, s0, h->cpl));
+    }
+    return PCGRL_OK;
+  }
   HIPCHK(launch(K_ROLLOUT, h->lpe, p, h->lds_bytes, (hipStream_t)stream, h->cpl));
   return PCGRL_OK;
 }

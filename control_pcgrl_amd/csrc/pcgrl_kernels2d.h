@@ -2219,14 +2219,21 @@ void step_kernel(Params p) {
 // per-step kernel boundary, no per-step state traffic, and waves advance independently (a launch no longer waits for
 // its slowest env at every step).  CTRL: controllable mode (per-env targets, float64 rewards); the general (non-FAST)
 // kernels also run the representation wrappers (static tiles / action patches, Params::ext).
-template <int PROB, int LPE, typename M, bool FAST, bool CTRL = false>
-__global__ __launch_bounds__(128) void rollout_kernel(Params p) {
+// ROLE (round 6): 0 = both roles in one workgroup (simulate wave + observe wave), as in rounds 2-5;
+//   1 = simulate only, 2 = observe only -- the two roles of ONE pcgrl_rollout call as two kernels on two streams.  They never
+//   exchange anything (the observe role replays actions and resets on its own copy of the RNG streams), so nothing ties them to
+//   one workgroup; apart they get a register budget each (together: the maximum, 224 VGPRs = two waves per SIMD) and the
+//   simulate role can give every env a wavefront of its own (Params::spread): a wave then advances at the pace of ITS env
+//   instead of the slowest of four at every step.  The observe kernel reads the state as it was BEFORE the call from a
+//   snapshot (the simulate kernel overwrites the live state when it ends): Params::planes / st / rng point there.
+template <int PROB, int LPE, typename M, bool FAST, bool CTRL = false, int ROLE = 0>
+__global__ __launch_bounds__(ROLE == 0 ? 128 : 64) void rollout_kernel(Params p) {
   constexpr int NB = ProbTraits<PROB>::NB, NS = ProbTraits<PROB>::NS, EPW = 64 / LPE;
   constexpr int NW = NB + ProbTraits<PROB>::NAUX;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   Grp<LPE> g;
   g.init();
-  const bool observer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;  // wave-uniform
+  const bool observer = ROLE == 2 ? true : (ROLE == 1 ? false : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0);  // wave-uniform
   if (observer && p.obs == nullptr) return;
   PHASE_DECL();  // (development builds: the shared helpers take the phase counters; nothing is flushed here)
   const int H = FAST ? 16 : p.cfg.dims[0], W = FAST ? 16 : p.cfg.dims[1];
@@ -2269,7 +2276,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(Params p) {
   rr.load(p.rng[e].rep);
   const size_t astride = N * (size_t)p.n_act;  // action entries per step
   int action = (active && p.n_act == 1) ? p.actions[e] : 0;
-  if (p.obs != nullptr) __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
+  if (ROLE == 0 && p.obs != nullptr) __syncthreads();  // both waves hold the old state before wave 0 may overwrite it
   if (PROB != PCGRL_PROB_ZELDA && !observer && p.n_envs <= 8192) __builtin_amdgcn_s_setprio(3);  // (as in step_kernel)
   bool any_change = false, any_reset = false, bad_any = false;
 

@@ -171,9 +171,17 @@ int32_t pcgrl_num_actions(pcgrl_handle h); /* narrow: n_tiles; turtle: n_tiles +
 int pcgrl_rollout(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                   int32_t obs_last_only, float *d_reward, uint8_t *d_done, int32_t *d_stats, void *stream);
 int32_t pcgrl_rollout_is_one_launch(pcgrl_handle h); /* 1: one launch per call; 0: n_steps step launches (2-D maps of more than 16 rows or 32 columns) */
-/* which form pcgrl_rollout[_ex] takes on this engine: -1 = chosen by shape (default), 1 = always the one-launch kernel, 0 = always
- * n_steps step launches.  Same results either way (tests and the fuzzer exercise both on every shape).  The environment variable
- * PCGRL_ROLLOUT_KERNEL=0|1 sets the engine's initial value at pcgrl_create (development). */
+/* which form pcgrl_rollout[_ex] takes on this engine: -1 = chosen by shape (default), 0 = always n_steps step launches, 1 = always
+ * the one-launch kernel (a simulate and an observe wavefront per workgroup), 2 = two kernels -- the simulate role on `stream`, the
+ * observe role on a stream of the engine's own, forked from and joined back into `stream` with events (capturable like any fork /
+ * join), reading a snapshot of the pre-call state: the roles never exchange anything, and apart each has its own register budget
+ * (simulate: 103 / 114 / 157 VGPRs for binary / zelda / sokoban against 224 / 323 / 335 together).  The role kernels exist for
+ * 16 x 16 maps with the default window in plain mode (no wrappers, no control metrics; form 2 is PCGRL_EUNSUPPORTED otherwise).
+ * What -1 does on those configurations: a call with d_obs == NULL runs the simulate kernel alone; when the batch has more
+ * workgroups than the two-role kernel keeps resident at once (asked of the runtime at pcgrl_create: more than 4096 binary or 2048
+ * zelda / sokoban envs on an MI355X) a call for the last observation runs the simulate kernel and then pcgrl_observe's, and a call
+ * of >= 16 steps for every observation takes form 2 (its snapshot + fork + join cost 15-25 us per call).  Same results in every
+ * form (tests and the fuzzer exercise all of them).  PCGRL_ROLLOUT_KERNEL=0|1 sets the engine's initial value at pcgrl_create. */
 int pcgrl_set_rollout_form(pcgrl_handle h, int32_t form);
 int pcgrl_rollout_ex(pcgrl_handle h, const int32_t *d_actions, int32_t n_steps, int32_t auto_reset, uint8_t *d_obs,
                      int32_t obs_last_only, float *d_reward, double *d_reward64, uint8_t *d_done, int32_t *d_stats,

@@ -327,8 +327,10 @@ def run_case(case, seed, verbose=False):
             want = str(rng.choice(["all", "last", "none"]))
             a = draw_actions(t, lead=(K,))
             # pcgrl_rollout picks its form by map size (one launch / n step launches); both forms stay under test on every shape
-            form = str(rng.choice(["auto", "1", "0"]))
-            env._L.pcgrl_set_rollout_form(env._h, -1 if form == "auto" else int(form))
+            form = str(rng.choice(["auto", "1", "0", "2"]))
+            if env._L.pcgrl_set_rollout_form(env._h, -1 if form == "auto" else int(form)) != 0:  # (form 2: 16 x 16 plain configs only)
+                form = "auto"
+                env._L.pcgrl_set_rollout_form(env._h, -1)
             try:
                 obs, rew, done, stats = env.rollout(a.to(env.device), want_obs=want)
             finally:

@@ -395,3 +395,93 @@ def test_step_ready_captured_in_a_hip_graph_equals_eager_launches():
     for a, b in zip(*out):
         assert torch.equal(a, b)
     assert int((out[0][0] & 2).sum()) > 0 and int((out[0][0] & 1).sum()) > 0
+
+
+# ------------------------------------------------------------------------------------- rollout roles as kernels of their own
+@pytest.mark.parametrize("form", [2, -1, "crowded"])
+@pytest.mark.parametrize("problem,rep,n", [("binary", "narrow", 300), ("zelda", "turtle", 150), ("sokoban", "wide", 96)])
+def test_rollout_two_kernel_form_and_simulate_only_vs_oracle(problem, rep, n, form, monkeypatch):
+    """pcgrl_set_rollout_form(2): the simulate role on the caller's stream, the observe role on the engine's side stream from a
+    snapshot of the pre-call state.  Form -1 (the default): the simulate kernel alone for a call without observations, the simulate
+    kernel followed by the observe kernel for a call that wants the last one and the two kernels for a call that wants every one
+    when the two-role kernel's workgroups would not all be resident at once ("crowded": PCGRL_ROLLOUT_RESIDENT makes this batch
+    count as one that large; test_rollout_by_shape_at_batches_beyond_one_round does it at real sizes), the two-role kernel
+    otherwise.  Auto-resets
+    inside the launches (short episodes), several calls in a row, then the same under HIP-graph capture (fork / join captured)."""
+    kw = dict(change_percentage=0.1)
+    seeds = 40 + np.arange(n)
+    orc = po.OracleVecEnv(problem, rep, (16, 16), n, seeds=seeds, threads=8, **kw)
+    if form == "crowded":
+        monkeypatch.setenv("PCGRL_ROLLOUT_RESIDENT", "8")
+        form = -1
+    env = _vec(problem, rep, (16, 16), n, seeds=seeds, auto_reset=True, **kw)
+    monkeypatch.delenv("PCGRL_ROLLOUT_RESIDENT", raising=False)
+    assert env._L.pcgrl_set_rollout_form(env._h, form) == 0
+    env.reset()
+    orc.reset()
+    g = torch.Generator().manual_seed(8)
+    K = 70
+    for call in range(3):
+        a = torch.randint(0, env.num_actions, (K, n), generator=g, dtype=torch.int32)
+        want = ("all", "none", "last")[call]
+        obs, rew, done, stats = env.rollout(a.cuda(), want_obs=want)
+        for t in range(K):
+            oobs, orew, odone, ostats = orc.step(a[t].numpy(), auto_reset=True)
+            assert np.array_equal(stats[t].cpu().numpy(), ostats), (call, t)
+            assert np.abs(rew[t].cpu().numpy().astype(np.float64) - orew).max() <= REW_TOL and np.array_equal(done[t].cpu().numpy(), odone)
+            if want == "all":
+                assert np.array_equal(obs[t].cpu().numpy(), oobs), (call, t)
+        if want == "last":
+            assert np.array_equal(obs.cpu().numpy(), oobs)
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    # captured: the fork into the side stream and the join back are part of the graph
+    a = torch.randint(0, env.num_actions, (K, n), generator=g, dtype=torch.int32).cuda()
+    obs = torch.zeros((K, n) + env.obs_shape, dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((K, n), dtype=torch.float32, device="cuda")
+    done = torch.zeros((K, n), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros((K, n, env.n_stats), dtype=torch.int32, device="cuda")
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            rc = env._L.pcgrl_rollout(env._h, a.data_ptr(), K, 1, obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr(), stats.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+    torch.cuda.current_stream().wait_stream(side)
+    for rep_ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for t in range(K):
+            oobs, orew, odone, ostats = orc.step(a[t].cpu().numpy(), auto_reset=True)
+            assert np.array_equal(stats[t].cpu().numpy(), ostats), (rep_, t)
+            assert np.array_equal(obs[t].cpu().numpy(), oobs), (rep_, t)
+    env.check_errors()
+    big = _vec(problem, rep, (32, 32) if rep != "wide" else (20, 20), 4, seeds=np.arange(4))
+    assert big._L.pcgrl_set_rollout_form(big._h, 2) == 2  # EUNSUPPORTED off the 16 x 16 point
+
+
+@pytest.mark.parametrize("problem,rep,n", [("binary", "narrow", 4608), ("zelda", "turtle", 2304)])
+def test_rollout_by_shape_at_batches_beyond_one_round(problem, rep, n):
+    """More envs than the two-role rollout kernel holds resident at once (binary: 4096, zelda: 2048 on an MI355X): by shape the
+    engine then runs the roles as kernels of their own -- every result the oracle's, whatever the form."""
+    seeds = 7 + np.arange(n)
+    orc = po.OracleVecEnv(problem, rep, (16, 16), n, seeds=seeds, threads=8, change_percentage=0.1)
+    env = _vec(problem, rep, (16, 16), n, seeds=seeds, auto_reset=True, change_percentage=0.1)
+    env.reset()
+    orc.reset()
+    g = torch.Generator().manual_seed(9)
+    K = 40
+    for want in ("all", "last", "none"):
+        a = torch.randint(0, env.num_actions, (K, n), generator=g, dtype=torch.int32)
+        obs, rew, done, stats = env.rollout(a.cuda(), want_obs=want)
+        for t in range(K):
+            oobs, orew, odone, ostats = orc.step(a[t].numpy(), auto_reset=True)
+            assert np.array_equal(stats[t].cpu().numpy(), ostats), (want, t)
+            assert np.array_equal(done[t].cpu().numpy(), odone)
+            assert np.abs(rew[t].cpu().numpy().astype(np.float64) - orew).max() <= REW_TOL
+            if want == "all":
+                assert np.array_equal(obs[t].cpu().numpy(), oobs), (want, t)
+        if want == "last":
+            assert np.array_equal(obs.cpu().numpy(), oobs)
+    assert np.array_equal(env.get_state().grids.cpu().numpy().reshape(n, -1), orc.get_state()["grids"])
+    env.check_errors()
