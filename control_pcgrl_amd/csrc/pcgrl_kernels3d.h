@@ -55,6 +55,9 @@ namespace pcgrl {
 #define M3_MARK(coarse, fine) PHASE_MARK(6)
 #elif defined(PCGRL_M3_TRIPS)  // [0] chain trips [1] general trips [2] / [3] their cycles; the first four phases land in [6]
 #define M3_MARK(coarse, fine) PHASE_MARK((coarse) < 4 ? 6 : (coarse))
+#elif defined(PCGRL_M3_TAILSPLIT)  // [0] write-back + state stores [1] everything before the walk [2] wait for the helper's region count
+// [3] walk [4] overlay [5] loss + outputs [6] closing barrier
+#define M3_MARK(coarse, fine) PHASE_MARK((coarse) == 3 ? 3 : ((coarse) == 4 ? 4 : ((coarse) == 5 ? 0 : 1)))
 #elif defined(PCGRL_M3_PHASES)
 #define M3_MARK(coarse, fine) PHASE_MARK(coarse)
 #else
@@ -800,6 +803,7 @@ struct M3Mail {
   // the region count, also on the helper wave (it does not depend on the searches): job number / completion, the edited
   // cell (plane bit, plane), kind (0 new AIR cell, 1 removed, 2 count from scratch), count before the edit -> count
   int32_t rseq, rdone, r_eq, r_ez, r_kind, r_old, r_out;
+  int32_t obs_read;  // observe waves that hold their copy of the old state (the simulate wave writes back after all of them)
 };
 __device__ inline int m3_ld(const int32_t *x) { return __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void m3_st(int32_t *x, int v) { __hip_atomic_store(x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1014,21 +1018,47 @@ __device__ inline void m3_paths(M3Env<SC> &E, M3Work<SC> &W, const M3Ctx &c, PM<
   // path tile (x,y,z) is drawn at array index [x][y][z]
   for (int i = c.lane; i < c.L.nw; i += 64) c.over[i] = 0;
   if (best_slot >= 0) {
-    // Lane z holds plane z of the path as a bit mask, so "no path tile directly below" (remove_stacked_path_tiles) is one
-    // shift between lanes; what is left -- a handful of tiles per plane -- is drawn bit by bit, every lane its own plane.
-    // (Round 3 walked all Z heights of every column: 60 dependent LDS reads per lane at 15^3, 4 us of a changing step.)
     const uint32_t *pathm = c.spath(best_slot);
-    const PM<PW> P = c.lane < c.Z ? m3_plane_bits<PW>(pathm, c, c.lane) : pm_zero<PW>();
-    PM<PW> keep = P & ~pm_up(P);  // (lane z - 1's plane; zero into lane 0)
-    const int z = c.lane;
-    while (M3_BALLOT(pm_any(keep)) != 0) {
-      if (pm_any(keep)) {
-        const int q = pm_ctz(keep);
-        keep = keep & ~pm_lowest(keep);
-        const int y = q / c.X, x = q - y * c.X;
-        if (x < c.Z && z < c.X) {
-          const int oi = (x * c.Y + y) * c.X + z;
-          atomicOr(&c.over[oi >> 5], 1u << (oi & 31));
+    bool by_rows = false;
+    if constexpr (SC == 0) by_rows = c.X <= 8 && c.Z * c.Y <= 64;  // (compile-time for the 7^3 kernels)
+    if (by_rows) {
+      // Small maps (7^3: 49 rows of 7 cells): lane r = z * Y + y takes ROW y of plane z -- X <= 8 bits of the packed path
+      // mask, and the same row one plane lower for "no path tile directly below" -- and draws it with X predicated LDS ORs: no
+      // loop over tiles, no ballots (round 6; rounds 3-5 gave every plane a lane and looped over its tiles, ~1 900 cycles of the
+      // critical wave's tail at 7^3).
+      const int r = c.lane, z = r / c.Y, y = r - z * c.Y;
+      if (r < c.Z * c.Y) {
+        auto row_at = [&](int o) -> uint32_t {  // X bits from bit offset o of the mask
+          const int w0 = o >> 5, w1 = w0 + 1 < c.L.nw ? w0 + 1 : w0;
+          const uint64_t v = (uint64_t)pathm[w0] | ((uint64_t)pathm[w1] << 32);
+          return (uint32_t)(v >> (o & 31)) & ((1u << c.X) - 1u);
+        };
+        const int o = r * c.X;
+        uint32_t keep = row_at(o);
+        if (z >= 1) keep &= ~row_at(o - c.YX);
+        if (z < c.X) {
+          for (int x = 0; x < c.X && x < c.Z; x++) {
+            const int oi = (x * c.Y + y) * c.X + z;
+            if ((keep >> x) & 1u) atomicOr(&c.over[oi >> 5], 1u << (oi & 31));
+          }
+        }
+      }
+    } else {
+      // Lane z holds plane z of the path as a bit mask, so "no path tile directly below" (remove_stacked_path_tiles) is one
+      // shift between lanes; what is left -- a handful of tiles per plane -- is drawn bit by bit, every lane its own plane.
+      // (Round 3 walked all Z heights of every column: 60 dependent LDS reads per lane at 15^3, 4 us of a changing step.)
+      const PM<PW> P = c.lane < c.Z ? m3_plane_bits<PW>(pathm, c, c.lane) : pm_zero<PW>();
+      PM<PW> keep = P & ~pm_up(P);  // (lane z - 1's plane; zero into lane 0)
+      const int z = c.lane;
+      while (M3_BALLOT(pm_any(keep)) != 0) {
+        if (pm_any(keep)) {
+          const int q = pm_ctz(keep);
+          keep = keep & ~pm_lowest(keep);
+          const int y = q / c.X, x = q - y * c.X;
+          if (x < c.Z && z < c.X) {
+            const int oi = (x * c.Y + y) * c.X + z;
+            atomicOr(&c.over[oi >> 5], 1u << (oi & 31));
+          }
         }
       }
     }
@@ -1278,12 +1308,12 @@ void m3_kernel(Params p, int cpl) {
       mail.rdone = 0;
       mail.cancel = 0;
       mail.exit = 0;
+      mail.obs_read = 0;
     }
     __syncthreads();  // (the waves of a workgroup start together: nobody waits here)
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1 + m3_observers<SC>()) {
       // ---------------------------------------------------------------------------------------- helper wave
       m3_helper<SC, HELP_S>(p, HELP_S ? *WH : W, c, mail PHASE_PASS);  // (regions only: W is not touched)
-      if (p.obs != nullptr) __syncthreads();  // (the closing barrier of the other two waves)
       return;
     }
   }
@@ -1305,6 +1335,11 @@ void m3_kernel(Params p, int cpl) {
       Pcg rp, rr;
       rp.load(p.rng[env].prob);
       rr.load(p.rng[env].rep);
+      // The simulate wave overwrites the env's state only after every observe wave holds its copy of the old one: each reports
+      // in once its loads have returned (rounds 3-5 closed the launch with a barrier of all waves, which made the simulate
+      // wave wait for the helper wave to notice the end of the launch: ~400 cycles of every launch's critical wave).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (c.lane == 0) __hip_atomic_fetch_add(&mail.obs_read, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       uint32_t *odirt = obits, *oover = obits + nw;
       iteration += upd_only ? 0 : 1;
       bool change = false;
@@ -1326,10 +1361,6 @@ void m3_kernel(Params p, int cpl) {
       }
       TRACE_PUT(4, _tr0);
       TRACE_PUT(3, TRACE_NOW());
-      // the simulate wave overwrites the env's state only after this wave has read it: it waits at the same barrier just
-      // before its write-back, by which time this wave is long done (the barrier is at the END of both so that neither
-      // wave's work waits for the other's loads)
-      __syncthreads();
       return;
     }
     __builtin_amdgcn_s_setprio(3);  // the simulate wave's dependent chain issues ahead of the observe wave on its SIMD
@@ -1607,6 +1638,9 @@ void m3_kernel(Params p, int cpl) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           st[0] = __builtin_amdgcn_readfirstlane(m3_ld(&mail.r_out));
         }
+#ifdef PCGRL_M3_TAILSPLIT
+        PHASE_MARK(2);
+#endif
         if (ovf)  // queue overflow: reported (pcgrl_poll_error), no statistics of an unfinished search are handed out
           for (int i = 0; i < NS; i++) st[i] = st_old[i];
       }
@@ -1657,9 +1691,43 @@ void m3_kernel(Params p, int cpl) {
     if ((ovf || ovf_any) && c.lane == 0) atomicOr(p.err, 4);
     // ---- write back, once the observe wave has read the old state
     if (HELP && c.lane == 0) m3_st(&mail.exit, 1);
-    if (MODE == M3_STEP && p.obs != nullptr) __syncthreads();
+#ifdef PCGRL_M3_TAILSPLIT
+    PHASE_MARK(5);
+#endif
+    if (MODE == M3_STEP && p.obs != nullptr) {
+      while (__builtin_amdgcn_readfirstlane(m3_ld(&mail.obs_read)) != m3_observers<SC>()) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+#ifdef PCGRL_M3_TAILSPLIT
+    PHASE_MARK(6);
+#endif
     if (whole_record) {
       store_record();
+    } else if (SC == 0) {
+      // size class 0: every piece fits one pass of the wave (nw <= 16 words, a slot <= 36): all LDS reads are issued before the
+      // first store instead of one LDS round trip per piece
+      constexpr int NSL = M3C<0>::SLOTS;
+      const int l_nw = c.lane < nw ? c.lane : 0;
+      const uint32_t v_dirt = c.dirt[l_nw], v_over = c.over[l_nw], v_col = E.rec[c.L.o_col + col_word];
+      const uint2 v_mv = ((const uint2 *)(E.rec + c.L.o_mv))[mv_chg ? mv_cell : 0];
+      const uint32_t dm = dirty_hdr | dirty_full;
+      uint32_t v_slot[NSL];
+#pragma unroll
+      for (int s = 0; s < NSL; s++) {
+        const int n = ((dirty_full >> s) & 1u) ? c.L.slot_words : M3_SLOT_HDR;
+        v_slot[s] = (s < n_slots && ((dm >> s) & 1u) && c.lane < n) ? E.rec[c.L.o_slots + s * c.L.slot_words + c.lane] : 0u;
+      }
+      if (edited) {
+        if (c.lane < nw) grec[c.lane] = v_dirt;
+        if (c.lane == 0) grec[c.L.o_col + col_word] = v_col;
+        if (mv_chg) ((uint2 *)(grec + c.L.o_mv))[mv_cell] = v_mv;
+      }
+      if (over_dirty && c.lane < nw) grec[c.L.o_over + c.lane] = v_over;
+#pragma unroll
+      for (int s = 0; s < NSL; s++) {
+        const int n = ((dirty_full >> s) & 1u) ? c.L.slot_words : M3_SLOT_HDR;
+        if (s < n_slots && ((dm >> s) & 1u) && c.lane < n) grec[c.L.o_slots + s * c.L.slot_words + c.lane] = v_slot[s];
+      }
     } else {
       if (edited) {  // the tile bits, one column mask, the changed rows of the move table
         for (int i = c.lane; i < nw; i += 64) grec[i] = c.dirt[i];
