@@ -58,6 +58,9 @@ namespace pcgrl {
 #elif defined(PCGRL_M3_TAILSPLIT)  // [0] write-back + state stores [1] everything before the walk [2] wait for the helper's region count
 // [3] walk [4] overlay [5] loss + outputs [6] closing barrier
 #define M3_MARK(coarse, fine) PHASE_MARK((coarse) == 3 ? 3 : ((coarse) == 4 ? 4 : ((coarse) == 5 ? 0 : 1)))
+#elif defined(PCGRL_M3_HEADSPLIT)  // [0] loads + LDS fill [1] the edit [2] move-table update + slot-drop test [4] position, observation
+// (rollout) [5] region job posted, planes [3] walk [6] everything after it
+#define M3_MARK(coarse, fine) PHASE_MARK((coarse) == 0 ? 0 : ((coarse) == 1 ? 4 : ((coarse) == 2 ? 5 : ((coarse) == 3 ? 3 : 6))))
 #elif defined(PCGRL_M3_PHASES)
 #define M3_MARK(coarse, fine) PHASE_MARK(coarse)
 #else
@@ -705,7 +708,8 @@ __device__ inline int m3_search(M3Work<SC> &W, const M3Ctx &c, int root, uint32_
   (void)_t_prev;
   (void)dbg_trips;
   (void)dbg_pushed;
-#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES) && !defined(PCGRL_M3_SPEC) && !defined(PCGRL_M3_TAIL)
+#elif defined(PCGRL_PHASE_TIMING) && !defined(PCGRL_M3_PHASES) && !defined(PCGRL_M3_SPEC) && !defined(PCGRL_M3_TAIL) && \
+    !defined(PCGRL_M3_TAILSPLIT) && !defined(PCGRL_M3_HEADSPLIT)
   (void)_t_prev;
   _ph[0] += (uint32_t)dbg_trips;
   _ph[1] += (uint32_t)dbg_pushed;
@@ -1572,15 +1576,22 @@ void m3_kernel(Params p, int cpl) {
         const bool old = m3_bit(c.dirt, ci);
         change = old != (action != 0);
         if (change) {
-          if (c.lane == 0) {
-            c.dirt[ci >> 5] ^= 1u << (ci & 31);
-            c.col[ey * c.X + ex] ^= (uint16_t)(1u << ez);
+          if (c.lane == 0) {  // (LDS XORs without a result: nothing to wait for, where a read-modify-write is two round trips each)
+            const int q = ey * c.X + ex;
+            atomicXor(&c.dirt[ci >> 5], 1u << (ci & 31));
+            atomicXor((uint32_t *)c.col + (q >> 1), (1u << ez) << (16 * (q & 1)));
           }
           col_word = (ey * c.X + ex) >> 1;
           // the edit changes at most 48 bytes of the move table and drops exactly the slots that accepted one of their cells
           if (edited) whole_record = true;  // (rollout: more than one edit per launch)
           edited = true;
+#ifdef PCGRL_M3_HEADSPLIT
+          PHASE_MARK(1);
+#endif
           dirty_hdr |= m3_update_moves(c, ex, ey, ez, mv_chg, mv_cell);
+#ifdef PCGRL_M3_HEADSPLIT
+          PHASE_MARK(2);
+#endif
         }
 #ifdef PCGRL_M3_PHASES
         M3_MARK(6, 5);  // (development: edit + move-table update, apart from the position arithmetic below)

@@ -15,7 +15,7 @@ NAMES = ["loads+barrier", "action+state", "stats refresh (total)", "  flood", " 
          "loss/outputs/write-back"]
 
 if "--build" in sys.argv:
-    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",) + (("PCGRL_M3_PHASES",) if "--m3-phases" in sys.argv else ()) + (("PCGRL_M3_PHASES", "PCGRL_M3_TRIPS") if "--m3-trips" in sys.argv else ()) + (("PCGRL_M3_SPEC",) if "--m3-spec" in sys.argv else ()) + (("PCGRL_M3_TAIL",) if "--m3-tail" in sys.argv else ()) + (("PCGRL_M3_TAILSPLIT",) if "--m3-tailsplit" in sys.argv else ()))
+    _lib.build(force=True, out=TIMING_LIB, defines=("PCGRL_PHASE_TIMING",) + (("PCGRL_M3_PHASES",) if "--m3-phases" in sys.argv else ()) + (("PCGRL_M3_PHASES", "PCGRL_M3_TRIPS") if "--m3-trips" in sys.argv else ()) + (("PCGRL_M3_SPEC",) if "--m3-spec" in sys.argv else ()) + (("PCGRL_M3_TAIL",) if "--m3-tail" in sys.argv else ()) + (("PCGRL_M3_TAILSPLIT",) if "--m3-tailsplit" in sys.argv else ()) + (("PCGRL_M3_HEADSPLIT",) if "--m3-headsplit" in sys.argv else ()))
     print("built", TIMING_LIB)
     sys.exit(0)
 

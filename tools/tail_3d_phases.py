@@ -16,6 +16,8 @@ pool = torch.randint(0, 2, (1021, n), generator=g, device="cuda", dtype=torch.in
 sp = torch.cuda.current_stream().cuda_stream
 out = np.zeros(8 * n, np.uint64)
 names = ["loads", "edit+moves", "regions", "walk", "overlay", "outputs+writeback", "fresh", "wall(10ns)"]
+if "--headsplit" in sys.argv:  # timing build with --m3-headsplit
+    names = ["loads+fill", "edit", "moves+slot-drop", "walk", "position", "region-job+planes", "after-walk", "wall(10ns)"]
 if "--tailsplit" in sys.argv:  # timing build with --m3-tailsplit
     names = ["write-back", "before-walk", "wait-regions", "walk", "overlay", "loss+outputs", "barrier", "wall(10ns)"]
 rows, means = [], []
