@@ -540,6 +540,9 @@ __device__ __attribute__((always_inline)) inline bool sk_visited_test_and_set(So
 __device__ inline bool sk_key_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
 // heap entry i: the top of the tree sits in LDS when the wave has some (no memory round trips there)
 constexpr int SK_LDS_HEAP = 8192;  // entries per helper wave (32 KiB): a 10 000-iteration stage rarely grows beyond
+#ifndef SK_ASYNC_HEAP
+#define SK_ASYNC_HEAP 2048  // entries of the resumable solver's heap kept in LDS per workgroup (8 KiB; one env per workgroup)
+#endif
 // LDSONLY (the whole heap is in LDS, the common case): no global access is compiled in, so the sift never waits for the
 // vector-memory counter -- i.e. for the previous iteration's record stores and the record requested ahead of time.
 template <bool LDSONLY>
@@ -706,6 +709,13 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
       c.n_nodes = rs->n_nodes;
     }
   }
+  if constexpr (RES) {
+    // the top of a parked A* heap comes back into LDS (the whole heap is in the workspace, see the park below)
+    if (!fresh && b2 >= 0 && c.hcap > 0) {
+      const int n = sk_u(tail) < c.hcap ? sk_u(tail) : c.hcap;
+      for (int i = c.lane; i < n; i += 64) c.hl[i] = c.q[i];
+    }
+  }
   if (fresh) {
     const int h_root = sk_u(SokoNode::unpack(c.nodes[0]).h);
     if (b2 < 0) {
@@ -850,6 +860,10 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
   SK_T_FLUSH(b2 < 0 ? 0 : 1, iters);
   if constexpr (RES) {
     if (iters < max_iter && head < tail) {  // stopped on the budget: park
+      if (b2 >= 0 && c.hcap > 0) {  // the heap's top leaves LDS: the workspace holds the whole open list between launches
+        const int n = sk_u(tail) < c.hcap ? sk_u(tail) : c.hcap;
+        for (int i = c.lane; i < n; i += 64) c.q[i] = c.hl[i];
+      }
       rs->parked = true;
       rs->head = sk_u(head);
       rs->tail = sk_u(tail);
@@ -1516,8 +1530,13 @@ __device__ __attribute__((always_inline)) inline bool sokoban_solve_async(const 
     c.lv = &s_level;
     c.lane = g.lane;
     c.pool_full = false;
-    c.hl = (uint32_t SK_LDS *)nullptr;
-    c.hcap = 0;
+    // The top SK_ASYNC_HEAP entries of the A* open list live in LDS while a launch works on the search (as the helper waves of
+    // the synchronous kernels keep theirs): a pop or a push of a heap that fits walks no global memory at all, where each of
+    // the sift's rounds was a dependent round trip -- most of an A* iteration's time in this mode.  Loaded at resume, written
+    // back at park (sk_stage); static, so every kernel that runs the resumable solver has it (one search at a time per wave).
+    __shared__ uint32_t s_async_heap[SK_ASYNC_HEAP];
+    c.hl = (uint32_t SK_LDS *)s_async_heap;
+    c.hcap = SK_ASYNC_HEAP;
     c.dbg = nullptr;
     int px = 0, py = 0, ncr = 0, ntg = 0;
     sk_build_level<LPE, M, SK_MAXC>(g, gi, H, W, solid, player, crate, target, px, py, ncr, ntg);
