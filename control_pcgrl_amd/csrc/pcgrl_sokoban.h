@@ -737,12 +737,20 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
     }
     return __builtin_amdgcn_readlane((int)qv, i - qbase);
   };
+  // The next node's record is REQUESTED one iteration ahead and first looked at when that iteration begins: it stays packed
+  // until then (unpacking it here -- a handful of bit operations -- made the compiler wait for the load on the spot, so the
+  // "prefetch" was a round trip of its own in every iteration, rounds 4-6).
+  // (Only the two words the expansion reads: with the whole record the unused `parent` register was reused right after the
+  // load was issued -- the same wait by another route.)
   bool pre_valid = false;
   int pre_cur = 0;
-  SokoNode pre_nd;
+  uint32_t pre_y = 0, pre_z = 0;  // words 1 and 2 of the record: depth | h << 16, px | py << 8
+  auto pre_unpack = [&]() -> SokoNode {
+    sk_u32x4 r = {0u, pre_y, pre_z, 0u};
+    return SokoNode::unpack(r);
+  };
   SkCrates<NH> pre_cr;
   pre_cr.clear();
-  pre_nd.parent = pre_nd.depth = pre_nd.h = pre_nd.px = pre_nd.py = 0;
   SK_T_DECL();
   while (iters < max_iter && head < tail) {
     if (cancel != nullptr && sk_u(sk_ld(cancel)) < my_stage) break;
@@ -768,7 +776,8 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
       head++;
     } else {  // heapq.heappop
       if (had_pre) {  // the next node is (almost always) the root the previous pop left behind: its visited-set line is
-        pkey = sk_key(c, sk_u(pre_nd.px), sk_u(pre_nd.py), pre_cr);  // requested now and arrives while the heap is sifted
+        const SokoNode pn = pre_unpack();
+        pkey = sk_key(c, sk_u(pn.px), sk_u(pn.py), pre_cr);  // requested now and arrives while the heap is sifted
         if (c.lane < 8) pgrp = c.vis[pkey.group() * 8 + c.lane];
         have_pgrp = true;
       }
@@ -780,7 +789,7 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
     SokoNode nd;
     SkCrates<NH> cr;
     if (had_pre) {
-      nd = pre_nd;
+      nd = pre_unpack();
       cr = pre_cr;
     } else {
       nd = SokoNode::unpack(c.nodes[cur]);
@@ -793,8 +802,10 @@ __device__ __attribute__((always_inline)) inline bool sk_stage(SokoCtx &c, const
     pre_valid = head < tail;  // BFS: the next queue entry; A*: the heap's new root
     if (pre_valid) {
       pre_cur = b2 < 0 ? bfs_entry(head) : (int)(new_top & 0xFFFFu);
-      pre_nd = SokoNode::unpack(c.nodes[pre_cur]);
+      const uint32_t SK_GLOBAL *rec = (const uint32_t SK_GLOBAL *)(c.nodes + pre_cur);
       pre_cr.load(c, pre_cur);
+      pre_y = rec[1];
+      pre_z = rec[2];
     }
     const int px = nd.px, py = nd.py;
     if (c.lv->ntg == c.ncr && c.ncr > 0 && cr.count_on(c.lv->tgt) == c.ncr) {  // checkWin engine.py:272-280
