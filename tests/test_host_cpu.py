@@ -326,3 +326,56 @@ def test_adapter_lease_returns_its_block_when_the_last_array_is_gone():
     del keep
     gc.collect()
     assert len(free) == 1 and free[0] is block
+
+
+# ------------------------------------------------------------------------------------- the bench line's profile echoes
+def test_bench_echoes_only_profiles_taken_on_these_kernels(monkeypatch):
+    """roofline.traffic / kernel_mean_us are echoes of committed rocprofv3 summaries: accepted when the summary's
+    kernel_sources_sha16 (per kernel family) equals the checkout's, refused -- with the reason -- when it does not."""
+    import bench
+
+    fam2, fam3 = bench.kernel_sources_sha16("2d"), bench.kernel_sources_sha16("3d")
+    assert bench.kernel_sources_sha16() == {"2d": fam2, "3d": fam3} and fam2 != fam3 and len(fam2) == 16
+    # the committed round-6 summary belongs to the committed kernels (tools/finish_round.py wrote both)
+    import json
+    import os
+    s = json.load(open(os.path.join(bench.ROOT, "profiles", "r06_summary.json")))
+    assert s["kernel_sources_sha16"] == {"2d": fam2, "3d": fam3}, "profiles/r06_summary.json was not taken on the kernels of this checkout"
+    assert isinstance(s.get("profiled_at_head"), str) and len(s["profiled_at_head"]) >= 7
+    traffic, source, head = bench.profiled_traffic("binary-narrow", 4096)
+    assert traffic and traffic > 13e6 and "r06_summary.json" in source and head == s["profiled_at_head"]
+    assert bench.profiled_kernel_mean_us("binary-narrow", 4096) > 4.0
+    t3, src3, head3 = bench.profiled_traffic("minecraft_3D_maze-narrow", 1024)
+    assert t3 and "r06_summary.json" in src3 and head3 == s["profiled_at_head"]
+    # other kernels than the profiled ones: nothing is echoed, and the line says why
+    real = bench.kernel_sources_sha16
+    monkeypatch.setattr(bench, "kernel_sources_sha16", lambda family=None: "0" * 16 if family else {"2d": "0" * 16, "3d": "0" * 16})
+    traffic, source, head = bench.profiled_traffic("binary-narrow", 4096)
+    assert traffic is None and head is None and "other kernels" in source and "0" * 16 in source
+    assert bench.profiled_kernel_mean_us("binary-narrow", 4096) is None
+    monkeypatch.setattr(bench, "kernel_sources_sha16", real)
+    # a size that was never profiled: no echo, no reason needed
+    assert bench.profiled_traffic("binary-narrow", 12345)[0] is None
+
+
+def test_kernel_hash_ignores_the_host_side_and_splits_the_families(tmp_path, monkeypatch):
+    """pcgrl_engine.hip (argument checks, allocation, launches) is not part of the kernels' identity; the 3-D header is part of
+    the 3-D family's only."""
+    import shutil
+    import bench
+
+    root = tmp_path / "repo"
+    shutil.copytree(os.path.join(bench.ROOT, "control_pcgrl_amd", "csrc"), root / "control_pcgrl_amd" / "csrc",
+                    ignore=shutil.ignore_patterns("*.so", "*.o", "_obj*"))
+    shutil.copytree(os.path.join(bench.ROOT, "include"), root / "include")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    h2, h3 = bench.kernel_sources_sha16("2d"), bench.kernel_sources_sha16("3d")
+    with open(root / "control_pcgrl_amd" / "csrc" / "pcgrl_engine.hip", "a") as f:
+        f.write("\n// host-side edit\n")
+    assert (bench.kernel_sources_sha16("2d"), bench.kernel_sources_sha16("3d")) == (h2, h3)
+    with open(root / "control_pcgrl_amd" / "csrc" / "pcgrl_kernels3d.h", "a") as f:
+        f.write("\n// 3-D kernel edit\n")
+    assert bench.kernel_sources_sha16("2d") == h2 and bench.kernel_sources_sha16("3d") != h3
+    with open(root / "control_pcgrl_amd" / "csrc" / "pcgrl_kernels2d.h", "a") as f:
+        f.write("\n// 2-D kernel edit\n")
+    assert bench.kernel_sources_sha16("2d") != h2
