@@ -26,6 +26,7 @@ def _bench(*argv, env=None, timeout=900):
     e = dict(os.environ if env is None else env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         e.pop(k, None)
+    e.setdefault("PCGRL_BENCH_RANK_TIMEOUT", "300")  # (a rank that hangs ends itself well inside this test's own timeout)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True,
                        timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
